@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: BASELINE.json configs[1] -- J2 isotropic-hardening (Voce) stress update + vjp
+w.r.t. the material parameters, 10M synthetic Gauss points per GPU, fp64.
+
+A "step" is one pass of the hot path over the resident batch: the fused kernel behind
+`cm_update_and_vjp` (Newton return mapping -> xi, sigma; reverse IFT sweep -> grad[12] reduced on chip),
+plus, for N > 1, one RCCL all-reduce of the 12 gradient doubles.  Points shard across ranks with no
+data-path collective (weak scaling).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "Gauss-point stress-updates/sec (fp64) + grad, 1/2/4/8 MI355X; % HBM roofline"
+BYTES_PER_UPDATE = 280           # read gradu 72 + xi_prev 56 + sigma_bar 48; write xi 56 + sigma 48
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(values, seconds_target=15.0):
+    """The CPU oracle (oracle/cmad_oracle.cpp: nested-dual AD restatement of the reference algorithm,
+    OpenMP over points) on a bounded sample of the same workload, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    from cmad_amd.synthetic import gauss_point_batch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    mat = ol.Material(values)
+    st = ol.newton_settings()
+
+    def run(B):
+        g = gauss_point_batch(B); xp = np.zeros((7, B)); sb = np.random.default_rng(0).normal(size=(6, B))
+        t0 = time.perf_counter()
+        xi, sig, it, cv = mat.update_batch(st, g, xp, nthreads=cores)
+        mat.update_vjp_batch(g, xp, xi, sb, nthreads=cores, want_bars=False)
+        return time.perf_counter() - t0
+
+    probe = 4096 * max(1, cores // 4)
+    t = run(probe)
+    B = int(max(probe, min(4_000_000, probe * seconds_target / max(t, 1e-6))))
+    t = run(B)
+    return {"value": B / t, "unit": "updates/s", "cores": cores, "kind": "port",
+            "sample": f"{B} points of the same synthetic batch (seed 22), oracle update + vjp, {t:.1f} s wall, "
+                      f"OpenMP {cores} threads; CPU restatement of the CMAD path (nested-dual AD), not JAX"}
+
+
+def load_traffic(points):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if int(t.get("points_per_launch", -1)) == int(points):
+            return float(t["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10_000_000, help="Gauss points per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cmad_amd.models.device import DeviceEvaluator, NewtonSettings, build_desc
+    from cmad_amd.synthetic import gauss_point_batch, j2_voce_values
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    distributed = world > 1
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.points
+    values = j2_voce_values()
+    newton = NewtonSettings()                      # newton_solve defaults: 10 iters, 1e-14, no line search
+    desc, info = build_desc(values, newton=newton)
+    ev = DeviceEvaluator(desc, info)
+
+    # resident inputs (disjoint shard per rank: seed + rank)
+    gradu = torch.from_numpy(gauss_point_batch(B, seed=22 + rank)).to(dev)
+    xi_prev = torch.zeros((7, B), dtype=torch.float64, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+    sigma_bar = torch.randn((6, B), dtype=torch.float64, device=dev, generator=gen)
+    out = {"xi": torch.empty((7, B), dtype=torch.float64, device=dev),
+           "sigma": torch.empty((6, B), dtype=torch.float64, device=dev),
+           "grad": torch.empty(12, dtype=torch.float64, device=dev)}
+
+    def step():
+        xi, sig, g = ev.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
+        if distributed:
+            dist.all_reduce(g)
+        return g
+
+    for _ in range(args.warmup):
+        step()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        starts[k].record()                         # events on the stream the kernels are launched on
+        ev.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
+        ends[k].record()
+        if distributed:
+            dist.all_reduce(out["grad"])
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # a cheap self-check so a broken run cannot report a number: all points converged, finite gradient
+    xi, sig, status = ev.update(gradu[:, :65536].contiguous(), xi_prev[:, :65536].contiguous())
+    status = status.cpu().numpy().astype(np.uint32)
+    assert ((status >> 16) & 1).all() and torch.isfinite(out["grad"]).all()
+    plastic_frac = float(((status & 0xFFFF) > 0).mean())
+
+    if rank == 0:
+        n = world
+        value = n * B * args.steps / elapsed
+        achieved = BYTES_PER_UPDATE * B / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": METRIC, "value": value, "unit": "updates/s", "n_gpus": n, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "J2 isotropic-hardening (Voce) stress update + vjp w.r.t. parameters, FULL_3D, "
+                            "synthetic Gauss points fp64 (BASELINE.json configs[1])",
+                "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
+                "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
+                           "line_search_max_evals": newton.line_search["max evals"]},
+                "parallelism": f"dp{n}: disjoint point shards, all-reduce of 12 fp64 gradient entries per step",
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(B),
+                         "kernel": "k_reverse<FULL_3D,J2,noROT,fused update+vjp>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_update": BYTES_PER_UPDATE},
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(values)
+        print(json.dumps(res))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

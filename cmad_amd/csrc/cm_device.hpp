@@ -1,0 +1,643 @@
+// Device-side math of the per-Gauss-point stress update (gfx950, fp64, one point per lane).
+//
+// Everything here is hand-derived closed form -- no AD on the device.  The formulas are checked
+// against the dual-number oracle (oracle/) and torch.func AD in tests/.  Notation:
+//   6-vectors are CMAD's un-weighted [xx,xy,xz,yy,yz,zz] (cmad/models/var_types.py:43-84);
+//   w  = [1,2,2,1,2,1]  multiplicity of a slot in a full 3x3 contraction;
+//   d  = [1,0,0,1,0,1]  diagonal indicator;
+//   gt = d phi~/d s_k   gradient of the effective stress w.r.t. the 6-vector (= w_k * n_k, n the
+//        reference's 3x3 yield normal jax.grad(effective_stress), small_elastic_plastic.py:90);
+//   Ht = d^2 phi~/d s_k d s_l  (6x6 symmetric).
+#pragma once
+#include <stdint.h>
+#include "../../include/cmad_hip.h"
+
+#if defined(CM_HOST_BUILD)
+// Host compilation of the same per-point math, used ONLY by tests/native (CPU sanitizer / debug builds
+// of the kernel arithmetic).  A "wave" is a single lane there.
+#include <cmath>
+#define CM_D inline
+static inline bool __any(bool p) { return p; }
+using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::exp; using std::pow; using std::isfinite;
+#else
+#include <hip/hip_runtime.h>
+#define CM_D __device__ __forceinline__
+#endif
+
+namespace cm {
+
+constexpr double kIW[6] = {1.0, 0.5, 0.5, 1.0, 0.5, 1.0};   // 1 / w_k
+constexpr double kW[6] = {1.0, 2.0, 2.0, 1.0, 2.0, 1.0};
+constexpr bool kDiag[6] = {true, false, false, true, false, true};
+
+template <int DEF> struct Dims;
+template <> struct Dims<CM_FULL_3D> { static constexpr int NX = 7, NU = 9, NE = 0; };
+template <> struct Dims<CM_PLANE_STRESS> { static constexpr int NX = 8, NU = 4, NE = 1; };
+
+// ---- symmetric 3x3 congruences on 6-vectors --------------------------------------------------
+// out = V(M^T T(a) M) (TRANSPOSE_FIRST) or V(M T(a) M^T)
+template <bool TRANSPOSE_FIRST>
+CM_D void congruence(const double* M, const double a[6], double out[6]) {
+    const double A[3][3] = {{a[0], a[1], a[2]}, {a[1], a[3], a[4]}, {a[2], a[4], a[5]}};
+    double T[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += A[i][k] * (TRANSPOSE_FIRST ? M[3 * k + j] : M[3 * j + k]);
+            T[i][j] = s;                       // A M   or   A M^T
+        }
+    constexpr int I6[6] = {0, 0, 0, 1, 1, 2}, J6[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s += (TRANSPOSE_FIRST ? M[3 * k + I6[r]] : M[3 * I6[r] + k]) * T[k][J6[r]];
+        out[r] = s;                            // M^T A M   or   M A M^T
+    }
+}
+
+// total strain 6-vector in the material frame from grad u
+// (cmad/models/small_elastic_plastic.py:38-62, kinematics.py:10-26; the out-of-plane stretch of
+//  PLANE_STRESS enters separately through z, see strain_z)
+template <int DEF, bool ROT>
+CM_D void strain_from_gradu(const cm_model_desc& m, const double* G, double eg[6]) {
+    double E[6];
+    if constexpr (DEF == CM_FULL_3D) {
+        E[0] = G[0]; E[1] = 0.5 * (G[1] + G[3]); E[2] = 0.5 * (G[2] + G[6]);
+        E[3] = G[4]; E[4] = 0.5 * (G[5] + G[7]); E[5] = G[8];
+    } else {
+        E[0] = G[0]; E[1] = 0.5 * (G[1] + G[2]); E[2] = 0.0; E[3] = G[3]; E[4] = 0.0; E[5] = 0.0;
+    }
+    if constexpr (ROT) congruence<true>(m.Q, E, eg);
+    else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) eg[k] = E[k];
+    }
+}
+
+// PLANE_STRESS: d(material strain)/d F33 = V(Q^T e3 e3^T Q) = V(q3 q3^T), q3 = third row of Q
+template <bool ROT>
+CM_D void strain_z(const cm_model_desc& m, double z[6]) {
+    if constexpr (ROT) {
+        const double a = m.Q[6], b = m.Q[7], c = m.Q[8];
+        z[0] = a * a; z[1] = a * b; z[2] = a * c; z[3] = b * b; z[4] = b * c; z[5] = c * c;
+    } else {
+        z[0] = z[1] = z[2] = z[3] = z[4] = 0.0; z[5] = 1.0;
+    }
+}
+
+// ---- effective stress: value, gradient gt[6], Hessian Ht[6][6] --------------------------------
+// J2   cmad/models/effective_stress.py:30-37   phi = sqrt(s^T A s), A = 3/2 (W - d d^T / 3)
+// Hill cmad/models/effective_stress.py:40-52   phi = sqrt(s^T A s), A from F,G,H,L,M,N
+struct QuadForm { double a00, a33, a55, a03, a05, a35, a11, a22, a44; };
+
+template <int YK>
+CM_D QuadForm quad_form(const cm_model_desc& m) {
+    QuadForm q;
+    if constexpr (YK == CM_YIELD_J2) {
+        q.a00 = q.a33 = q.a55 = 1.0; q.a03 = q.a05 = q.a35 = -0.5; q.a11 = q.a22 = q.a44 = 3.0;
+    } else {
+        const double F = m.yc[0], G = m.yc[1], H = m.yc[2], L = m.yc[3], M = m.yc[4], N = m.yc[5];
+        q.a00 = G + H; q.a33 = F + H; q.a55 = F + G; q.a03 = -H; q.a05 = -G; q.a35 = -F;
+        q.a11 = 2.0 * N; q.a22 = 2.0 * M; q.a44 = 2.0 * L;
+    }
+    return q;
+}
+
+template <int YK, bool HESS>
+CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
+    if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
+        const QuadForm q = quad_form<YK>(m);
+        double As[6];
+        As[0] = q.a00 * s[0] + q.a03 * s[3] + q.a05 * s[5];
+        As[3] = q.a03 * s[0] + q.a33 * s[3] + q.a35 * s[5];
+        As[5] = q.a05 * s[0] + q.a35 * s[3] + q.a55 * s[5];
+        As[1] = q.a11 * s[1]; As[2] = q.a22 * s[2]; As[4] = q.a44 * s[4];
+        double qq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) qq += s[k] * As[k];
+        phi = sqrt(qq);
+        const double ip = 1.0 / phi;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gt[k] = As[k] * ip;
+        if constexpr (HESS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int l = 0; l < 6; ++l) Ht[k][l] = -gt[k] * gt[l] * ip;
+            Ht[0][0] += q.a00 * ip; Ht[3][3] += q.a33 * ip; Ht[5][5] += q.a55 * ip;
+            Ht[0][3] += q.a03 * ip; Ht[3][0] += q.a03 * ip;
+            Ht[0][5] += q.a05 * ip; Ht[5][0] += q.a05 * ip;
+            Ht[3][5] += q.a35 * ip; Ht[5][3] += q.a35 * ip;
+            Ht[1][1] += q.a11 * ip; Ht[2][2] += q.a22 * ip; Ht[4][4] += q.a44 * ip;
+        }
+    } else if constexpr (YK == CM_YIELD_HOSFORD) {
+        // cmad/models/effective_stress.py:167-177: phi = vm (1/2 sum |d_i/vm|^a)^(1/a) with
+        // d = (s00-s11, s11-s22, s22-s00); the vm scaling cancels analytically, so
+        // phi = (1/2 sum |d_i|^a)^(1/a).  Scaled here by max|d_i| instead (same purpose: no overflow).
+        const double a = m.yc[0];
+        const double dd[3] = {s[0] - s[3], s[3] - s[5], s[5] - s[0]};
+        const double t0 = fabs(dd[0]), t1 = fabs(dd[1]), t2 = fabs(dd[2]);
+        const double mx = fmax(t0, fmax(t1, t2));
+        const double u[3] = {t0 / mx, t1 / mx, t2 / mx};
+        const double S = 0.5 * (pow(u[0], a) + pow(u[1], a) + pow(u[2], a));
+        const double Sr = pow(S, 1.0 / a);
+        phi = mx * Sr;
+        double p[3], r[3], sg[3], ram2[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            r[i] = u[i] / Sr;                                  // |d_i| / phi
+            sg[i] = (dd[i] > 0.0) ? 1.0 : ((dd[i] < 0.0) ? -1.0 : 0.0);
+            ram2[i] = pow(r[i], a - 2.0);
+            p[i] = 0.5 * ram2[i] * r[i] * sg[i];               // d phi / d d_i
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gt[k] = 0.0;
+        gt[0] = p[0] - p[2]; gt[3] = p[1] - p[0]; gt[5] = p[2] - p[1];
+        if constexpr (HESS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int l = 0; l < 6; ++l) Ht[k][l] = 0.0;
+            double Hd[3][3];
+            const double ip = 1.0 / phi;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Hd[i][j] = 0.5 * (a - 1.0) * ram2[i] * ((i == j ? 1.0 : 0.0) - sg[i] * r[i] * p[j]) * ip;
+            // D = d d / d (s0,s3,s5): rows d_i, cols (0,3,5)
+            constexpr double D[3][3] = {{1.0, -1.0, 0.0}, {0.0, 1.0, -1.0}, {-1.0, 0.0, 1.0}};
+            constexpr int IDX[3] = {0, 3, 5};
+#pragma unroll
+            for (int A = 0; A < 3; ++A)
+#pragma unroll
+                for (int Bc = 0; Bc < 3; ++Bc) {
+                    double sH = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) sH += D[i][A] * Hd[i][j] * D[j][Bc];
+                    Ht[IDX[A]][IDX[Bc]] = sH;
+                }
+        }
+    }
+}
+
+// ---- hardening  cmad/models/hardening.py:9-34 --------------------------------------------------
+struct Hard { double H, dH, expo; };
+CM_D Hard hardening(const cm_model_desc& m, double alpha) {
+    Hard h; h.H = 0.0; h.dH = 0.0; h.expo = 0.0;
+    if (m.has_voce) {
+        h.expo = exp(-m.voce_D * alpha);
+        h.H += m.voce_S * (1.0 - h.expo);
+        h.dH += m.voce_S * m.voce_D * h.expo;
+    }
+    if (m.has_linear) { h.H += m.lin_K * alpha; h.dH += m.lin_K; }
+    return h;
+}
+
+// ---- state evaluation ----------------------------------------------------------------------
+// Everything the residual and its derivatives need at one iterate.
+template <int DEF>
+struct Eval {
+    double e[6];      // elastic strain (material frame)
+    double s[6];      // material Cauchy stress
+    double tr;        // tr(e)
+    double phi, f, dgam;
+    double gt[6];
+    bool plastic;
+    Hard hd;
+};
+
+// e = eg (+ (F33-1) z) - v ; s = lambda tr(e) d + 2 mu e   (elastic_stress.py:14-21)
+template <int DEF>
+CM_D void strain_stress(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, Eval<DEF>& ev) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double e = eg[k] - x[k];
+        if constexpr (DEF == CM_PLANE_STRESS) e += (x[7] - 1.0) * z[k];
+        ev.e[k] = e;
+    }
+    ev.tr = ev.e[0] + ev.e[3] + ev.e[5];
+    const double twomu = 2.0 * m.mu;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ev.s[k] = twomu * ev.e[k] + (kDiag[k] ? m.lambda * ev.tr : 0.0);
+}
+
+// residual C(x) of cmad/models/small_elastic_plastic.py:237-302 with the branch select of
+// cmad/models/paths.py:26-27 evaluated at the current iterate.  Ht filled when HESS.
+template <int DEF, int YK, bool HESS>
+CM_D void residual(const cm_model_desc& m, const double eg[6], const double z[6],
+                   const double* x, const double* xp, Eval<DEF>& ev, double* C, double Ht[6][6]) {
+    constexpr int NX = Dims<DEF>::NX;
+    strain_stress<DEF>(m, eg, z, x, ev);
+    yield_eval<YK, HESS>(m, ev.s, ev.phi, ev.gt, Ht);
+    ev.hd = hardening(m, x[6]);
+    const double i2mu = 0.5 / m.mu;
+    ev.f = (ev.phi - (m.Y + ev.hd.H)) * i2mu;
+    ev.dgam = x[6] - xp[6];
+    ev.plastic = (ev.f > m.yield_tol) || (fabs(ev.f) < m.yield_tol);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double ce = x[k] - xp[k];
+        C[k] = ev.plastic ? (ce - ev.dgam * ev.gt[k] * kIW[k]) : ce;
+    }
+    C[6] = ev.plastic ? ev.f : ev.dgam;
+    if constexpr (DEF == CM_PLANE_STRESS) {
+        // (Q s Q^T)[2][2] / 2mu = sum_k w_k z_k s_k / 2mu  (small_elastic_plastic.py:288-300)
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r += kW[k] * z[k] * ev.s[k];
+        C[NX - 1] = r * i2mu;
+    }
+}
+
+// A = dC/dx at the evaluated state (needs Ht).  TRANSPOSED stores A^T (for adjoint solves).
+template <int DEF, bool TRANSPOSED>
+CM_D void jacobian_x(const cm_model_desc& m, const double z[6], const Eval<DEF>& ev, const double Ht[6][6],
+                     double (&A)[Dims<DEF>::NX][Dims<DEF>::NX]) {
+    constexpr int NX = Dims<DEF>::NX;
+    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+#define CM_A(r, c) (TRANSPOSED ? A[c][r] : A[r][c])
+#pragma unroll
+    for (int r = 0; r < NX; ++r)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) CM_A(r, c) = (r == c) ? 1.0 : 0.0;
+    if (ev.plastic) {
+        double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double hd = Ht[k][0] + Ht[k][3] + Ht[k][5];
+            const double sc = ev.dgam * kIW[k];
+#pragma unroll
+            for (int l = 0; l < 6; ++l)
+                CM_A(k, l) += sc * (twomu * Ht[k][l] + (kDiag[l] ? lam * hd : 0.0));
+            CM_A(k, 6) = -ev.gt[k] * kIW[k];
+            CM_A(6, k) = -(ev.gt[k] + (kDiag[k] ? lam * gd * i2mu : 0.0));
+        }
+        CM_A(6, 6) = -ev.hd.dH * i2mu;
+    }
+    if constexpr (DEF == CM_PLANE_STRESS) {
+        // Cel z and Cel (w o z);  z0 + z3 + z5 = |q3|^2
+        const double zt = z[0] + z[3] + z[5];
+        double cz[6], czw[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            cz[k] = twomu * z[k] + (kDiag[k] ? lam * zt : 0.0);
+            czw[k] = twomu * kW[k] * z[k] + (kDiag[k] ? lam * zt : 0.0);
+        }
+        double zcz = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) zcz += kW[k] * z[k] * cz[k];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) CM_A(7, l) = -czw[l] * i2mu;
+        CM_A(7, 6) = 0.0;
+        CM_A(7, 7) = zcz * i2mu;
+        if (ev.plastic) {
+            double gcz = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                double hcz = 0.0;
+#pragma unroll
+                for (int l = 0; l < 6; ++l) hcz += Ht[k][l] * cz[l];
+                CM_A(k, 7) = -ev.dgam * kIW[k] * hcz;
+                gcz += ev.gt[k] * cz[k];
+            }
+            CM_A(6, 7) = gcz * i2mu;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) CM_A(k, 7) = 0.0;
+        }
+    }
+#undef CM_A
+}
+
+// ---- dense N x N solves, fully unrolled, no pivoting ---------------------------------------------
+// (the leading 6x6 block is I + dgam * (PSD-like); a vanishing pivot is reported)
+template <int N>
+CM_D bool lu_factor(double (&A)[N][N]) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double piv = A[k][k];
+        ok = ok && (fabs(piv) > 1e-300);
+        const double ip = 1.0 / piv;
+        A[k][k] = ip;                       // store reciprocal pivot
+#pragma unroll
+        for (int r = k + 1; r < N; ++r) {
+            const double l = A[r][k] * ip;
+            A[r][k] = l;
+#pragma unroll
+            for (int c = k + 1; c < N; ++c) A[r][c] -= l * A[k][c];
+        }
+    }
+    return ok;
+}
+template <int N>
+CM_D void lu_subst(const double (&A)[N][N], double (&b)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int r = k + 1; r < N; ++r) b[r] -= A[r][k] * b[k];
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        double s = b[k];
+#pragma unroll
+        for (int c = k + 1; c < N; ++c) s -= A[k][c] * b[c];
+        b[k] = s * A[k][k];
+    }
+}
+
+template <int N>
+CM_D double norm2(const double* v) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) s += v[k] * v[k];
+    return sqrt(s);
+}
+template <int N>
+CM_D double dot(const double* a, const double* b) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) s += a[k] * b[k];
+    return s;
+}
+
+// cmad/util/line_search.py:74-85
+CM_D double quad_min(double phi0, double dphi0, double a, double phi) {
+    const double denom = 2.0 * (phi - phi0 - dphi0 * a);
+    const double safe = (denom == 0.0) ? 1.0 : denom;
+    return (denom == 0.0) ? 0.5 * a : (-dphi0 * a * a / safe);
+}
+
+// ---- local Newton ------------------------------------------------------------------------------
+// make_newton_solve (cmad/models/nonlinear_solver.py:102-155) with the quadratic Armijo line search
+// of cmad/util/line_search.py:95-189 (ls_max_evals > 0) or the plain Newton of newton_solve
+// (:14-85, ls_max_evals == 0).  One point per lane; wave-level ballots (__any) drive the loops so an
+// all-elastic / all-converged wavefront leaves at once and the rest iterate under the exec mask.
+// Returns the status word.
+template <int DEF, int YK>
+CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x,
+                     bool lane_valid) {
+    constexpr int NX = Dims<DEF>::NX;
+    Eval<DEF> ev;
+    double C[NX], Ht[6][6];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) x[k] = xp[k];
+    residual<DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
+    const double norm0 = norm2<NX>(C);
+    int it = 0;
+    bool running = lane_valid;
+    uint32_t flags = 0;
+    for (;;) {
+        const double nrm = norm2<NX>(C);
+        const double rel = nrm / norm0;
+        const bool conv = (rel < m.rel_tol) || (nrm < m.abs_tol);
+        if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
+        if (running && it >= m.max_iters) running = false;
+        if (!__any(running)) break;
+        if (running) {
+            double A[NX][NX], delta[NX];
+            residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
+            jacobian_x<DEF, false>(m, z, ev, Ht, A);
+            if (!lu_factor<NX>(A)) flags |= CM_STATUS_SINGULAR;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) delta[k] = C[k];
+            lu_subst<NX>(A, delta);
+            if (m.ls_max_evals <= 0) {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) x[k] -= delta[k];
+                residual<DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
+            } else {
+                const double cc = dot<NX>(C, C);
+                const double phi0 = 0.5 * cc, dphi0 = -cc, armijo = m.ls_c1 * dphi0;
+                int n = 0;
+                double alpha = 1.0, best_alpha = 1.0, best_phi = INFINITY;
+                bool accepted = false;
+                double Cbest[NX], Ct[NX], xt[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) { Cbest[k] = C[k]; Ct[k] = C[k]; }
+                bool ls = true;
+                while (__any(ls)) {
+                    if (ls) {
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) xt[k] = x[k] - alpha * delta[k];
+                        Eval<DEF> et;
+                        residual<DEF, YK, false>(m, eg, z, xt, xp, et, Ct, Ht);
+                        const double phi = 0.5 * dot<NX>(Ct, Ct);
+                        const bool finite = isfinite(phi);
+                        if (finite && phi < best_phi) {
+                            best_alpha = alpha; best_phi = phi;
+#pragma unroll
+                            for (int k = 0; k < NX; ++k) Cbest[k] = Ct[k];
+                        }
+                        accepted = finite && (phi <= phi0 + alpha * armijo);
+                        const double am = quad_min(phi0, dphi0, alpha, phi);
+                        const double ac = fmin(fmax(am, m.ls_lo * alpha), m.ls_hi * alpha);
+                        if (!accepted) alpha = finite ? ac : 0.5 * alpha;
+                        ++n;
+                        ls = (n < m.ls_max_evals) && !accepted;
+                    }
+                }
+                const double ra = accepted ? alpha : best_alpha;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) { x[k] -= ra * delta[k]; C[k] = accepted ? Ct[k] : Cbest[k]; }
+            }
+            ++it;
+        }
+    }
+    return flags | (uint32_t)it;
+}
+
+// global Cauchy stress 6-vector from the material one (small_elastic_plastic.py:318-319)
+template <bool ROT>
+CM_D void to_global(const cm_model_desc& m, const double s[6], double out[6]) {
+    if constexpr (ROT) congruence<false>(m.Q, s, out);
+    else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = s[k];
+    }
+}
+// pull a cotangent of the 6 stored global entries back to the material 6-vector:
+// sbar_m[k] = sum_r sbar[r] d sig_g[r] / d s[k] = w_k V(Q^T Sbar Q)_k with Sbar_ij = sbar_ij / w_ij
+template <bool ROT>
+CM_D void cotangent_to_material(const cm_model_desc& m, const double sb[6], double out[6]) {
+    if constexpr (ROT) {
+        double t[6], r[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = sb[k] * kIW[k];
+        congruence<true>(m.Q, t, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = kW[k] * r[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = sb[k];
+    }
+}
+
+// Cel a = 2 mu a + lambda (a0+a3+a5) d
+CM_D void apply_cel(const cm_model_desc& m, const double a[6], double out[6]) {
+    const double t = m.lambda * (a[0] + a[3] + a[5]), twomu = 2.0 * m.mu;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] = twomu * a[k] + (kDiag[k] ? t : 0.0);
+}
+
+// ---- reverse sweep at a converged state -------------------------------------------------------------
+// Given the cotangent sbar_m of the MATERIAL stress 6-vector and an incoming cotangent xin of xi
+// (NULL = 0), solve  lam = A^-T ( (d s/d x)^T sbar_m + xin )  and return
+//   pbar[j]  = sbar_m . d s/d p_j - lam . dC/dp_j            (KP order, CM_NUM_PARAMS entries)
+//   xpbar    = -(dC/dx_prev)^T lam
+//   egbar    = Cel sbar_m - (dC/d eg)^T lam                   (cotangent of the material total strain)
+// This is the transpose of the IFT rule cmad/models/nonlinear_solver.py:158-171 and one step of
+// cmad/objectives/mp_objective.py:112-142 (with phi = -lam, history = -xin).
+template <int DEF, int YK>
+CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double z[6],
+                        const double* x, const double* xp, const double sbm[6], const double* xin,
+                        double* pbar, double* xpbar, double* egbar) {
+    constexpr int NX = Dims<DEF>::NX;
+    Eval<DEF> ev;
+    double C[NX], Ht[6][6], At[NX][NX], lam[NX];
+    residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
+    jacobian_x<DEF, true>(m, z, ev, Ht, At);
+    const bool ok = lu_factor<NX>(At);
+    double csb[6];
+    apply_cel(m, sbm, csb);                                  // Cel sbar_m (Cel symmetric)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lam[k] = -csb[k];            // d s / d v = -Cel
+    lam[6] = 0.0;
+    if constexpr (DEF == CM_PLANE_STRESS) lam[7] = dot<6>(z, csb);   // d s / d F33 = Cel z
+    if (xin) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) lam[k] += xin[k];
+    }
+    lu_subst<NX>(At, lam);
+    const double i2mu = 0.5 / m.mu;
+    // ---- u_k = -dgam lam_k / w_k (plastic rows), hu = Ht u
+    double u[6], hu[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = ev.plastic ? (-ev.dgam * lam[k] * kIW[k]) : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) s += Ht[k][l] * u[l];
+        hu[k] = ev.plastic ? s : 0.0;
+    }
+    const double lam6 = ev.plastic ? lam[6] : 0.0;           // elastic: dC_6/d(anything but x) = 0
+    if (pbar) {
+        const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5], ge = dot<6>(ev.gt, ev.e);
+        const double hud = hu[0] + hu[3] + hu[5], hue = dot<6>(hu, ev.e);
+        const double sbd = sbm[0] + sbm[3] + sbm[5], sbe = dot<6>(sbm, ev.e);
+        // lam . dC/dp
+        double cl = hud * ev.tr + lam6 * gd * ev.tr * i2mu;                        // lambda
+        double cm_ = 2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f / m.mu);           // mu
+        if constexpr (DEF == CM_PLANE_STRESS) {
+            const double zt = z[0] + z[3] + z[5];
+            double zwe = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) zwe += kW[k] * z[k] * ev.e[k];
+            cl += lam[7] * zt * ev.tr * i2mu;
+            cm_ += lam[7] * (2.0 * zwe * i2mu - C[7] / m.mu);
+        }
+        pbar[CM_P_LAMBDA] = sbd * ev.tr - cl;
+        pbar[CM_P_MU] = 2.0 * sbe - cm_;
+        pbar[CM_P_Y] = lam6 * i2mu;
+        pbar[CM_P_VOCE_S] = m.has_voce ? lam6 * (1.0 - ev.hd.expo) * i2mu : 0.0;
+        pbar[CM_P_VOCE_D] = m.has_voce ? lam6 * m.voce_S * x[6] * ev.hd.expo * i2mu : 0.0;
+        pbar[CM_P_LIN_K] = m.has_linear ? lam6 * x[6] * i2mu : 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pbar[CM_P_YC0 + j] = 0.0;
+        if constexpr (YK == CM_YIELD_HILL) {
+            // phi = sqrt(sum_j c_j q_j(s));  d phi/d c_j = q_j / (2 phi);
+            // d gt/d c_j = (dA/dc_j) s / phi - gt q_j / (2 phi^2)
+            if (ev.plastic) {
+                const double* s = ev.s;
+                const double ip = 1.0 / ev.phi;
+                const double d12 = s[3] - s[5], d20 = s[5] - s[0], d01 = s[0] - s[3];
+                const double qj[6] = {d12 * d12, d20 * d20, d01 * d01, 2.0 * s[4] * s[4], 2.0 * s[2] * s[2], 2.0 * s[1] * s[1]};
+                // u . (dA/dc_j) s
+                const double uAs[6] = {(u[3] - u[5]) * d12, (u[5] - u[0]) * d20, (u[0] - u[3]) * d01,
+                                       2.0 * u[4] * s[4], 2.0 * u[2] * s[2], 2.0 * u[1] * s[1]};
+                const double ug = dot<6>(u, ev.gt);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double ldc = uAs[j] * ip - ug * qj[j] * 0.5 * ip * ip + lam6 * qj[j] * 0.5 * ip * i2mu;
+                    pbar[CM_P_YC0 + j] = -ldc;
+                }
+            }
+        }
+    }
+    if (xpbar) {
+        // plastic: dC_k/dv_prev = -delta, dC_k/dalpha_prev = +n_k ; elastic: -I on the first 7
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xpbar[k] = lam[k];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += ev.gt[k] * kIW[k] * lam[k];
+        xpbar[6] = ev.plastic ? -s : lam[6];
+        if constexpr (DEF == CM_PLANE_STRESS) xpbar[7] = 0.0;
+    }
+    if (egbar) {
+        // dC_k/deg_l = -dgam/w_k (Ht Cel)_kl ; dC_6/deg_l = (gt Cel)_l / 2mu ; PS row: (Cel (w o z))_l / 2mu
+        double t[6], ct[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = hu[k] + lam6 * ev.gt[k] * i2mu;
+        if constexpr (DEF == CM_PLANE_STRESS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t[k] += lam[7] * kW[k] * z[k] * i2mu;
+        }
+        apply_cel(m, t, ct);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) egbar[k] = csb[k] - ct[k];
+    }
+    return ok;
+}
+
+// ---- forward tangent at a converged state -----------------------------------------------------------
+// T[r][l] = d s_r / d eg_l  (material stress w.r.t. material total strain), IFT rule
+// cmad/models/nonlinear_solver.py:158-171:  dx/deg = -A^-1 dC/deg ; ds/deg = Cel (I - dv/deg + z dF33/deg)
+template <int DEF, int YK>
+CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double z[6],
+                        const double* x, const double* xp, double (&T)[6][6]) {
+    constexpr int NX = Dims<DEF>::NX;
+    Eval<DEF> ev;
+    double C[NX], Ht[6][6], A[NX][NX];
+    residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
+    jacobian_x<DEF, false>(m, z, ev, Ht, A);
+    const bool ok = lu_factor<NX>(A);
+    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        double b[NX];
+        // b = -dC/deg_l
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double hd = Ht[k][0] + Ht[k][3] + Ht[k][5];
+            b[k] = ev.plastic ? ev.dgam * kIW[k] * (twomu * Ht[k][l] + (kDiag[l] ? lam * hd : 0.0)) : 0.0;
+        }
+        b[6] = ev.plastic ? -(ev.gt[l] + (kDiag[l] ? lam * gd * i2mu : 0.0)) : 0.0;
+        if constexpr (DEF == CM_PLANE_STRESS) {
+            const double zt = z[0] + z[3] + z[5];
+            b[7] = -(twomu * kW[l] * z[l] + (kDiag[l] ? lam * zt : 0.0)) * i2mu;
+        }
+        lu_subst<NX>(A, b);                                  // b = dx/deg_l
+        double de[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            de[k] = ((k == l) ? 1.0 : 0.0) - b[k];
+            if constexpr (DEF == CM_PLANE_STRESS) de[k] += z[k] * b[7];
+        }
+        double ds[6];
+        apply_cel(m, de, ds);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) T[r][l] = ds[r];
+    }
+    return ok;
+}
+
+}  // namespace cm

@@ -1,0 +1,403 @@
+// Kernels and C-ABI of the batched constitutive-model evaluator (see include/cmad_hip.h).
+// gfx950 only.  One Gauss point per lane; SoA arrays so that lane b of a wavefront reads
+// element [k*B + b] -> every global access is a 512-byte contiguous row per wave instruction.
+#include <hip/hip_runtime.h>
+#include "cm_device.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;           // 4 wavefronts
+constexpr int kRed = 1 + CM_NUM_PARAMS;
+
+using namespace cm;
+
+template <int N>
+__device__ __forceinline__ void load_soa(const double* __restrict__ p, int64_t B, int64_t b, double* out) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = p[(int64_t)k * B + b];
+}
+template <int N>
+__device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, int64_t b, const double* v) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[(int64_t)k * B + b] = v[k];
+}
+
+// ---- cm_update / cm_update_tangent ----------------------------------------------------------------
+template <int DEF, int YK, bool ROT, bool TANGENT>
+__global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ xi_prev,
+        double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = b0 < B;
+    const int64_t b = valid ? b0 : B - 1;          // tail lanes shadow the last point, never store
+    double G[NU], xp[NX], x[NX], eg[6], z[6];
+    load_soa<NU>(gradu, B, b, G);
+    load_soa<NX>(xi_prev, B, b, xp);
+    strain_from_gradu<DEF, ROT>(m, G, eg);
+    strain_z<ROT>(m, z);
+    uint32_t st = newton<DEF, YK>(m, eg, z, xp, x, valid);
+    Eval<DEF> ev;
+    strain_stress<DEF>(m, eg, z, x, ev);
+    if (status) {
+        // branch at the returned state (informational)
+        double phi, gt[6], Ht[6][6];
+        yield_eval<YK, false>(m, ev.s, phi, gt, Ht);
+        const double f = (phi - (m.Y + hardening(m, x[6]).H)) * 0.5 / m.mu;
+        if ((f > m.yield_tol) || (fabs(f) < m.yield_tol)) st |= CM_STATUS_PLASTIC;
+    }
+    double sg[6];
+    to_global<ROT>(m, ev.s, sg);
+    if (valid) {
+        store_soa<NX>(xi, B, b, x);
+        if (sigma) store_soa<6>(sigma, B, b, sg);
+        if (status) status[b] = st;
+    }
+    if constexpr (TANGENT) {
+        double T[6][6];
+        const bool ok = tangent_point<DEF, YK>(m, eg, z, x, xp, T);
+        if (!ok && valid && status) status[b] = st | CM_STATUS_SINGULAR;
+        // d sig_g / d G_c = Rg T Rm dE/dG_c : push each unit grad-u direction through
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            double Gd[NU], dm[6], t[6], tg[6];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gd, dm);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < 6; ++l) s += T[r][l] * dm[l];
+                t[r] = s;
+            }
+            to_global<ROT>(m, t, tg);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) dsig[(int64_t)(r * NU + c) * B + b] = tg[r];
+            }
+        }
+    }
+}
+
+// ---- block reduction of NV doubles per lane into partials[blockIdx][NV] ----------------------------
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double* v, double* __restrict__ partials) {
+    __shared__ double sh[kBlock / 64][NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double a = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        v[k] = a;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sh[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
+        partials[(int64_t)blockIdx.x * NV + threadIdx.x] = s;
+    }
+}
+
+// final deterministic reduction: one block, fixed order.  out[k] (+)= sum_blocks partials[blk][k]
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ partials, int64_t nblocks,
+                                                   double* __restrict__ out, int out_offset, int accumulate) {
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    for (int64_t i = threadIdx.x; i < nblocks; i += kBlock) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] += partials[i * NV + k];
+    }
+    __shared__ double sh[kBlock / 64][NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double a = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        acc[k] = a;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sh[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
+        const int o = out_offset + threadIdx.x;
+        out[o] = accumulate ? out[o] + s : s;
+    }
+}
+
+// ---- cm_update_vjp / cm_objective_grad / cm_adjoint_step ----------------------------------------------
+// MODE 0: vjp for a given sigma_bar (xi given, converged)
+// MODE 1: fused update + calibration QoI + gradient (xi computed here)
+// MODE 2: adjoint step (xi given; QoI cotangent + incoming history)
+// MODE 3: fused update + vjp for a given sigma_bar (xi and sigma computed and stored here)
+struct Wsq { double w[6]; };
+
+template <int DEF, int YK, bool ROT, int MODE>
+__global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi_in,
+        const double* __restrict__ sbar_or_data, Wsq wsq, const double* __restrict__ hist_in,
+        double* __restrict__ xi_out, double* __restrict__ sigma_out, double* __restrict__ xpbar_out,
+        double* __restrict__ gbar_out, double* __restrict__ partials) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = b0 < B;
+    const int64_t b = valid ? b0 : B - 1;
+    double G[NU], xp[NX], x[NX], eg[6], z[6], sd[6];
+    load_soa<NU>(gradu, B, b, G);
+    load_soa<NX>(xi_prev, B, b, xp);
+    load_soa<6>(sbar_or_data, B, b, sd);
+    strain_from_gradu<DEF, ROT>(m, G, eg);
+    strain_z<ROT>(m, z);
+    if constexpr (MODE == 1 || MODE == 3) {
+        newton<DEF, YK>(m, eg, z, xp, x, valid);
+        if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
+        if constexpr (MODE == 3) {
+            if (sigma_out) {
+                Eval<DEF> ev;
+                strain_stress<DEF>(m, eg, z, x, ev);
+                double sg[6];
+                to_global<ROT>(m, ev.s, sg);
+                if (valid) store_soa<6>(sigma_out, B, b, sg);
+            }
+        }
+    } else {
+        load_soa<NX>(xi_in, B, b, x);
+    }
+    double red[kRed];
+    double sb[6];
+    red[0] = 0.0;
+    if constexpr (MODE == 0 || MODE == 3) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sb[k] = sd[k];
+    } else {
+        // J = 1/2 sum_r wsq_r (sig_r - data_r)^2 ;  sbar_r = wsq_r (sig_r - data_r)   (qois/calibration.py:56-66)
+        Eval<DEF> ev;
+        strain_stress<DEF>(m, eg, z, x, ev);
+        double sg[6];
+        to_global<ROT>(m, ev.s, sg);
+        double J = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double mm = sg[k] - sd[k];
+            sb[k] = wsq.w[k] * mm;
+            J += 0.5 * sb[k] * mm;
+        }
+        red[0] = J;
+    }
+    double sbm[6], xin[NX], xpbar[NX], egbar[6];
+    cotangent_to_material<ROT>(m, sb, sbm);
+    const double* xinp = nullptr;
+    if constexpr (MODE == 2) {
+        if (hist_in) {
+            load_soa<NX>(hist_in, B, b, xin);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xin[k] = -xin[k];       // history vector = -(cotangent of xi)
+            xinp = xin;
+        }
+    }
+    reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xinp, &red[1], (xpbar_out ? xpbar : nullptr),
+                           (gbar_out ? egbar : nullptr));
+    if (xpbar_out && valid) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xpbar[k] = -xpbar[k];   // back to history-vector sign
+        }
+        store_soa<NX>(xpbar_out, B, b, xpbar);
+    }
+    if (gbar_out) {
+        // cotangent of grad u: Gbar_c = egbar . d eg / d G_c
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            double Gd[NU], dm[6];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gd, dm);
+            if (valid) gbar_out[(int64_t)c * B + b] = dot<6>(egbar, dm);
+        }
+    }
+    if (!valid) {
+#pragma unroll
+        for (int k = 0; k < kRed; ++k) red[k] = 0.0;
+    }
+    block_reduce_store<kRed>(red, partials);
+}
+
+// ---- dispatch --------------------------------------------------------------------------------------
+inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
+
+inline bool supported(const cm_model_desc* m) {
+    if (m->model_kind != CM_SMALL_ELASTIC_PLASTIC) return false;
+    if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS) return false;
+    if (m->yield_kind != CM_YIELD_J2 && m->yield_kind != CM_YIELD_HILL && m->yield_kind != CM_YIELD_HOSFORD) return false;
+    return true;
+}
+
+// calls F.template operator()<DEF, YK, ROT>() for the runtime (def_type, yield_kind, rotation) triple
+template <class F>
+inline void dispatch(const cm_model_desc* m, F&& f) {
+    const bool rot = !m->rotation_is_identity;
+#define CM_CASE(D, Y) \
+    if (m->def_type == D && m->yield_kind == Y) { if (rot) f.template operator()<D, Y, true>(); else f.template operator()<D, Y, false>(); return; }
+    CM_CASE(CM_FULL_3D, CM_YIELD_J2)
+    CM_CASE(CM_FULL_3D, CM_YIELD_HILL)
+    CM_CASE(CM_FULL_3D, CM_YIELD_HOSFORD)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_J2)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_HILL)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
+#undef CM_CASE
+}
+
+int g_last_hip_error = 0;
+inline int check_launch() {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return CM_ERR_LAUNCH; }
+    return CM_OK;
+}
+
+template <bool TANGENT>
+int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+                  double* xi, double* sigma, double* dsig, uint32_t* status, void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m)) return CM_ERR_UNSUPPORTED;
+    if (B == 0) return CM_OK;                       // empty batch: nothing to read or write
+    if (!gradu || !xi_prev || !xi || (TANGENT && !dsig)) return CM_ERR_BAD_ARG;
+    const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
+    dispatch(m, [&]<int D, int Y, bool R>() {
+        hipLaunchKernelGGL((k_update<D, Y, R, TANGENT>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
+    });
+    return check_launch();
+}
+
+template <int MODE>
+int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi_in,
+                   const double* sd, const double* wsq6, const double* hist_in, double* xi_out, double* sigma_out,
+                   double* xpbar, double* gbar, double* out, int out_offset, int accumulate, void* workspace,
+                   int64_t wbytes, void* stream) {
+    if (!m || B < 0 || !out || !workspace) return CM_ERR_BAD_ARG;
+    if (B > 0 && (!gradu || !xi_prev || !sd)) return CM_ERR_BAD_ARG;
+    if (B > 0 && (MODE == 0 || MODE == 2) && !xi_in) return CM_ERR_BAD_ARG;
+    if ((MODE == 1 || MODE == 2) && !wsq6) return CM_ERR_BAD_ARG;
+    if (!supported(m)) return CM_ERR_UNSUPPORTED;
+    if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = (double*)workspace;
+    const int64_t nb = nblocks_of(B);
+    Wsq w; for (int k = 0; k < 6; ++k) w.w[k] = wsq6 ? wsq6[k] : 0.0;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();            // drop any stale error left by other users of the runtime
+    if (B > 0) {
+        const dim3 grid((unsigned)nb), block(kBlock);
+        dispatch(m, [&]<int D, int Y, bool R>() {
+            hipLaunchKernelGGL((k_reverse<D, Y, R, MODE>), grid, block, 0, s, md, B, gradu, xi_prev, xi_in, sd, w,
+                               hist_in, xi_out, sigma_out, xpbar, gbar, partials);
+        });
+        if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
+    }
+    // MODE 0 has no objective: skip slot 0 of the partials by reducing all and writing grad only
+    hipLaunchKernelGGL((k_reduce<kRed>), dim3(1), dim3(kBlock), 0, s, partials, nb, out, out_offset, accumulate);
+    return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm_abi_version(void) { return 1; }
+const char* cm_last_hip_error(void) { return hipGetErrorName((hipError_t)g_last_hip_error); }
+
+int cm_num_xi(const cm_model_desc* m) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->def_type == CM_FULL_3D) return 7;
+    if (m->def_type == CM_PLANE_STRESS) return 8;
+    if (m->def_type == CM_UNIAXIAL_STRESS) return m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC ? 12 : 9;
+    return CM_ERR_UNSUPPORTED;
+}
+
+int cm_num_gradu(const cm_model_desc* m) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->def_type == CM_FULL_3D) return 9;
+    if (m->def_type == CM_PLANE_STRESS || m->def_type == CM_PLANE_STRAIN) return 4;
+    if (m->def_type == CM_UNIAXIAL_STRESS) return 1;
+    return CM_ERR_UNSUPPORTED;
+}
+
+int64_t cm_workspace_bytes(int64_t B) {
+    if (B < 0) return CM_ERR_BAD_ARG;
+    const int64_t nb = B == 0 ? 1 : nblocks_of(B);
+    return (nb + 1) * kRed * (int64_t)sizeof(double);      // block partials + one result row
+}
+
+int cm_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+              double* xi, double* sigma, uint32_t* status, void* stream) {
+    return launch_update<false>(m, B, gradu, xi_prev, xi, sigma, nullptr, status, stream);
+}
+
+int cm_update_tangent(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+                      double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream) {
+    return launch_update<true>(m, B, gradu, xi_prev, xi, sigma, dsigma_dgradu, status, stream);
+}
+
+int cm_update_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                  const double* sigma_bar, double* grad_p, double* xi_prev_bar, double* gradu_bar,
+                  void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!grad_p) return CM_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    // reduce into the workspace's result row {J=0, grad[12]}, then copy grad out on the stream
+    double* tail = (double*)((char*)workspace + cm_workspace_bytes(B)) - kRed;
+    int rc = launch_reverse<0>(m, B, gradu, xi_prev, xi, sigma_bar, nullptr, nullptr, nullptr, nullptr, xi_prev_bar,
+                               gradu_bar, tail, 0, 0, workspace, workspace_bytes, stream);
+    if (rc != CM_OK) return rc;
+    if (hipMemcpyAsync(grad_p, tail + 1, CM_NUM_PARAMS * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return CM_ERR_LAUNCH;
+    return CM_OK;
+}
+
+int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+                      const double* sigma_bar, double* xi, double* sigma, double* grad_p,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!grad_p || !xi) return CM_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    double* tail = (double*)((char*)workspace + cm_workspace_bytes(B)) - kRed;
+    int rc = launch_reverse<3>(m, B, gradu, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr, nullptr,
+                               tail, 0, 0, workspace, workspace_bytes, stream);
+    if (rc != CM_OK) return rc;
+    if (hipMemcpyAsync(grad_p, tail + 1, CM_NUM_PARAMS * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return CM_ERR_LAUNCH;
+    return CM_OK;
+}
+
+int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
+
+int cm_objective_grad(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+                      const double* data, const double* wsq6, double* out, double* xi,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+    return launch_reverse<1>(m, B, gradu, xi_prev, nullptr, data, wsq6, nullptr, xi, nullptr, nullptr, nullptr,
+                             out, 0, 0, workspace, workspace_bytes, stream);
+}
+
+int cm_adjoint_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                    const double* data, const double* wsq6, const double* hist_in, double* hist_out, double* out,
+                    int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!hist_out) return CM_ERR_BAD_ARG;
+    return launch_reverse<2>(m, B, gradu, xi_prev, xi, data, wsq6, hist_in, nullptr, nullptr, hist_out, nullptr,
+                             out, 0, accumulate, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+"""Host side of the HIP path: builds `cm_model_desc` from a CMAD parameter tree and launches the
+C-ABI entry points (include/cmad_hip.h) on torch device tensors.  torch is only the carrier of device
+memory and streams; all arithmetic happens in cmad_amd/csrc.
+
+There is deliberately no CPU implementation behind these calls: without the HIP library (or without a
+GPU) they raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .. import _lib
+from .deformation_types import DefType
+from .elastic_constants import lame_jacobian
+
+YIELD_KINDS = {"J2": 0, "hill": 1, "hosford": 2}
+HILL_NAMES = ("F", "G", "H", "L", "M", "N")
+
+# cmad/util/line_search.py:40-46
+DEFAULT_LINE_SEARCH_SETTINGS = {
+    "max evals": 4,
+    "sufficient decrease": 1.0e-4,
+    "min backtrack factor": 0.5,
+    "max backtrack factor": 0.9,
+}
+
+
+@dataclass
+class NewtonSettings:
+    """Local Newton controls.  Defaults = imperative `newton_solve` (cmad/models/nonlinear_solver.py:14-20):
+    10 iterations, 1e-14 tolerances, no line search.  `traced()` gives `make_newton_solve`'s defaults
+    (:88-100) with the quadratic Armijo search of cmad/util/line_search.py."""
+    max_iters: int = 10
+    abs_tol: float = 1e-14
+    rel_tol: float = 1e-14
+    line_search: dict = field(default_factory=lambda: {**DEFAULT_LINE_SEARCH_SETTINGS, "max evals": 0})
+
+    @classmethod
+    def traced(cls, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search_settings=None):
+        return cls(max_iters, abs_tol, rel_tol, {**DEFAULT_LINE_SEARCH_SETTINGS, **(line_search_settings or {})})
+
+
+def _first_key(d):
+    return next(iter(d))
+
+
+def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, uniaxial_stress_idx=0,
+               newton: NewtonSettings | None = None, effective_stress_type: str | None = None):
+    """Flatten a CMAD parameter tree into a `cm_model_desc`.
+
+    Returns (desc, info) where info carries what the sensitivity mapping needs:
+    elastic names and d(lambda, mu)/d(elastic pair)."""
+    newton = newton or NewtonSettings()
+    d = _lib.ModelDesc()
+    d.model_kind = int(model_kind)
+    d.def_type = int(def_type)
+    plastic = values["plastic"]
+    ytype = effective_stress_type or _first_key(plastic["effective stress"])     # small_elastic_plastic.py:190-195
+    if ytype not in YIELD_KINDS:
+        raise NotImplementedError(f"effective stress '{ytype}' has no HIP kernel")
+    d.yield_kind = YIELD_KINDS[ytype]
+    Q = np.asarray(values.get("rotation matrix", np.eye(3)), dtype=np.float64).reshape(3, 3)
+    for i in range(9):
+        d.Q[i] = float(Q.reshape(9)[i])
+    d.rotation_is_identity = int(np.array_equal(Q, np.eye(3)))
+    names, lm, mu, J = lame_jacobian(values["elastic"])
+    d.lmbda, d.mu = float(lm), float(mu)
+    fs = plastic["flow stress"]
+    d.Y = float(fs["initial yield"]["Y"])
+    hard = fs.get("hardening", {}) or {}
+    for k in hard:
+        if k not in ("voce", "linear"):
+            raise NotImplementedError(f"hardening '{k}'")
+    d.has_voce = int("voce" in hard)
+    d.has_linear = int("linear" in hard)
+    if d.has_voce:
+        d.voce_S, d.voce_D = float(hard["voce"]["S"]), float(hard["voce"]["D"])
+    if d.has_linear:
+        d.lin_K = float(hard["linear"]["K"])
+    if ytype == "hill":
+        h = plastic["effective stress"]["hill"]
+        for i, n in enumerate(HILL_NAMES):
+            d.yc[i] = float(h[n])
+    elif ytype == "hosford":
+        d.yc[0] = float(plastic["effective stress"]["hosford"]["a"])
+    d.uniaxial_idx = int(uniaxial_stress_idx)
+    d.yield_tol = float(yield_tol)
+    d.max_iters = int(newton.max_iters)
+    d.abs_tol, d.rel_tol = float(newton.abs_tol), float(newton.rel_tol)
+    ls = newton.line_search
+    d.ls_max_evals = int(ls.get("max evals", 0))
+    d.ls_c1 = float(ls.get("sufficient decrease", 1e-4))
+    d.ls_lo = float(ls.get("min backtrack factor", 0.5))
+    d.ls_hi = float(ls.get("max backtrack factor", 0.9))
+    info = {"elastic_names": names, "lame_jac": J, "yield_type": ytype}
+    return d, info
+
+
+def kp_to_leaf_grad(path, g_kp, info):
+    """Sensitivity w.r.t. the parameter-tree leaf at `path` from the kernel's KP-order vector
+    (include/cmad_hip.h `cm_param_index`).  `g_kp` may have trailing batch/row dims on axis 0 = KP."""
+    leaf = path[-1]
+    if path[0] == "elastic":
+        j = info["elastic_names"].index(leaf)
+        J = info["lame_jac"]
+        return g_kp[_lib.P_LAMBDA] * J[0, j] + g_kp[_lib.P_MU] * J[1, j]
+    if path[0] == "rotation matrix":
+        raise NotImplementedError("sensitivities w.r.t. the rotation matrix are not available in the HIP path")
+    if leaf == "Y":
+        return g_kp[_lib.P_Y]
+    parent = path[-2] if len(path) >= 2 else None
+    if parent == "voce":
+        return g_kp[{"S": _lib.P_VOCE_S, "D": _lib.P_VOCE_D}[leaf]]
+    if parent == "linear":
+        return g_kp[_lib.P_LIN_K]
+    if parent == "hill":
+        return g_kp[_lib.P_YC0 + HILL_NAMES.index(leaf)]
+    if parent == "effective stress" and leaf == "J2":
+        return g_kp[0] * 0.0
+    if parent == "hosford":
+        raise NotImplementedError("sensitivity w.r.t. the Hosford exponent is not available in the HIP path")
+    raise KeyError(path)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check_soa(t, rows, B, name):
+    torch = _torch()
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+            and tuple(t.shape) == (rows, B)):
+        raise ValueError(f"{name}: expected a contiguous float64 CUDA tensor of shape ({rows}, {B}), "
+                         f"got {type(t).__name__} {getattr(t, 'shape', None)} {getattr(t, 'dtype', None)} "
+                         f"{getattr(t, 'device', None)}")
+
+
+def fold_weight_and_data(weight, data9=None):
+    """Fold a 3x3 weight mask (qois/calibration.py:23-33) into squared weights of the 6 unique stress
+    entries; optionally fold (possibly non-symmetric) 3x3 data into the equivalent symmetric 6-vector
+    data plus a constant:  1/2 w_ij^2 (s - d_ij)^2 + 1/2 w_ji^2 (s - d_ji)^2
+                         = 1/2 W (s - D)^2 + const,  W = w_ij^2 + w_ji^2,  D = (w_ij^2 d_ij + w_ji^2 d_ji)/W."""
+    w = np.asarray(weight, dtype=np.float64).reshape(3, 3)
+    pairs = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    wsq6 = np.array([w[i, j] ** 2 if i == j else w[i, j] ** 2 + w[j, i] ** 2 for i, j in pairs])
+    if data9 is None:
+        return wsq6
+    d = np.asarray(data9, dtype=np.float64)            # (3, 3, ...)
+    data6 = np.zeros((6,) + d.shape[2:])
+    const = np.zeros(d.shape[2:])
+    for r, (i, j) in enumerate(pairs):
+        if i == j:
+            data6[r] = d[i, j]
+        else:
+            a, b = w[i, j] ** 2, w[j, i] ** 2
+            W = a + b
+            D = (a * d[i, j] + b * d[j, i]) / W if W != 0.0 else 0.5 * (d[i, j] + d[j, i])
+            data6[r] = D
+            const = const + 0.5 * (a * d[i, j] ** 2 + b * d[j, i] ** 2 - W * D ** 2)
+    return wsq6, data6, const
+
+
+class DeviceEvaluator:
+    """Launches the batched kernels for one model description on the current torch CUDA stream."""
+
+    def __init__(self, desc, info):
+        self.desc, self.info = desc, info
+        self.L = _lib.lib()
+        self.nx = self.L.cm_num_xi(C.byref(desc))
+        self.nu = self.L.cm_num_gradu(C.byref(desc))
+        if self.nx < 0 or self.nu < 0:
+            raise NotImplementedError("def_type not available in the HIP library")
+        self._ws = None
+
+    # -- helpers
+    def _stream(self):
+        torch = _torch()
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _workspace(self, B, device):
+        torch = _torch()
+        need = self.L.cm_workspace_bytes(B)
+        if self._ws is None or self._ws.numel() * 8 < need or self._ws.device != device:
+            self._ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=device)
+        return self._ws, need
+
+    # -- entry points
+    def update(self, gradu, xi_prev, want_sigma=True, want_status=True, tangent=False, out=None):
+        torch = _torch()
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
+        dev = gradu.device
+        o = out or {}
+        xi = o.get("xi") if o.get("xi") is not None else torch.empty((self.nx, B), dtype=torch.float64, device=dev)
+        sigma = (o.get("sigma") if o.get("sigma") is not None else
+                 torch.empty((6, B), dtype=torch.float64, device=dev)) if want_sigma else None
+        status = (o.get("status") if o.get("status") is not None else
+                  torch.empty((B,), dtype=torch.int32, device=dev)) if want_status else None
+        if tangent:
+            ds = torch.empty((6 * self.nu, B), dtype=torch.float64, device=dev)
+            rc = self.L.cm_update_tangent(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma),
+                                          _ptr(ds), _ptr(status), self._stream())
+            _lib.check(rc, "cm_update_tangent")
+            return xi, sigma, status, ds.view(6, self.nu, B)
+        rc = self.L.cm_update(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma),
+                              _ptr(status), self._stream())
+        _lib.check(rc, "cm_update")
+        return xi, sigma, status
+
+    def update_vjp(self, gradu, xi_prev, xi, sigma_bar, want_xi_prev_bar=False, want_gradu_bar=False):
+        torch = _torch()
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
+        _check_soa(xi, self.nx, B, "xi"); _check_soa(sigma_bar, 6, B, "sigma_bar")
+        dev = gradu.device
+        g = torch.empty(_lib.CM_NUM_PARAMS, dtype=torch.float64, device=dev)
+        xb = torch.empty((self.nx, B), dtype=torch.float64, device=dev) if want_xi_prev_bar else None
+        ub = torch.empty((self.nu, B), dtype=torch.float64, device=dev) if want_gradu_bar else None
+        ws, need = self._workspace(B, dev)
+        rc = self.L.cm_update_vjp(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma_bar),
+                                  _ptr(g), _ptr(xb), _ptr(ub), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_update_vjp")
+        return g, xb, ub
+
+    def update_and_vjp(self, gradu, xi_prev, sigma_bar, want_sigma=True, out=None):
+        """Fused cm_update + cm_update_vjp; returns xi, sigma, grad_kp (device, KP order)."""
+        torch = _torch()
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
+        _check_soa(sigma_bar, 6, B, "sigma_bar")
+        dev = gradu.device
+        o = out or {}
+        xi = o.get("xi") if o.get("xi") is not None else torch.empty((self.nx, B), dtype=torch.float64, device=dev)
+        sigma = (o.get("sigma") if o.get("sigma") is not None else
+                 torch.empty((6, B), dtype=torch.float64, device=dev)) if want_sigma else None
+        g = o.get("grad") if o.get("grad") is not None else torch.empty(_lib.CM_NUM_PARAMS, dtype=torch.float64, device=dev)
+        ws, need = self._workspace(B, dev)
+        rc = self.L.cm_update_and_vjp(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(sigma_bar), _ptr(xi),
+                                      _ptr(sigma), _ptr(g), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_update_and_vjp")
+        return xi, sigma, g
+
+    def objective_grad(self, gradu, xi_prev, data6, wsq6, want_xi=False, out=None):
+        torch = _torch()
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
+        _check_soa(data6, 6, B, "data")
+        dev = gradu.device
+        res = out if out is not None else torch.empty(1 + _lib.CM_NUM_PARAMS, dtype=torch.float64, device=dev)
+        xi = torch.empty((self.nx, B), dtype=torch.float64, device=dev) if want_xi else None
+        w = (C.c_double * 6)(*[float(v) for v in wsq6])
+        ws, need = self._workspace(B, dev)
+        rc = self.L.cm_objective_grad(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(data6), w,
+                                      _ptr(res), _ptr(xi), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_objective_grad")
+        return res, xi
+
+    def adjoint_step(self, gradu, xi_prev, xi, data6, wsq6, hist_in, hist_out, out, accumulate=True):
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
+        _check_soa(xi, self.nx, B, "xi"); _check_soa(data6, 6, B, "data"); _check_soa(hist_out, self.nx, B, "hist_out")
+        w = (C.c_double * 6)(*[float(v) for v in wsq6])
+        ws, need = self._workspace(B, gradu.device)
+        rc = self.L.cm_adjoint_step(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(data6), w,
+                                    _ptr(hist_in), _ptr(hist_out), _ptr(out), int(bool(accumulate)),
+                                    _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_adjoint_step")
+        return hist_out, out

@@ -1,0 +1,121 @@
+"""Isotropic elastic constants, any two of {E, nu, mu, kappa, lambda} -> Lame pair
+(mirror of /root/reference/cmad/models/elastic_constants.py:23-104).  Host-side only: the kernels
+take (lambda, mu); `lame_jacobian` supplies d(lambda, mu)/d(given pair) for the chain rule that maps
+kernel sensitivities back onto the user's parameters."""
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+_CONSTANT_NAMES = ("E", "nu", "mu", "kappa", "lambda")
+
+
+def compute_mu(E, nu):
+    return E / (2. * (1. + nu))
+
+
+def compute_kappa(E, nu):
+    return E / (3. * (1. - 2. * nu))
+
+
+def compute_lambda(E, nu):
+    return E * nu / ((1. + nu) * (1. - 2. * nu))
+
+
+def _sqrt(x):
+    return x.sqrt() if hasattr(x, "sqrt") else np.sqrt(x)
+
+
+@dataclass(frozen=True)
+class ElasticConstants:
+    lmbda: Any
+    mu: Any
+
+    @property
+    def kappa(self):
+        return self.lmbda + 2. * self.mu / 3.
+
+    @property
+    def E(self):
+        return self.mu * (3. * self.lmbda + 2. * self.mu) / (self.lmbda + self.mu)
+
+    @property
+    def nu(self):
+        return self.lmbda / (2. * (self.lmbda + self.mu))
+
+    @classmethod
+    def from_params(cls, elastic: dict) -> "ElasticConstants":
+        given = tuple(n for n in _CONSTANT_NAMES if n in elastic)
+        if len(given) != 2:
+            raise ValueError(f"ElasticConstants needs exactly two of {_CONSTANT_NAMES}; got {given}")
+        pair = frozenset(given)
+        if pair == frozenset(("lambda", "mu")):
+            lmbda, mu = elastic["lambda"], elastic["mu"]
+        elif pair == frozenset(("E", "nu")):
+            E, nu = elastic["E"], elastic["nu"]
+            lmbda, mu = compute_lambda(E, nu), compute_mu(E, nu)
+        elif pair == frozenset(("mu", "kappa")):
+            mu, kappa = elastic["mu"], elastic["kappa"]
+            lmbda = kappa - 2. * mu / 3.
+        elif pair == frozenset(("E", "mu")):
+            E, mu = elastic["E"], elastic["mu"]
+            lmbda = mu * (E - 2. * mu) / (3. * mu - E)
+        elif pair == frozenset(("E", "kappa")):
+            E, kappa = elastic["E"], elastic["kappa"]
+            mu = 3. * kappa * E / (9. * kappa - E)
+            lmbda = 3. * kappa * (3. * kappa - E) / (9. * kappa - E)
+        elif pair == frozenset(("mu", "nu")):
+            mu, nu = elastic["mu"], elastic["nu"]
+            lmbda = 2. * mu * nu / (1. - 2. * nu)
+        elif pair == frozenset(("kappa", "nu")):
+            kappa, nu = elastic["kappa"], elastic["nu"]
+            mu = 3. * kappa * (1. - 2. * nu) / (2. * (1. + nu))
+            lmbda = 3. * kappa * nu / (1. + nu)
+        elif pair == frozenset(("lambda", "nu")):
+            lmbda, nu = elastic["lambda"], elastic["nu"]
+            mu = lmbda * (1. - 2. * nu) / (2. * nu)
+        elif pair == frozenset(("lambda", "kappa")):
+            lmbda, kappa = elastic["lambda"], elastic["kappa"]
+            mu = 3. * (kappa - lmbda) / 2.
+        elif pair == frozenset(("E", "lambda")):
+            E, lmbda = elastic["E"], elastic["lambda"]
+            R = _sqrt(E ** 2 + 9. * lmbda ** 2 + 2. * E * lmbda)
+            mu = (E - 3. * lmbda + R) / 4.
+        else:
+            raise ValueError(f"unsupported elastic-constant pair: {given}")
+        return cls(lmbda=lmbda, mu=mu)
+
+
+class _D2:
+    """Minimal forward-mode dual with two tangent slots (host only, for lame_jacobian)."""
+    __slots__ = ("v", "d")
+
+    def __init__(self, v, d=(0., 0.)):
+        self.v, self.d = float(v), np.asarray(d, dtype=float)
+
+    @staticmethod
+    def _c(o):
+        return o if isinstance(o, _D2) else _D2(o)
+
+    def __add__(self, o): o = self._c(o); return _D2(self.v + o.v, self.d + o.d)
+    __radd__ = __add__
+    def __sub__(self, o): o = self._c(o); return _D2(self.v - o.v, self.d - o.d)
+    def __rsub__(self, o): return self._c(o) - self
+    def __mul__(self, o): o = self._c(o); return _D2(self.v * o.v, self.d * o.v + self.v * o.d)
+    __rmul__ = __mul__
+    def __truediv__(self, o): o = self._c(o); q = self.v / o.v; return _D2(q, (self.d - q * o.d) / o.v)
+    def __rtruediv__(self, o): return self._c(o) / self
+    def __neg__(self): return _D2(-self.v, -self.d)
+    def __pow__(self, n): return _D2(self.v ** n, n * self.v ** (n - 1) * self.d)
+    def sqrt(self): r = np.sqrt(self.v); return _D2(r, self.d / (2. * r))
+
+
+def lame_jacobian(elastic: dict):
+    """Return (names, lmbda, mu, J) with J[i, j] = d (lmbda, mu)[i] / d elastic[names[j]]."""
+    names = tuple(n for n in _CONSTANT_NAMES if n in elastic)
+    if len(names) != 2:
+        raise ValueError(f"ElasticConstants needs exactly two of {_CONSTANT_NAMES}; got {names}")
+    seeded = {names[0]: _D2(elastic[names[0]], (1., 0.)), names[1]: _D2(elastic[names[1]], (0., 1.))}
+    ec = ElasticConstants.from_params(seeded)
+    lm, mu = _D2._c(ec.lmbda), _D2._c(ec.mu)
+    return names, lm.v, mu.v, np.array([lm.d, mu.d])

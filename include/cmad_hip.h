@@ -1,0 +1,177 @@
+/*
+ * cmad_hip.h -- C-ABI of the MI355X (gfx950) batched constitutive-model evaluator.
+ *
+ * The reference (sandialabs/cmad) is pure Python + JAX and has NO FFI for this path; the drop-in
+ * boundary is its Python operator API (cmad/models/model.py:25-88, cmad/parameters/parameters.py:176-203).
+ * This C-ABI is the layer directly under the Python facade cmad_amd.models / cmad_amd.parameters and is
+ * what a cmad maintainer would bind with ctypes (INTEGRATION.md shows the stub).  Each entry point names
+ * the reference interface whose per-point work it replaces, batched over B Gauss points.
+ *
+ * Conventions
+ *   - All arrays are DEVICE pointers to fp64 structure-of-arrays: component k of point b at [k*B + b].
+ *   - Symmetric tensors are 6-vectors in CMAD order [xx, xy, xz, yy, yz, zz], un-weighted
+ *     (cmad/models/var_types.py:43-84).  grad u is row-major: gradu[3*k + j] = d u_k / d x_j
+ *     (cmad/models/global_fields.py:12-41).
+ *   - n_xi = 7 (FULL_3D: plastic strain 6 + alpha), 8 (PLANE_STRESS: + F33), see cm_num_xi().
+ *   - `stream` is a hipStream_t passed as void*; NULL = default stream.  Calls are asynchronous.
+ *   - Every function returns 0 on success, a negative cm_status otherwise; nothing throws, nothing is
+ *     allocated or synchronised inside (graph-capture safe), no ownership is transferred.
+ *   - Newton non-convergence is NOT an error (reference: models/nonlinear_solver.py:85,153-155 return
+ *     the last iterate silently); it is reported per point in `status`.
+ */
+#ifndef CMAD_HIP_H
+#define CMAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum cm_status {
+    CM_OK = 0,
+    CM_ERR_BAD_ARG = -1,        /* null pointer / negative size */
+    CM_ERR_UNSUPPORTED = -2,    /* def_type / yield / model kind not built (maps to NotImplementedError) */
+    CM_ERR_LAUNCH = -3,         /* hipGetLastError() != hipSuccess after launch */
+    CM_ERR_WORKSPACE = -4       /* workspace too small */
+};
+
+/* cmad/models/deformation_types.py:4-9 */
+enum cm_def_type { CM_FULL_3D = 0, CM_PLANE_STRAIN = 1, CM_PLANE_STRESS = 2, CM_UNIAXIAL_STRESS = 3 };
+/* registry names cmad/models/small_elastic_plastic.py:95, small_rate_elastic_plastic.py */
+enum cm_model_kind { CM_SMALL_ELASTIC_PLASTIC = 0, CM_SMALL_RATE_ELASTIC_PLASTIC = 1 };
+/* cmad/models/effective_stress.py:15-27 (+ hybrid_hill :149-163) */
+enum cm_yield_kind { CM_YIELD_J2 = 0, CM_YIELD_HILL = 1, CM_YIELD_HOSFORD = 2, CM_YIELD_HYBRID_HILL_NN = 3 };
+
+/* Kernel-level parameter order used by every sensitivity output ("KP order").
+ * The Python facade maps it onto cmad.parameters' sorted-pytree flat order and applies the
+ * elastic-constant chain rule (any two of E, nu, mu, kappa, lambda -> lambda, mu). */
+enum cm_param_index {
+    CM_P_LAMBDA = 0, CM_P_MU = 1, CM_P_Y = 2, CM_P_VOCE_S = 3, CM_P_VOCE_D = 4, CM_P_LIN_K = 5,
+    CM_P_YC0 = 6,               /* hill F,G,H,L,M,N = 6..11 ; hosford a = 6 */
+    CM_NUM_PARAMS = 12
+};
+
+/* status word written per point by cm_update* (all optional outputs may be NULL) */
+#define CM_STATUS_ITERS_MASK 0xFFFFu
+#define CM_STATUS_CONVERGED  (1u << 16)
+#define CM_STATUS_PLASTIC    (1u << 17)   /* plastic branch selected at the returned state */
+#define CM_STATUS_SINGULAR   (1u << 18)   /* a vanishing pivot was met in a local solve */
+
+/* Everything SmallElasticPlastic(parameters, def_type, ...) + make_newton_solve(...) fix at
+ * construction time (small_elastic_plastic.py:109-211, nonlinear_solver.py:88-100,
+ * util/line_search.py:40-46), flattened to plain data.  Passed by value. */
+typedef struct cm_model_desc {
+    int32_t model_kind;         /* cm_model_kind */
+    int32_t def_type;           /* cm_def_type */
+    int32_t yield_kind;         /* cm_yield_kind */
+    int32_t has_voce;           /* hardening dict contains "voce"  (models/hardening.py:9-13) */
+    int32_t has_linear;         /* hardening dict contains "linear" (models/hardening.py:16-19) */
+    int32_t uniaxial_idx;       /* uniaxial_stress_idx, UNIAXIAL_STRESS only */
+    int32_t rotation_is_identity; /* params["rotation matrix"] == eye(3) exactly -> skip Q products */
+    int32_t reserved0;
+    double  yield_tol;          /* cond_residual tolerance, models/paths.py:26-27 (default 1e-14) */
+    double  Q[9];               /* params["rotation matrix"], row-major */
+    double  lambda, mu;         /* Lame pair, models/elastic_constants.py:53-104 */
+    double  Y;                  /* initial yield */
+    double  voce_S, voce_D;     /* Voce S(1 - exp(-D alpha)) */
+    double  lin_K;              /* linear K alpha */
+    double  yc[6];              /* hill F,G,H,L,M,N | hosford a in yc[0] */
+    /* local Newton (models/nonlinear_solver.py:88-155) */
+    int32_t max_iters;          /* default 10 (MP path) / 20 (FE binding) */
+    int32_t ls_max_evals;       /* 0 = plain Newton (imperative newton_solve default); default 4 traced */
+    double  abs_tol, rel_tol;   /* default 1e-14 / 1e-14 */
+    double  ls_c1, ls_lo, ls_hi;/* sufficient decrease 1e-4, backtrack factors 0.5 / 0.9 */
+    /* symmetric input-convex network of the hybrid Hill + NN yield surface
+     * (neural_networks/input_convex_neural_network.py:36-69); device pointer or NULL */
+    const double* nn_weights;
+    int32_t nn_nlayers;
+    int32_t nn_widths[7];
+} cm_model_desc;
+
+/* library / build info */
+int  cm_abi_version(void);
+const char* cm_last_hip_error(void);             /* name of the last HIP error behind a CM_ERR_LAUNCH */
+int  cm_sizeof_model_desc(void);                 /* sizeof(cm_model_desc) as compiled, for binding checks */
+int  cm_num_xi(const cm_model_desc* m);          /* local dofs per point, <0 if unsupported */
+int  cm_num_gradu(const cm_model_desc* m);       /* 9 (FULL_3D), 4 (PLANE_STRESS), 1 (UNIAXIAL_STRESS) */
+int64_t cm_workspace_bytes(int64_t B);           /* scratch needed by the reducing entry points */
+
+/*
+ * cm_update: one backward-Euler stress update per Gauss point.
+ * Replaces, per point: make_newton_solve(model._residual)(xi_prev, params, U, U_prev)
+ * (cmad/models/nonlinear_solver.py:102-155) / newton_solve(model) (:14-85), followed by
+ * model.cauchy(...) (cmad/models/small_elastic_plastic.py:307-321).
+ *   in : gradu[n_gradu][B], xi_prev[n_xi][B]
+ *   out: xi[n_xi][B], sigma[6][B] (global Cauchy stress, may be NULL), status[B] (may be NULL)
+ */
+int cm_update(const cm_model_desc* m, int64_t B,
+              const double* gradu, const double* xi_prev,
+              double* xi, double* sigma, uint32_t* status, void* stream);
+
+/*
+ * cm_update_tangent: cm_update plus the IFT-consistent tangent d sigma / d gradu.
+ * Replaces jacfwd through the custom_jvp rule (cmad/models/nonlinear_solver.py:158-171) as used by
+ * GlobalResidual._for_model_coupled (cmad/global_residuals/global_residual.py:373-394).
+ *   out: dsigma_dgradu[6*n_gradu][B], entry (r, c) at [(r*n_gradu + c)*B + b]
+ */
+int cm_update_tangent(const cm_model_desc* m, int64_t B,
+                      const double* gradu, const double* xi_prev,
+                      double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream);
+
+/*
+ * cm_update_vjp: reverse-mode sensitivities of one converged update for a given stress cotangent.
+ * Replaces the transpose of the custom_jvp rule (nonlinear_solver.py:158-171):
+ *   lam = (dC/dxi)^-T (dsigma/dxi)^T sbar ;  pbar = (dsigma/dp)^T sbar - (dC/dp)^T lam  (same for xi_prev, gradu)
+ *   in : gradu, xi_prev, xi (converged, from cm_update), sigma_bar[6][B] (cotangent of the 6 stored entries)
+ *   out: grad_p[CM_NUM_PARAMS] (device, sum over points, KP order, NATIVE lambda/mu parameters),
+ *        xi_prev_bar[n_xi][B] (may be NULL), gradu_bar[n_gradu][B] (may be NULL)
+ *   workspace: cm_workspace_bytes(B) device bytes
+ */
+int cm_update_vjp(const cm_model_desc* m, int64_t B,
+                  const double* gradu, const double* xi_prev, const double* xi, const double* sigma_bar,
+                  double* grad_p, double* xi_prev_bar, double* gradu_bar,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * cm_update_and_vjp: cm_update and cm_update_vjp fused in one pass over the batch (the state never
+ * leaves registers between the Newton solve and the reverse sweep): reads gradu, xi_prev, sigma_bar;
+ * writes xi, sigma (may be NULL) and the reduced grad_p[CM_NUM_PARAMS].  Same reference lines as the
+ * two calls it fuses.  For a sigma_bar that does not depend on this step's sigma.
+ */
+int cm_update_and_vjp(const cm_model_desc* m, int64_t B,
+                      const double* gradu, const double* xi_prev, const double* sigma_bar,
+                      double* xi, double* sigma, double* grad_p,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * cm_objective_grad: fused single-step calibration objective and gradient.
+ * Replaces, per point and summed over the batch: MPAdjointObjective._evaluate for a one-step history
+ * (cmad/objectives/mp_objective.py:95-147) with QoI Calibration._qoi (cmad/qois/calibration.py:56-66):
+ *   J = sum_b 1/2 sum_ij (w_ij (sigma_ij - data_ij))^2 ,  grad = dJ/dp (KP order, native parameters)
+ *   in : gradu, xi_prev, data[6][B] (measured stress, 6 unique entries), wsq6[6] (HOST pointer): squared
+ *        weights of the 6 unique entries, w_ii^2 on the diagonal and w_ij^2 + w_ji^2 off it (a 3x3
+ *        weight mask and non-symmetric data fold into this form exactly; the facade does it)
+ *   out: out[1 + CM_NUM_PARAMS] device doubles = {J, grad...}; xi[n_xi][B] optional (NULL = not stored)
+ */
+int cm_objective_grad(const cm_model_desc* m, int64_t B,
+                      const double* gradu, const double* xi_prev, const double* data, const double* wsq6,
+                      double* out, double* xi, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * cm_adjoint_step: one reverse-time step of the adjoint pass of a K-step history
+ * (cmad/objectives/mp_objective.py:112-142), for all points:
+ *   phi = (dC/dxi)^-T (-dJ/dxi^T + h_in) ; h_out = -(dC/dxi_prev)^T phi ; grad += phi^T dC/dp + dJ/dp
+ *   in : gradu (step k), xi_prev (= xi_{k-1}), xi (= xi_k), data[6][B], wsq6[6] (host), hist_in[n_xi][B] (NULL = 0)
+ *   out: hist_out[n_xi][B] (may alias hist_in), out[1 + CM_NUM_PARAMS] += {J_k, grad_k} when accumulate != 0
+ */
+int cm_adjoint_step(const cm_model_desc* m, int64_t B,
+                    const double* gradu, const double* xi_prev, const double* xi,
+                    const double* data, const double* wsq6, const double* hist_in,
+                    double* hist_out, double* out, int accumulate,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMAD_HIP_H */

@@ -1,0 +1,62 @@
+"""Loader of tests/native/libhost_harness.so: the per-point device math of cmad_amd/csrc/cm_device.hpp
+compiled for the host.  TEST INFRASTRUCTURE ONLY (lets CPU CI and sanitizers exercise the hand-derived
+formulas the GPU kernels use); the product never loads it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native")
+_SO = os.path.join(_DIR, "libhost_harness.so")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def build(force=False, sanitize=False):
+    src = os.path.join(_DIR, "host_harness.cpp")
+    deps = [src, os.path.join(_ROOT, "cmad_amd", "csrc", "cm_device.hpp"), os.path.join(_ROOT, "include", "cmad_hip.h")]
+    out = _SO if not sanitize else os.path.join(_DIR, "libhost_harness_asan.so")
+    stale = (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+    if force or stale:
+        flags = ["-O1", "-g", "-std=c++20", "-fPIC", "-shared", "-ffp-contract=off"]
+        if sanitize:
+            flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+        subprocess.run(["g++"] + flags + ["-o", out, src], check=True, capture_output=True)
+    return out
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def update(desc, gradu, xi_prev, nx, tangent=False):
+    L = lib()
+    from cmad_amd import _lib as cl
+    assert L.hh_sizeof_desc() == C.sizeof(cl.ModelDesc)
+    gradu = np.ascontiguousarray(gradu, dtype=np.float64); xi_prev = np.ascontiguousarray(xi_prev, dtype=np.float64)
+    B = gradu.shape[1]
+    xi = np.zeros((nx, B)); sig = np.zeros((6, B)); st = np.zeros(B, dtype=np.uint32)
+    ds = np.zeros((6 * gradu.shape[0], B)) if tangent else None
+    rc = L.hh_update(C.byref(desc), C.c_int64(B), _p(gradu), _p(xi_prev), _p(xi), _p(sig), _p(st), _p(ds))
+    assert rc == 0
+    return (xi, sig, st, ds.reshape(6, gradu.shape[0], B)) if tangent else (xi, sig, st)
+
+
+def vjp(desc, gradu, xi_prev, xi, sbar, xin=None):
+    L = lib()
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    gradu, xi_prev, xi, sbar, xin = c(gradu), c(xi_prev), c(xi), c(sbar), c(xin)
+    B = gradu.shape[1]
+    g = np.zeros(12); xb = np.zeros_like(xi); ub = np.zeros_like(gradu)
+    rc = L.hh_vjp(C.byref(desc), C.c_int64(B), _p(gradu), _p(xi_prev), _p(xi), _p(sbar), _p(xin), _p(g), _p(xb), _p(ub))
+    assert rc == 0
+    return g, xb, ub

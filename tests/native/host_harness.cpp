@@ -1,0 +1,96 @@
+// TEST INFRASTRUCTURE ONLY: compiles the per-point device math of cmad_amd/csrc/cm_device.hpp for the
+// host (g++, -DCM_HOST_BUILD) so the hand-derived formulas can be checked against the oracle -- and
+// run under AddressSanitizer/UBSan -- on machines without a GPU.  Not a product path: nothing under
+// cmad_amd/ loads this.
+#include <cstdint>
+#include <cstring>
+#define CM_HOST_BUILD 1
+#include "../../cmad_amd/csrc/cm_device.hpp"
+
+using namespace cm;
+
+template <int DEF, int YK, bool ROT>
+static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, const double* xi_prev,
+                       double* xi, double* sigma, uint32_t* status, double* dsig) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    for (int64_t b = 0; b < B; ++b) {
+        double G[NU], xp[NX], x[NX], eg[6], z[6];
+        for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b];
+        for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
+        strain_from_gradu<DEF, ROT>(m, G, eg);
+        strain_z<ROT>(m, z);
+        uint32_t st = newton<DEF, YK>(m, eg, z, xp, x, true);
+        Eval<DEF> ev;
+        strain_stress<DEF>(m, eg, z, x, ev);
+        double sg[6];
+        to_global<ROT>(m, ev.s, sg);
+        for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
+        if (sigma) for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
+        if (status) status[b] = st;
+        if (dsig) {
+            double T[6][6];
+            tangent_point<DEF, YK>(m, eg, z, x, xp, T);
+            for (int c = 0; c < NU; ++c) {
+                double Gd[NU], dm[6], t[6], tg[6];
+                for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+                strain_from_gradu<DEF, ROT>(m, Gd, dm);
+                for (int r = 0; r < 6; ++r) { double s = 0; for (int l = 0; l < 6; ++l) s += T[r][l] * dm[l]; t[r] = s; }
+                to_global<ROT>(m, t, tg);
+                for (int r = 0; r < 6; ++r) dsig[(int64_t)(r * NU + c) * B + b] = tg[r];
+            }
+        }
+    }
+}
+
+// reverse sweep for a given sigma cotangent at given converged xi: pbar summed over points (KP order)
+template <int DEF, int YK, bool ROT>
+static void run_vjp(const cm_model_desc& m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                    const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        double G[NU], xp[NX], x[NX], eg[6], z[6], sb[6], sbm[6], pb[CM_NUM_PARAMS], xb[NX], eb[6], xi_in[NX];
+        for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b];
+        for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; if (xin) xi_in[k] = xin[k * B + b]; }
+        for (int k = 0; k < 6; ++k) sb[k] = sbar[k * B + b];
+        strain_from_gradu<DEF, ROT>(m, G, eg);
+        strain_z<ROT>(m, z);
+        cotangent_to_material<ROT>(m, sb, sbm);
+        reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+        for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
+        if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
+        if (gbar) for (int c = 0; c < NU; ++c) {
+            double Gd[NU], dm[6];
+            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gd, dm);
+            gbar[c * B + b] = dot<6>(eb, dm);
+        }
+    }
+}
+
+template <class F>
+static int dispatch(const cm_model_desc* m, F&& f) {
+    const bool rot = !m->rotation_is_identity;
+#define CM_CASE(D, Y) \
+    if (m->def_type == D && m->yield_kind == Y) { if (rot) f.template operator()<D, Y, true>(); else f.template operator()<D, Y, false>(); return 0; }
+    CM_CASE(CM_FULL_3D, CM_YIELD_J2)
+    CM_CASE(CM_FULL_3D, CM_YIELD_HILL)
+    CM_CASE(CM_FULL_3D, CM_YIELD_HOSFORD)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_J2)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_HILL)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
+#undef CM_CASE
+    return -2;
+}
+
+extern "C" {
+int hh_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+              double* xi, double* sigma, uint32_t* status, double* dsig) {
+    return dispatch(m, [&]<int D, int Y, bool R>() { run_update<D, Y, R>(*m, B, gradu, xi_prev, xi, sigma, status, dsig); });
+}
+int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+           const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
+    return dispatch(m, [&]<int D, int Y, bool R>() { run_vjp<D, Y, R>(*m, B, gradu, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
+}
+int hh_sizeof_desc(void) { return (int)sizeof(cm_model_desc); }
+}

@@ -266,10 +266,12 @@ class Material:
                                        _p(g), _p(Jb), _p(xk), nthreads)
         return J.value, g, Jb, xk
 
-    def update_vjp_batch(self, gradu, xi_prev, xi, sbar6, gradu_prev=None, nthreads=0):
+    def update_vjp_batch(self, gradu, xi_prev, xi, sbar6, gradu_prev=None, nthreads=0, want_bars=True):
         gradu, xi_prev, xi, sbar6 = f64(gradu), f64(xi_prev), f64(xi), f64(sbar6)
         B = gradu.shape[1]
-        g = np.zeros(NP); xb = np.zeros((self.nx, B)); ub = np.zeros((self.nu, B))
+        g = np.zeros(NP)
+        xb = np.zeros((self.nx, B)) if want_bars else None
+        ub = np.zeros((self.nu, B)) if want_bars else None
         gp = None if gradu_prev is None else f64(gradu_prev)
         lib().orc_update_vjp_batch(C.byref(self.desc), _p(self.p), B, _p(gradu), _p(gp), _p(xi_prev), _p(xi),
                                    _p(sbar6), _p(g), _p(xb), _p(ub), nthreads)

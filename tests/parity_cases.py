@@ -1,0 +1,143 @@
+"""Shared parity scenarios: the same seeded inputs are pushed through a backend (the HIP library on a
+GPU, or the host build of the same per-point math) and through the CPU oracle, then compared.
+
+Tolerances: fp64, rtol 1e-10 on state/stress (north star), atol scaled to field magnitudes
+(strain ~1e-3, stress ~1e2); batch sums at rtol 1e-9 (different summation order)."""
+import numpy as np
+
+import oracle_lib as ol
+
+XI_ATOL = 1e-13
+HILL = [0.1477, 0.6805, 0.5345, 1.7977, 1.7148, 2.1675]
+YIELDS = [("J2", {}), ("hill", {"hill": HILL}), ("hosford", {"a": 4.}), ("hosford", {"a": 8.})]
+
+
+def rand_rot(rng):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] *= -1
+    return q
+
+
+def settings_pair(ls):
+    from cmad_amd.models.device import NewtonSettings
+    if ls:
+        return (ol.newton_settings(max_iters=20, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=4),
+                NewtonSettings.traced(max_iters=20, abs_tol=1e-12, rel_tol=1e-12))
+    return ol.newton_settings(), NewtonSettings()
+
+
+def param_paths(yield_kind):
+    p = [("elastic", "E"), ("elastic", "nu"),
+         ("plastic", "flow stress", "initial yield", "Y"),
+         ("plastic", "flow stress", "hardening", "voce", "S"),
+         ("plastic", "flow stress", "hardening", "voce", "D")]
+    if yield_kind == "hill":
+        p += [("plastic", "effective stress", "hill", n) for n in ol.HILL_NAMES]
+    return p
+
+
+def leaf_grads(g_kp, info, mat, yield_kind, g_oracle):
+    from cmad_amd.models.device import kp_to_leaf_grad
+    got = np.array([kp_to_leaf_grad(path, g_kp, info) for path in param_paths(yield_kind)])
+    ref = np.array([g_oracle[mat.param_index(path)] for path in param_paths(yield_kind)])
+    return got, ref
+
+
+class Scenario:
+    """Material + a non-trivial previous state + a load step, with the oracle's answers."""
+
+    def __init__(self, def_type, yield_kind, kw, rot, ls, B, seed=22):
+        from cmad_amd.models.device import build_desc
+        from cmad_amd.synthetic import gauss_point_batch
+        rng = np.random.default_rng(seed)
+        self.yield_kind = yield_kind
+        self.values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+        self.nd = 3 if def_type == ol.FULL_3D else 2
+        self.st_o, self.st_d = settings_pair(ls)
+        self.mat = ol.Material(self.values, def_type=def_type)
+        self.desc, self.info = build_desc(self.values, def_type=def_type, newton=self.st_d)
+        self.B = B
+        g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=self.nd)
+        self.gradu0 = g0
+        self.xi0 = np.tile(self.mat.init_xi()[:, None], (1, B))
+        self.xi1, self.sig1, self.it1, self.cv1 = self.mat.update_batch(self.st_o, g0, self.xi0)
+        self.gradu = 1.4 * g0 + 0.2 * gauss_point_batch(B, seed=seed + 1, skew=True, ndims=self.nd)
+        self.xi2, self.sig2, self.it2, self.cv2 = self.mat.update_batch(self.st_o, self.gradu, self.xi1)
+        assert self.cv1.all() and self.cv2.all(), "oracle did not converge on the synthetic batch"
+
+
+def check_update(backend, sc):
+    for gradu, xp, xi_o, sig_o, it_o in ((sc.gradu0, sc.xi0, sc.xi1, sc.sig1, sc.it1),
+                                         (sc.gradu, sc.xi1, sc.xi2, sc.sig2, sc.it2)):
+        xi_d, sig_d, status = backend.update(sc, gradu, xp)
+        status = status.astype(np.uint32)
+        it_d = (status & 0xFFFF).astype(np.int32)
+        assert ((status >> 16) & 1).all(), "backend did not converge on the synthetic batch"
+        assert ((status >> 18) & 1).sum() == 0
+        # the local Newton stops at ||C|| < 1e-14 (1e-12 with the FE settings), so two correct solves
+        # of the same point may differ by ~10x that in xi (|xi| ~ 1e-3) and 2 mu x that in stress
+        np.testing.assert_allclose(xi_d, xi_o, rtol=1e-10, atol=XI_ATOL)
+        np.testing.assert_allclose(sig_d, sig_o, rtol=1e-10, atol=1e-8)
+        # identical algorithm -> identical iteration counts except where a norm sits at the tolerance
+        assert np.mean(it_d == it_o) > 0.98
+        assert np.abs(it_d - it_o).max() <= 1
+        assert (it_o > 0).mean() > 0.2          # a real share of plastic points
+
+
+def check_tangent(backend, sc):
+    ds_o, _ = sc.mat.tangent_batch(sc.gradu, sc.xi1, sc.xi2)
+    xi_d, sig_d, st, ds_d = backend.update(sc, sc.gradu, sc.xi1, tangent=True)
+    np.testing.assert_allclose(xi_d, sc.xi2, rtol=1e-10, atol=XI_ATOL)
+    scale = np.abs(ds_o).max()
+    np.testing.assert_allclose(ds_d, ds_o, rtol=1e-9, atol=1e-10 * scale)
+
+
+def check_vjp(backend, sc, incoming=False):
+    rng = np.random.default_rng(5)
+    sbar = rng.normal(size=(6, sc.B))
+    g_o, xb_o, ub_o = sc.mat.update_vjp_batch(sc.gradu, sc.xi1, sc.xi2, sbar)
+    g_d, xb_d, ub_d = backend.vjp(sc, sc.gradu, sc.xi1, sc.xi2, sbar)
+    np.testing.assert_allclose(xb_d, xb_o, rtol=1e-9, atol=1e-9 * np.abs(xb_o).max())
+    np.testing.assert_allclose(ub_d, ub_o, rtol=1e-9, atol=1e-9 * np.abs(ub_o).max())
+    got, ref = leaf_grads(g_d, sc.info, sc.mat, sc.yield_kind, g_o)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+    return sbar, ref
+
+
+class HostBackend:
+    """Host build of cm_device.hpp (tests/native) -- CPU CI coverage of the kernel arithmetic."""
+
+    def update(self, sc, gradu, xi_prev, tangent=False):
+        import host_harness_lib as hh
+        return hh.update(sc.desc, gradu, xi_prev, sc.mat.nx, tangent=tangent)
+
+    def vjp(self, sc, gradu, xi_prev, xi, sbar):
+        import host_harness_lib as hh
+        return hh.vjp(sc.desc, gradu, xi_prev, xi, sbar)
+
+
+class GpuBackend:
+    """The product path: C-ABI of libcmad_hip.so on cuda:0."""
+
+    def ev(self, sc):
+        from cmad_amd.models.device import DeviceEvaluator
+        if getattr(sc, "_gpu_ev", None) is None:
+            sc._gpu_ev = DeviceEvaluator(sc.desc, sc.info)
+        return sc._gpu_ev
+
+    @staticmethod
+    def t(a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def update(self, sc, gradu, xi_prev, tangent=False):
+        out = self.ev(sc).update(self.t(gradu), self.t(xi_prev), tangent=tangent)
+        res = [o.cpu().numpy() for o in out]
+        res[2] = res[2].astype(np.uint32)
+        return tuple(res)
+
+    def vjp(self, sc, gradu, xi_prev, xi, sbar):
+        g, xb, ub = self.ev(sc).update_vjp(self.t(gradu), self.t(xi_prev), self.t(xi), self.t(sbar),
+                                           want_xi_prev_bar=True, want_gradu_bar=True)
+        return g.cpu().numpy(), xb.cpu().numpy(), ub.cpu().numpy()

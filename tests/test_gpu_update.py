@@ -1,0 +1,74 @@
+"""GPU parity of the HIP stress update against the CPU oracle, through the C-ABI (`-m gpu`).
+Scenarios and tolerances: tests/parity_cases.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return pc.GpuBackend()
+
+
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS)
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_update(backend, def_type, yield_kind, kw, rot, ls):
+    pc.check_update(backend, pc.Scenario(def_type, yield_kind, kw, rot, ls, B=4096))
+
+
+def test_ragged_and_tiny_batches():
+    """B not a multiple of the block / wave size, B = 1, B = 0."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+    values = ol.j2_voce_values()
+    mat = ol.Material(values)
+    desc, info = build_desc(values)
+    ev = DeviceEvaluator(desc, info)
+    for B in (1, 63, 65, 257, 1000):
+        gradu = gauss_point_batch(B, seed=B, dev_scale=6.0)
+        xi_prev = np.zeros((7, B))
+        xi_o, sig_o, it_o, _ = mat.update_batch(ol.newton_settings(), gradu, xi_prev)
+        xi_d, sig_d, st = ev.update(torch.from_numpy(gradu).cuda(), torch.from_numpy(xi_prev).cuda())
+        np.testing.assert_allclose(xi_d.cpu().numpy(), xi_o, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(sig_d.cpu().numpy(), sig_o, rtol=1e-10, atol=1e-8)
+    g0 = torch.empty((9, 0), dtype=torch.float64, device="cuda")
+    x0 = torch.empty((7, 0), dtype=torch.float64, device="cuda")
+    xi, sig, st = ev.update(g0, x0)
+    assert xi.shape == (7, 0)
+
+
+def test_elastic_points_take_zero_iterations():
+    """FULL_3D elastic steps satisfy C_e(x_prev) = 0 exactly -> 0 iterations."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+    values = ol.j2_voce_values()
+    desc, info = build_desc(values)
+    ev = DeviceEvaluator(desc, info)
+    gradu = gauss_point_batch(2048, dev_scale=0.5)          # all below yield
+    xi, sig, st = ev.update(torch.from_numpy(gradu).cuda(), torch.zeros((7, 2048), dtype=torch.float64, device="cuda"))
+    st = st.cpu().numpy().astype(np.uint32)
+    assert ((st & 0xFFFF) == 0).all() and ((st >> 16) & 1).all() and not ((st >> 17) & 1).any()
+    assert torch.count_nonzero(xi).item() == 0
+
+
+def test_bad_arguments_raise():
+    """Host-side operand checks run before any launch: wrong shape / dtype / device are ValueErrors."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    desc, info = build_desc(ol.j2_voce_values())
+    ev = DeviceEvaluator(desc, info)
+    g = torch.zeros((9, 8), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        ev.update(g, torch.zeros((7, 9), dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        ev.update(g.float(), torch.zeros((7, 8), dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        ev.update(g.cpu(), torch.zeros((7, 8), dtype=torch.float64))
