@@ -105,16 +105,19 @@ __device__ __forceinline__ void block_reduce_store(double* v, double* __restrict
     }
 }
 
-// final deterministic reduction: one block, fixed order.  out[k] (+)= sum_blocks partials[blk][k]
+// deterministic two-stage reduction of the block partials (fixed order, no atomics):
+// stage 1: kRedBlocks blocks each sum a contiguous slice of rows -> stage[kRedBlocks][NV]
+// stage 2: one block sums the kRedBlocks rows -> out[k] (+)= ...
+constexpr int kRedBlocks = 128;
+
 template <int NV>
-__global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ partials, int64_t nblocks,
-                                                   double* __restrict__ out, int out_offset, int accumulate) {
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int64_t begin, int64_t end, double* res) {
     double acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.0;
-    for (int64_t i = threadIdx.x; i < nblocks; i += kBlock) {
+    for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) acc[k] += partials[i * NV + k];
+        for (int k = 0; k < NV; ++k) acc[k] += rows[i * NV + k];
     }
     __shared__ double sh[kBlock / 64][NV];
 #pragma unroll
@@ -134,8 +137,31 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ pa
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
+        res[threadIdx.x] = s;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_reduce_stage1(const double* __restrict__ partials, int64_t nrows,
+                                                          double* __restrict__ stage) {
+    const int64_t per = (nrows + kRedBlocks - 1) / kRedBlocks;
+    const int64_t begin = (int64_t)blockIdx.x * per;
+    const int64_t end = begin + per < nrows ? begin + per : nrows;
+    __shared__ double res[NV];
+    reduce_rows<NV>(partials, begin < nrows ? begin : nrows, end, res);
+    __syncthreads();
+    if (threadIdx.x < NV) stage[(int64_t)blockIdx.x * NV + threadIdx.x] = res[threadIdx.x];
+}
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_reduce_stage2(const double* __restrict__ stage, double* __restrict__ out,
+                                                          int out_offset, int accumulate) {
+    __shared__ double res[NV];
+    reduce_rows<NV>(stage, 0, kRedBlocks, res);
+    __syncthreads();
+    if (threadIdx.x < NV) {
         const int o = out_offset + threadIdx.x;
-        out[o] = accumulate ? out[o] + s : s;
+        out[o] = accumulate ? out[o] + res[threadIdx.x] : res[threadIdx.x];
     }
 }
 
@@ -310,8 +336,9 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         });
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
-    // MODE 0 has no objective: skip slot 0 of the partials by reducing all and writing grad only
-    hipLaunchKernelGGL((k_reduce<kRed>), dim3(1), dim3(kBlock), 0, s, partials, nb, out, out_offset, accumulate);
+    double* stage = partials + nb * kRed;
+    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kBlock), 0, s, partials, B > 0 ? nb : 0, stage);
+    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kBlock), 0, s, stage, out, out_offset, accumulate);
     return check_launch();
 }
 
@@ -341,7 +368,7 @@ int cm_num_gradu(const cm_model_desc* m) {
 int64_t cm_workspace_bytes(int64_t B) {
     if (B < 0) return CM_ERR_BAD_ARG;
     const int64_t nb = B == 0 ? 1 : nblocks_of(B);
-    return (nb + 1) * kRed * (int64_t)sizeof(double);      // block partials + one result row
+    return (nb + kRedBlocks + 1) * kRed * (int64_t)sizeof(double);   // block partials + stage rows + one result row
 }
 
 int cm_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
