@@ -640,4 +640,134 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
     return ok;
 }
 
+
+// ---- explicit derivative blocks at an arbitrary state (the reference's stateful evaluate() surface) ----
+// cmad/models/model.py:168-190 (Jac for DXI / DXI_PREV / DPARAMS / DU) and :273-293 (dSigma).
+// Column counts: DXI, DXI_PREV -> NX ; DPARAMS -> CM_NUM_PARAMS (KP order) ; DU -> NU.
+// J is row-major [NX][ncols], S is [6][ncols] (global stress 6-vector rows).
+enum { CM_W_XI = 0, CM_W_XI_PREV = 1, CM_W_PARAMS = 2, CM_W_U = 3, CM_W_NONE = 5 };
+
+template <int DEF, int YK, bool ROT>
+CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double* x, const double* xp, int which,
+                          double* C, double* J /* NX x ncols or null */, double* sg /* 6 */, double* S /* 6 x ncols or null */) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    double eg[6], z[6], Ht[6][6];
+    Eval<DEF> ev;
+    strain_from_gradu<DEF, ROT>(m, G, eg);
+    strain_z<ROT>(m, z);
+    residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
+    to_global<ROT>(m, ev.s, sg);
+    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
+    if (which == CM_W_NONE) return;
+    // material-frame stress derivative columns ds[6] per column, then rotated
+    auto put_S = [&](int c, const double ds[6]) {
+        if (!S) return;
+        double dg[6];
+        to_global<ROT>(m, ds, dg);
+        for (int r = 0; r < 6; ++r) S[r * ncols + c] = dg[r];
+    };
+    const double zero6[6] = {0, 0, 0, 0, 0, 0};
+    if (which == CM_W_XI) {
+        double A[NX][NX];
+        jacobian_x<DEF, false>(m, z, ev, Ht, A);
+        if (J) for (int r = 0; r < NX; ++r) for (int c = 0; c < NX; ++c) J[r * NX + c] = A[r][c];
+        for (int c = 0; c < 6; ++c) {
+            double de[6] = {0, 0, 0, 0, 0, 0}, ds[6];
+            de[c] = -1.0;
+            apply_cel(m, de, ds);
+            put_S(c, ds);
+        }
+        put_S(6, zero6);
+        if constexpr (DEF == CM_PLANE_STRESS) { double ds[6]; apply_cel(m, z, ds); put_S(7, ds); }
+    } else if (which == CM_W_XI_PREV) {
+        if (J) {
+            for (int r = 0; r < NX; ++r) for (int c = 0; c < NX; ++c) J[r * NX + c] = 0.0;
+            for (int k = 0; k < 6; ++k) J[k * NX + k] = -1.0;
+            if (ev.plastic) { for (int k = 0; k < 6; ++k) J[k * NX + 6] = ev.gt[k] * kIW[k]; }
+            else J[6 * NX + 6] = -1.0;
+        }
+        for (int c = 0; c < NX; ++c) put_S(c, zero6);
+    } else if (which == CM_W_PARAMS) {
+        constexpr int NP_ = CM_NUM_PARAMS;
+        if (J) for (int i = 0; i < NX * NP_; ++i) J[i] = 0.0;
+        double dvec[6], e2[6], Hd[6], He[6];
+        for (int k = 0; k < 6; ++k) { dvec[k] = kDiag[k] ? 1.0 : 0.0; e2[k] = 2.0 * ev.e[k]; }
+        for (int k = 0; k < 6; ++k) {
+            double a = 0, b = 0;
+            for (int l = 0; l < 6; ++l) { a += Ht[k][l] * dvec[l]; b += Ht[k][l] * e2[l]; }
+            Hd[k] = a; He[k] = b;
+        }
+        if (J && ev.plastic) {
+            const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5], ge2 = dot<6>(ev.gt, e2);
+            for (int k = 0; k < 6; ++k) {
+                J[k * NP_ + CM_P_LAMBDA] = -ev.dgam * kIW[k] * Hd[k] * ev.tr;
+                J[k * NP_ + CM_P_MU] = -ev.dgam * kIW[k] * He[k];
+            }
+            J[6 * NP_ + CM_P_LAMBDA] = gd * ev.tr * i2mu;
+            J[6 * NP_ + CM_P_MU] = ge2 * i2mu - ev.f / m.mu;
+            J[6 * NP_ + CM_P_Y] = -i2mu;
+            if (m.has_voce) {
+                J[6 * NP_ + CM_P_VOCE_S] = -(1.0 - ev.hd.expo) * i2mu;
+                J[6 * NP_ + CM_P_VOCE_D] = -m.voce_S * x[6] * ev.hd.expo * i2mu;
+            }
+            if (m.has_linear) J[6 * NP_ + CM_P_LIN_K] = -x[6] * i2mu;
+            if constexpr (YK == CM_YIELD_HILL) {
+                const double* s = ev.s;
+                const double ip = 1.0 / ev.phi;
+                const double d12 = s[3] - s[5], d20 = s[5] - s[0], d01 = s[0] - s[3];
+                const double qj[6] = {d12 * d12, d20 * d20, d01 * d01, 2.0 * s[4] * s[4], 2.0 * s[2] * s[2], 2.0 * s[1] * s[1]};
+                double dAs[6][6] = {{0}};     // [j][k] = (dA/dc_j s)_k
+                dAs[0][3] = d12; dAs[0][5] = -d12;
+                dAs[1][5] = d20; dAs[1][0] = -d20;
+                dAs[2][0] = d01; dAs[2][3] = -d01;
+                dAs[3][4] = 2.0 * s[4]; dAs[4][2] = 2.0 * s[2]; dAs[5][1] = 2.0 * s[1];
+                for (int j = 0; j < 6; ++j) {
+                    for (int k = 0; k < 6; ++k) {
+                        const double dg = dAs[j][k] * ip - ev.gt[k] * qj[j] * 0.5 * ip * ip;
+                        J[k * NP_ + CM_P_YC0 + j] = -ev.dgam * kIW[k] * dg;
+                    }
+                    J[6 * NP_ + CM_P_YC0 + j] = qj[j] * 0.5 * ip * i2mu;
+                }
+            }
+        }
+        if constexpr (DEF == CM_PLANE_STRESS) {
+            if (J) {
+                const double zt = z[0] + z[3] + z[5];
+                double zwe = 0.0;
+                for (int k = 0; k < 6; ++k) zwe += kW[k] * z[k] * ev.e[k];
+                J[7 * NP_ + CM_P_LAMBDA] = zt * ev.tr * i2mu;
+                J[7 * NP_ + CM_P_MU] = 2.0 * zwe * i2mu - C[7] / m.mu;
+            }
+        }
+        for (int c = 0; c < NP_; ++c) {
+            double ds[6] = {0, 0, 0, 0, 0, 0};
+            if (c == CM_P_LAMBDA) for (int k = 0; k < 6; ++k) ds[k] = dvec[k] * ev.tr;
+            if (c == CM_P_MU) for (int k = 0; k < 6; ++k) ds[k] = e2[k];
+            put_S(c, ds);
+        }
+    } else if (which == CM_W_U) {
+        for (int c = 0; c < NU; ++c) {
+            double Gd[NU], dm[6], cd[6];
+            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gd, dm);        // d eg / d G_c
+            apply_cel(m, dm, cd);                          // Cel d eg
+            put_S(c, cd);
+            if (J) {
+                for (int k = 0; k < 6; ++k) {
+                    double hc = 0.0;
+                    for (int l = 0; l < 6; ++l) hc += Ht[k][l] * cd[l];
+                    J[k * NU + c] = ev.plastic ? -ev.dgam * kIW[k] * hc : 0.0;
+                }
+                J[6 * NU + c] = ev.plastic ? dot<6>(ev.gt, cd) * i2mu : 0.0;
+                if constexpr (DEF == CM_PLANE_STRESS) {
+                    double r = 0.0;
+                    for (int k = 0; k < 6; ++k) r += kW[k] * z[k] * cd[k];
+                    J[7 * NU + c] = r * i2mu;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace cm

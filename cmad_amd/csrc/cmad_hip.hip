@@ -262,6 +262,29 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
     block_reduce_store<kRed>(red, partials);
 }
 
+// ---- cm_evaluate: residual / Jacobian block / stress / stress-derivative block at given states ----------
+template <int DEF, int YK, bool ROT>
+__global__ __launch_bounds__(64) void k_evaluate(cm_model_desc m, int64_t B, int which,
+        const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi,
+        double* __restrict__ C_out, double* __restrict__ J_out, double* __restrict__ s_out, double* __restrict__ S_out) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int MAXC = CM_NUM_PARAMS;
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double G[NU], xp[NX], x[NX], C[NX], sg[6], J[NX * MAXC], S[6 * MAXC];
+    load_soa<NU>(gradu, B, b, G);
+    load_soa<NX>(xi_prev, B, b, xp);
+    load_soa<NX>(xi, B, b, x);
+    evaluate_blocks<DEF, YK, ROT>(m, G, x, xp, which, C, J_out ? J : nullptr, sg, S_out ? S : nullptr);
+    const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
+    if (C_out) store_soa<NX>(C_out, B, b, C);
+    if (s_out) store_soa<6>(s_out, B, b, sg);
+    if (which != CM_W_NONE) {
+        if (J_out) for (int i = 0; i < NX * ncols; ++i) J_out[(int64_t)i * B + b] = J[i];
+        if (S_out) for (int i = 0; i < 6 * ncols; ++i) S_out[(int64_t)i * B + b] = S[i];
+    }
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 
@@ -411,6 +434,24 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
 }
 
 int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
+
+int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
+                const double* xi, double* C, double* jac, double* sigma, double* dsigma, void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m)) return CM_ERR_UNSUPPORTED;
+    if (which != CM_W_XI && which != CM_W_XI_PREV && which != CM_W_PARAMS && which != CM_W_U && which != CM_W_NONE)
+        return CM_ERR_BAD_ARG;
+    if (B == 0) return CM_OK;
+    if (!gradu || !xi_prev || !xi) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    dispatch(m, [&]<int D, int Y, bool R>() {
+        hipLaunchKernelGGL((k_evaluate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, xi_prev, xi, C, jac, sigma, dsigma);
+    });
+    return check_launch();
+}
 
 int cm_objective_grad(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       const double* data, const double* wsq6, double* out, double* xi,

@@ -1,0 +1,388 @@
+"""`Model`: material-point constitutive model contract -- host mirror of the reference's
+``cmad.models.model.Model`` (/root/reference/cmad/models/model.py:25-563), same method names, argument
+meaning and assertion behaviour.
+
+Where the reference jit-compiles a residual and lets JAX produce Jacobians, every evaluation here is a
+launch of the HIP library (include/cmad_hip.h): `evaluate()` / `evaluate_cauchy()` call `cm_evaluate` with
+B = 1; the batched additions (`update_batch`, `update_tangent_batch`, `update_vjp_batch`,
+`objective_grad_batch`) expose the data-parallel kernels directly.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from abc import ABC
+from typing import Any, ClassVar, Sequence
+
+import numpy as np
+
+from .. import _lib
+from ..parameters.parameters import Parameters
+from .deriv_types import DerivType
+from .device import DeviceEvaluator, NewtonSettings, _ptr, build_desc, kp_to_leaf_grad
+from .global_fields import GlobalFieldsAtPoint
+from .var_types import VarType
+
+_V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+
+
+def _sym3(v6):
+    """6 stored entries (leading axis) -> symmetric 3x3 (two leading axes)."""
+    v6 = np.asarray(v6)
+    out = np.zeros((3, 3) + v6.shape[1:], dtype=v6.dtype)
+    for r, (i, j) in enumerate(_V6):
+        out[i, j] = v6[r]
+        out[j, i] = v6[r]
+    return out
+
+
+class Model(ABC):
+    """Material-point constitutive model (reference :25-88)."""
+
+    supports_closed_form_cauchy: ClassVar[bool] = False
+    supports_mixed: ClassVar[bool] = False
+
+    # set by subclasses before Model.__init__ (reference :42-49)
+    parameters: Parameters
+    dtype: type
+    _is_complex: bool
+    _ndims: int
+    _def_type: int
+    _model_kind: int = 0
+    _yield_tol: float = 1e-14
+    _uniaxial_stress_idx: int = 0
+
+    @classmethod
+    def from_deck(cls, model_section: dict, parameters: Parameters, def_type: int) -> "Model":
+        raise NotImplementedError
+
+    @classmethod
+    def material_defaults(cls) -> dict:
+        return {}
+
+    def __init__(self) -> None:
+        if getattr(self, "_is_complex", False):
+            # the reference's complex-step models (is_complex=True) rely on holomorphic JAX tracing
+            raise NotImplementedError("complex-step models are not available in the HIP path")
+        self._deriv_mode = DerivType.DNONE
+        self.newton_settings = NewtonSettings()
+        self.parameters.compute_mixed_block_shapes(self._num_eqs)
+        self._Jac = None
+        self._dSigma = None
+
+    # ------------------------------------------------------------------ device plumbing
+    def _desc(self, params=None, newton: NewtonSettings | None = None):
+        return build_desc(self.parameters.values if params is None else params, def_type=self._def_type,
+                          model_kind=self._model_kind, yield_tol=self._yield_tol,
+                          uniaxial_stress_idx=self._uniaxial_stress_idx, newton=newton or self.newton_settings)
+
+    def device_evaluator(self, newton: NewtonSettings | None = None) -> DeviceEvaluator:
+        """A `DeviceEvaluator` for the CURRENT parameter values (rebuilt per call: parameters change between
+        objective evaluations, and the description is 296 bytes)."""
+        return DeviceEvaluator(*self._desc(newton=newton))
+
+    @staticmethod
+    def _flat(blocks) -> np.ndarray:
+        return np.concatenate([np.atleast_1d(np.asarray(b, dtype=np.float64)).ravel() for b in blocks])
+
+    def _point_evaluate(self, which, xi, xi_prev, params, U, want_jac=True):
+        """cm_evaluate for one point -> (C, J, sigma6, S) as numpy."""
+        import torch
+        desc, info = self._desc(params)
+        L = _lib.lib()
+        nx, nu = L.cm_num_xi(C.byref(desc)), L.cm_num_gradu(C.byref(desc))
+        if nx < 0:
+            raise NotImplementedError("def_type not available in the HIP library")
+        dev = torch.device("cuda")
+        G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).to(dev)
+        g, x1, x0 = t(G), t(self._flat(xi)), t(self._flat(xi_prev))
+        ncols = {0: nx, 1: nx, 2: _lib.CM_NUM_PARAMS, 3: nu, 5: 1}[int(which)]
+        Cd = torch.empty((nx, 1), dtype=torch.float64, device=dev)
+        s = torch.empty((6, 1), dtype=torch.float64, device=dev)
+        J = torch.empty((nx * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
+        S = torch.empty((6 * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
+        rc = L.cm_evaluate(C.byref(desc), 1, int(which), _ptr(g), _ptr(x0), _ptr(x1), _ptr(Cd), _ptr(J), _ptr(s), _ptr(S),
+                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "cm_evaluate")
+        out_J = J.cpu().numpy().reshape(nx, ncols) if want_jac and which != DerivType.DNONE else None
+        out_S = S.cpu().numpy().reshape(6, ncols) if want_jac and which != DerivType.DNONE else None
+        return Cd.cpu().numpy()[:, 0], out_J, s.cpu().numpy()[:, 0], out_S, info
+
+    def _active_columns(self, M_kp, info):
+        """(rows, KP) kernel-order block -> (rows, num_active_params) in Parameters' flat active order
+        (reference `_active_params_jacobian`, parameters.py:368-377)."""
+        cols = [kp_to_leaf_grad(path[:-1] if isinstance(path[-1], int) else path, M_kp.T, info)
+                for path in self.parameters.active_paths()]
+        return np.stack(cols, axis=1) if cols else np.zeros((M_kp.shape[0], 0))
+
+    # ------------------------------------------------------------------ reference :168-190
+    def evaluate(self) -> None:
+        """Evaluate the residual (C) or its jacobian (Jac)."""
+        xi, xi_prev, params, U, U_prev = self.variables()
+        mode = self._deriv_mode
+        if mode == DerivType.DNONE:
+            Cv, _, _, _, _ = self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)
+            self._C = np.asarray(Cv, dtype=self.dtype)
+            self._Jac = None
+        elif mode == DerivType.DPARAMS:
+            _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U)
+            self._Jac = np.asarray(self._active_columns(J, info), dtype=np.float64)
+        elif mode == DerivType.DU_PREV:
+            nu = self._ndims ** 2
+            self._Jac = np.zeros((self.num_dofs, nu))          # the small-strain residual ignores U_prev
+        else:
+            _, J, _, _, _ = self._point_evaluate(mode, xi, xi_prev, params, U)
+            self._Jac = J
+
+    def evaluate_hessians(self) -> None:
+        raise NotImplementedError("second derivatives of the residual are a SURVEY section 8(f) 'next' row")
+
+    # ------------------------------------------------------------------ reference :273-293
+    def evaluate_cauchy(self) -> None:
+        """Evaluate the cauchy stress (Sigma) or its derivatives (dSigma)."""
+        xi, xi_prev, params, U, U_prev = self.variables()
+        mode = self._deriv_mode
+        if mode == DerivType.DNONE:
+            _, _, s6, _, _ = self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)
+            self._Sigma = np.asarray(_sym3(s6), dtype=np.float64)
+            self._dSigma = None
+        elif mode == DerivType.DU_PREV:
+            self._dSigma = np.zeros((3, 3, self._ndims ** 2))
+        elif mode == DerivType.DPARAMS:
+            _, _, _, S, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U)
+            S9 = _sym3(S).reshape(9, -1)                                   # (9, KP)
+            self._dSigma = np.asarray(self._active_columns(S9, info), dtype=np.float64)
+        else:
+            _, _, _, S, _ = self._point_evaluate(mode, xi, xi_prev, params, U)
+            self._dSigma = _sym3(S)                                         # (3, 3, n_xi) == np.dstack of blocks
+
+    def set_xi_to_init_vals(self) -> None:
+        for ii in range(self.num_residuals):
+            self._xi[ii] = self._init_xi[ii].copy().astype(self.dtype)
+            self._xi_prev[ii] = self._init_xi[ii].copy().astype(self.dtype)
+
+    def C(self):
+        return self._C
+
+    def Jac(self):
+        assert self._Jac is not None, "Jac() requires a non-DNONE deriv mode (seed_xi/xi_prev/params)"
+        return self._Jac
+
+    def Sigma(self):
+        return self._Sigma
+
+    def dSigma(self):
+        assert self._dSigma is not None, "dSigma() requires a non-DNONE deriv mode (seed_xi/xi_prev/params)"
+        return self._dSigma
+
+    # ------------------------------------------------------------------ pure-function surface (:125-153, :316-374)
+    def _split(self, flat):
+        out, pos = [], 0
+        for n in self._num_eqs:
+            out.append(np.array(flat[pos:pos + n]))
+            pos += n
+        return out
+
+    def _residual(self, xi, xi_prev, params, U, U_prev):
+        return self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)[0]
+
+    def cauchy(self, xi, xi_prev, params, U, U_prev):
+        return _sym3(self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)[2])
+
+    def _block_list(self, J):
+        """(n_xi, n_xi) -> list over variable blocks of (n_xi, n_block) arrays, the pytree jacfwd returns."""
+        out, pos = [], 0
+        for n in self._num_eqs:
+            out.append(J[:, pos:pos + n])
+            pos += n
+        return out
+
+    def dC_dxi(self, xi, xi_prev, params, U, U_prev):
+        return self._block_list(self._point_evaluate(DerivType.DXI, xi, xi_prev, params, U)[1])
+
+    def dC_dxi_prev(self, xi, xi_prev, params, U, U_prev):
+        return self._block_list(self._point_evaluate(DerivType.DXI_PREV, xi, xi_prev, params, U)[1])
+
+    def dC_dp(self, xi, xi_prev, params, U, U_prev):
+        """Active-parameter columns (n_xi, num_active); the reference returns the full params pytree and
+        slices with `model_active_params_jacobian` -- callers only ever use the active slice."""
+        _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U)
+        return self._active_columns(J, info)
+
+    def dC_dU(self, xi, xi_prev, params, U, U_prev):
+        J = self._point_evaluate(DerivType.DU, xi, xi_prev, params, U)[1]
+        n = self._ndims
+        return GlobalFieldsAtPoint(fields={"u": np.zeros((self.num_dofs, n))},
+                                   grad_fields={"u": J.reshape(self.num_dofs, n, n)})
+
+    def dC_dU_prev(self, xi, xi_prev, params, U, U_prev):
+        n = self._ndims
+        return GlobalFieldsAtPoint(fields={"u": np.zeros((self.num_dofs, n))},
+                                   grad_fields={"u": np.zeros((self.num_dofs, n, n))})
+
+    def variables(self):
+        return (self._xi, self._xi_prev, self.parameters.values, self._U, self._U_prev)
+
+    # ------------------------------------------------------------------ reference :383-408
+    def _init_residuals(self, num_residuals: int) -> None:
+        self.num_residuals = num_residuals
+        self._num_eqs = np.zeros(num_residuals, dtype=int)
+        self._var_types = np.zeros(num_residuals, dtype=int)
+        self.resid_names = [None] * num_residuals
+        self.var_names = [None] * num_residuals
+
+    def _init_state_variables(self) -> None:
+        n = self.num_residuals
+        self._xi = [None] * n
+        self._xi_prev = [None] * n
+        self.num_dofs = 0
+        self._delta_xi_offsets = np.zeros(n, dtype=int)
+        for ii in range(n):
+            self._delta_xi_offsets[ii] += self.num_dofs
+            self.num_dofs += self._num_eqs[ii]
+
+    def delta_xi_offset(self, res_idx: int, eq_idx: int) -> int:
+        return self._delta_xi_offsets[res_idx] + eq_idx
+
+    def var_type(self, residual: int) -> int:
+        return self._var_types[residual]
+
+    def resid_name(self, residual: int):
+        return self.resid_names[residual]
+
+    def state_output_fields(self):
+        return [(self.var_names[r], VarType(int(self._var_types[r]))) for r in range(self.num_residuals)]
+
+    def derived_output_field_names(self):
+        return []
+
+    @property
+    def ndims(self) -> int:
+        return self._ndims
+
+    # ------------------------------------------------------------------ reference :451-525
+    def gather_global(self, U: GlobalFieldsAtPoint, U_prev: GlobalFieldsAtPoint) -> None:
+        self._U = U
+        self._U_prev = U_prev
+
+    def gather_xi(self, xi: Sequence, xi_prev: Sequence) -> None:
+        self._xi = list(xi)
+        self._xi_prev = list(xi_prev)
+
+    def seed_xi(self) -> None:
+        self._deriv_mode = DerivType.DXI
+
+    def seed_xi_prev(self) -> None:
+        self._deriv_mode = DerivType.DXI_PREV
+
+    def seed_params(self) -> None:
+        self._deriv_mode = DerivType.DPARAMS
+
+    def seed_none(self) -> None:
+        self._deriv_mode = DerivType.DNONE
+
+    def deriv_mode(self) -> int:
+        return self._deriv_mode
+
+    def xi(self):
+        return self._xi
+
+    def xi_prev(self):
+        return self._xi_prev
+
+    def advance_xi(self) -> None:
+        for ii in range(self.num_residuals):
+            self._xi_prev[ii] = self._xi[ii].copy()
+
+    def set_scalar_xi(self, idx: int, xi) -> None:
+        self._xi[idx] = xi.copy()
+
+    def set_vector_xi(self, idx: int, xi) -> None:
+        self._xi[idx] = xi.copy()
+
+    def set_sym_tensor_xi(self, idx: int, xi) -> None:
+        self._set_sym(self._xi, idx, xi)
+
+    def _set_sym(self, target, idx, t) -> None:
+        n = self._num_eqs[idx]
+        if n == 6:
+            target[idx][:] = [t[0, 0], t[0, 1], t[0, 2], t[1, 1], t[1, 2], t[2, 2]]
+        elif n == 3:
+            target[idx][:] = [t[0, 0], t[0, 1], t[1, 1]]
+        elif n == 1:
+            target[idx][0] = t[0, 0]
+
+    _NDIM_BY_NUM_EQS: ClassVar[dict] = {9: 3, 4: 2, 1: 1}
+
+    @staticmethod
+    def get_tensor_ndim(num_eqs: int) -> int:
+        try:
+            return Model._NDIM_BY_NUM_EQS[num_eqs]
+        except KeyError as e:
+            raise ValueError(f"Unknown num_eqs for tensor variable: {num_eqs}") from e
+
+    def set_tensor_xi(self, idx: int, xi) -> None:
+        n = Model.get_tensor_ndim(self._num_eqs[idx])
+        self._xi[idx][:] = np.asarray(xi)[:n, :n].reshape(-1)
+
+    def add_to_xi(self, delta_xi) -> None:
+        for idx in range(self.num_residuals):
+            if self._var_types[idx] != VarType.SCALAR:
+                for eq in range(self._num_eqs[idx]):
+                    self._xi[idx][eq] += delta_xi[self.delta_xi_offset(idx, eq)]
+            else:
+                self._xi[idx] = self._xi[idx] + delta_xi[self.delta_xi_offset(idx, 0)]
+
+    def set_scalar_xi_prev(self, idx: int, xi_prev) -> None:
+        self._xi_prev[idx] = xi_prev.copy()
+
+    def set_vector_xi_prev(self, idx: int, xi_prev) -> None:
+        self._xi_prev[idx] = xi_prev.copy()
+
+    def set_sym_tensor_xi_prev(self, idx: int, xi_prev) -> None:
+        self._set_sym(self._xi_prev, idx, xi_prev)
+
+    def set_tensor_xi_prev(self, idx: int, xi_prev) -> None:
+        n = Model.get_tensor_ndim(self._num_eqs[idx])
+        self._xi_prev[idx][:] = np.asarray(xi_prev)[:n, :n].reshape(-1)
+
+    @staticmethod
+    def store_xi(xi_list, xi_val, step: int) -> None:
+        for idx in range(len(xi_list[step])):
+            xi_list[step][idx] = xi_val[idx].copy()
+
+    # ------------------------------------------------------------------ local Newton on the device (B = 1)
+    def device_newton(self, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search=None):
+        """Solve the local problem for the gathered state with ONE `cm_update` launch; sets xi, returns
+        (iters, converged).  Same algorithm as newton_solve / make_newton_solve (nonlinear_solver.py)."""
+        import torch
+        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0})
+        ev = self.device_evaluator(st)
+        dev = torch.device("cuda")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).to(dev)
+        G = np.asarray(self._U.grad_fields["u"], dtype=np.float64)
+        xi, _, status = ev.update(t(G), t(self._flat(self._xi_prev)), want_sigma=False)
+        self._xi = [b.astype(self.dtype) for b in self._split(xi.cpu().numpy()[:, 0])]
+        s = int(status.cpu().numpy().astype(np.uint32)[0])
+        return s & _lib.STATUS_ITERS_MASK, bool(s & _lib.STATUS_CONVERGED)
+
+    # ------------------------------------------------------------------ batched API (new capability)
+    def update_batch(self, gradu, xi_prev, newton: NewtonSettings | None = None, **kw):
+        """(n_gradu, B), (n_xi, B) float64 CUDA tensors -> xi, sigma6, status."""
+        return self.device_evaluator(newton).update(gradu, xi_prev, **kw)
+
+    def update_tangent_batch(self, gradu, xi_prev, newton: NewtonSettings | None = None):
+        return self.device_evaluator(newton).update(gradu, xi_prev, tangent=True)
+
+    def active_grad_from_kp(self, g_kp, info=None):
+        """Kernel-order gradient (12,) -> Parameters' flat active order, NATIVE parameters (apply
+        `parameters.transform_grad` afterwards for canonical ones, as the objectives do)."""
+        info = info or self._desc()[1]
+        g = np.asarray(g_kp, dtype=np.float64)
+        return np.array([kp_to_leaf_grad(path[:-1] if isinstance(path[-1], int) else path, g, info)
+                         for path in self.parameters.active_paths()])
+
+    def update_vjp_batch(self, gradu, xi_prev, xi, sigma_bar, newton: NewtonSettings | None = None, **kw):
+        ev = self.device_evaluator(newton)
+        g, xb, ub = ev.update_vjp(gradu, xi_prev, xi, sigma_bar, **kw)
+        return self.active_grad_from_kp(g.cpu().numpy(), ev.info), xb, ub

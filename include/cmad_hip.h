@@ -171,6 +171,22 @@ int cm_adjoint_step(const cm_model_desc* m, int64_t B,
                     double* hist_out, double* out, int accumulate,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/*
+ * cm_evaluate: residual, one Jacobian block, stress and one stress-derivative block at GIVEN states
+ * (no Newton solve).  Replaces the stateful evaluate surface of the reference, per point:
+ * Model.evaluate() / C() / Jac() (cmad/models/model.py:168-190) and Model.evaluate_cauchy() / Sigma() /
+ * dSigma() (:273-293), whose derivative blocks the reference obtains with jacfwd/jacrev.
+ *   which: cm_deriv (cmad/models/deriv_types.py:4-10): 0 d/dxi, 1 d/dxi_prev, 2 d/dparams (KP order, native
+ *          lambda/mu), 3 d/dgradu, 5 none
+ *   out  : C[n_xi][B]; jac[n_xi*ncols][B], entry (r,c) at [(r*ncols+c)*B+b]; sigma[6][B];
+ *          dsigma[6*ncols][B] (rows = the 6 stored entries of the global stress); any may be NULL.
+ *          ncols = n_xi (0,1), CM_NUM_PARAMS (2), n_gradu (3).
+ */
+enum cm_deriv { CM_DXI = 0, CM_DXI_PREV = 1, CM_DPARAMS = 2, CM_DU = 3, CM_DU_PREV = 4, CM_DNONE = 5 };
+int cm_evaluate(const cm_model_desc* m, int64_t B, int which,
+                const double* gradu, const double* xi_prev, const double* xi,
+                double* C, double* jac, double* sigma, double* dsigma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,3 +60,16 @@ def vjp(desc, gradu, xi_prev, xi, sbar, xin=None):
     rc = L.hh_vjp(C.byref(desc), C.c_int64(B), _p(gradu), _p(xi_prev), _p(xi), _p(sbar), _p(xin), _p(g), _p(xb), _p(ub))
     assert rc == 0
     return g, xb, ub
+
+
+def evaluate(desc, which, gradu, xi_prev, xi, nx):
+    """Explicit blocks at given states: C (nx,B), J (nx,ncols,B), sigma6 (6,B), S (6,ncols,B)."""
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu, xi_prev, xi = c(gradu), c(xi_prev), c(xi)
+    B, nu = gradu.shape[1], gradu.shape[0]
+    ncols = {0: nx, 1: nx, 2: 12, 3: nu, 5: 1}[which]
+    Cc = np.zeros((nx, B)); J = np.zeros((nx * ncols, B)); s = np.zeros((6, B)); S = np.zeros((6 * ncols, B))
+    rc = L.hh_evaluate(C.byref(desc), C.c_int64(B), C.c_int(which), _p(gradu), _p(xi_prev), _p(xi), _p(Cc), _p(J), _p(s), _p(S))
+    assert rc == 0
+    return Cc, J.reshape(nx, ncols, B), s, S.reshape(6, ncols, B)

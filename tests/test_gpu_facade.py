@@ -1,0 +1,210 @@
+"""The reference's own tests, re-run through the cmad_amd facade (`-m gpu`; every model/qoi evaluation is a
+HIP launch):
+  * tests/models/test_elastic_plastic_models.py:15-125   analytical J2+Voce fields, J2/Hill/Hosford models
+  * tests/objectives/test_J2_fd_checks.py:303-386        direct == adjoint, FD error drops > 5 decades
+  * tests/objectives/test_calibrations.py:57-109         L-BFGS-B recovers [D, S, Y] to 1e-7
+  * tests/global_residuals/test_for_model_coupled.py:231-295  local equilibrium + IFT tangent vs FD
+plus the batched objective against the one-point-per-call objectives and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from problems import params_J2_voce, plane_stress_F
+
+pytestmark = pytest.mark.gpu
+
+
+def _models():
+    from cmad_amd.models import DefType, SmallElasticPlastic
+    return DefType, SmallElasticPlastic
+
+
+@pytest.mark.parametrize("def_name", ["FULL_3D", "PLANE_STRESS"])
+@pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
+def test_models_reproduce_analytical_fields(golden_dir, def_name, yield_kind):
+    from cmad_amd.models import mp_U_from_F, newton_solve
+    from cmad_amd.qois import Calibration
+    DefType, SmallElasticPlastic = _models()
+    def_type = getattr(DefType, def_name)
+    nd = 3 if def_type == DefType.FULL_3D else 2
+    g = np.load(os.path.join(golden_dir, "j2_voce_analytical.npz"))
+    for name in ("uniaxial", "biaxial"):
+        stress, strain, alpha, mask = g[f"{name}_stress"], g[f"{name}_strain"], g[f"{name}_alpha"], g[f"{name}_mask"]
+        num_steps = 100
+        F = np.repeat(np.eye(nd)[:, :, None], num_steps + 1, axis=2)
+        F[:, :, 1:] += strain[:nd, :nd, :]
+        model = SmallElasticPlastic(params_J2_voce(yield_kind=yield_kind), def_type)
+        weight = np.abs(mask)
+        cauchy = np.zeros((3, 3, num_steps + 1))
+        qoi = Calibration(model, cauchy.copy(), weight)
+        J = 0.
+        alphas = []
+        model.set_xi_to_init_vals()
+        for step in range(1, num_steps + 1):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            newton_solve(model)
+            alphas.append(model.xi()[1][0])
+            model.seed_none()
+            qoi.evaluate(step)
+            J += qoi.J()
+            model.evaluate_cauchy()
+            cauchy[:, :, step] = model.Sigma().copy()
+            model.advance_xi()
+        tol = 1e-6
+        assert np.linalg.norm(np.array(alphas) - alpha) < tol
+        assert np.linalg.norm(cauchy[:, :, 1:] - stress) < tol
+        assert abs(J - 0.5 * np.linalg.norm(weight[:, :, None] * cauchy) ** 2) < tol
+
+
+def _compute_cauchy(model, F):
+    from cmad_amd.models import mp_U_from_F, newton_solve
+    n = F.shape[2] - 1
+    cauchy = np.zeros((3, 3, n + 1))
+    model.set_xi_to_init_vals()
+    for step in range(1, n + 1):
+        model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+        newton_solve(model)
+        model.evaluate_cauchy()
+        cauchy[:, :, step] = model.Sigma().copy()
+        model.advance_xi()
+    return cauchy
+
+
+def _J_only(qoi, F):
+    from cmad_amd.models import mp_U_from_F, newton_solve
+    model = qoi.model()
+    model.set_xi_to_init_vals()
+    J = 0.
+    for step in range(1, F.shape[2]):
+        model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+        newton_solve(model)
+        model.seed_none()
+        qoi.evaluate(step)
+        J += qoi.J()
+        model.advance_xi()
+    return float(J)
+
+
+def test_direct_equals_adjoint_and_fd_error_drops():
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectObjective
+    from cmad_amd.qois import Calibration
+    DefType, SmallElasticPlastic = _models()
+    F = plane_stress_F(0.02, 10)                       # 20 steps (reference uses 100; same two-leg path)
+    model = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+    cauchy = _compute_cauchy(model, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    qoi = Calibration(model, cauchy, weight)
+    true_vals = model.parameters.flat_active_values(False)
+    model.parameters.set_active_values_from_flat(1.1 * true_vals, False)
+    x = model.parameters.flat_active_values(True)
+    Jd, gd = MPDirectObjective(qoi, F).evaluate(x)
+    Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
+    assert abs(Jd - Ja) <= 1e-12 * abs(Jd)
+    np.testing.assert_allclose(gd, ga, rtol=1e-9, atol=1e-10 * np.abs(ga).max())
+    rng = np.random.default_rng(22)
+    d = rng.uniform(-1., 1., size=x.size)
+    errs = []
+    for h in np.logspace(-1, -6, 6):
+        model.parameters.set_active_values_from_flat(x + h * d)
+        Jp = _J_only(qoi, F)
+        model.parameters.set_active_values_from_flat(x - h * d)
+        Jm = _J_only(qoi, F)
+        errs.append(abs((Jp - Jm) / (2 * h) - ga @ d))
+    assert np.log10(max(errs) / min(errs)) > 5.0       # reference: error_drop_tol = 5 decades
+
+
+def test_batched_objective_matches_pointwise_and_oracle():
+    """B copies of one history with per-point data: the batched kernels == sum of one-point objectives."""
+    import torch
+    from cmad_amd.objectives import BatchedCalibrationObjective, MPAdjointObjective
+    from cmad_amd.qois import Calibration
+    DefType, SmallElasticPlastic = _models()
+    F = plane_stress_F(0.02, 4)                        # 8 steps
+    K = F.shape[2] - 1
+    params = params_J2_voce()
+    model = SmallElasticPlastic(params, DefType.PLANE_STRESS)
+    cauchy = _compute_cauchy(model, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    rng = np.random.default_rng(22)
+    B = 3
+    datas = [cauchy + rng.normal(0., 5., cauchy.shape) for _ in range(B)]
+    datas = [0.5 * (d + d.transpose(1, 0, 2)) for d in datas]
+    model.parameters.set_active_values_from_flat(1.05 * model.parameters.flat_active_values(False), False)
+    x = model.parameters.flat_active_values(True)
+    J_ref, g_ref = 0., 0.
+    for d in datas:
+        r = MPAdjointObjective(Calibration(model, d, weight), F).evaluate(x)
+        J_ref += r.J; g_ref = g_ref + r.grad
+    gh = torch.from_numpy(np.stack([np.tile((F[:, :, k] - np.eye(2)).reshape(4, 1), (1, B)) for k in range(K + 1)])).cuda()
+    V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    dh = torch.from_numpy(np.stack([np.stack([[d[i, j, k] for d in datas] for i, j in V6]) for k in range(K + 1)])).cuda()
+    obj = BatchedCalibrationObjective(model, gh.contiguous(), dh.contiguous(), weight)
+    r = obj.evaluate(x)
+    np.testing.assert_allclose(r.J, J_ref, rtol=1e-11)
+    np.testing.assert_allclose(r.grad, g_ref, rtol=1e-8, atol=1e-10 * np.abs(g_ref).max())
+
+
+def test_calibration_recovers_truth():
+    """L-BFGS-B on the batched objective from canonical 0.1 recovers [D, S, Y] = [20, 200, 200]."""
+    import torch
+    from scipy.optimize import fmin_l_bfgs_b
+    from cmad_amd.objectives import BatchedCalibrationObjective
+    DefType, SmallElasticPlastic = _models()
+    F = plane_stress_F(0.01, 25)                       # 50 steps
+    K = F.shape[2] - 1
+    model = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+    true_params = model.parameters.flat_active_values()
+    cauchy = _compute_cauchy(model, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    gh = torch.from_numpy(np.stack([(F[:, :, k] - np.eye(2)).reshape(4, 1) for k in range(K + 1)])).cuda().contiguous()
+    dh = torch.from_numpy(np.stack([np.array([[cauchy[i, j, k]] for i, j in V6]) for k in range(K + 1)])).cuda().contiguous()
+    obj = BatchedCalibrationObjective(model, gh, dh, weight)
+    fun = lambda x: tuple(obj.evaluate(x))
+    opt, fval, info = fmin_l_bfgs_b(fun, 0.1 * np.ones(3), bounds=model.parameters.opt_bounds, factr=10)
+    model.parameters.set_active_values_from_flat(opt)
+    assert np.linalg.norm(model.parameters.flat_active_values() - true_params) < 1e-7
+
+
+def test_local_equilibrium_and_ift_tangent_vs_fd():
+    """tests/global_residuals/test_for_model_coupled.py:65-82,231-295: fixed plastic point
+    U[1,0]=0.005, U[2,1]=0.003, U[3,2]=0.002 -> ||C(xi*)|| < 1e-10 and IFT tangent == central FD."""
+    import torch
+    from cmad_amd.models import GlobalFieldsAtPoint, NewtonSettings, make_newton_solve
+    DefType, SmallElasticPlastic = _models()
+    model = SmallElasticPlastic(params_J2_voce(scale_params=False), DefType.FULL_3D)
+    G = np.zeros((3, 3)); G[0, 0] = 0.005; G[1, 1] = 0.003; G[2, 2] = 0.002
+    U = GlobalFieldsAtPoint(fields={"u": np.zeros(3)}, grad_fields={"u": G})
+    solve = make_newton_solve(model._residual, max_iters=20, abs_tol=1e-12, rel_tol=1e-12)
+    xi0 = [b.copy() for b in model._init_xi]
+    xi = solve(xi0, model.parameters.values, U, U)
+    assert xi[1][0] > 0.0
+    C = model._residual(xi, xi0, model.parameters.values, U, U)
+    assert np.linalg.norm(C) < 1e-10
+    st = NewtonSettings.traced(max_iters=20, abs_tol=1e-12, rel_tol=1e-12)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).cuda()
+    xp = t(np.zeros(7))
+    _, sig, _, ds = model.update_tangent_batch(t(G), xp, st)
+    ds = ds.cpu().numpy()[:, :, 0]
+    h = 1e-7
+    fd = np.zeros((6, 9))
+    for c in range(9):
+        Gp, Gm = G.reshape(9).copy(), G.reshape(9).copy()
+        Gp[c] += h; Gm[c] -= h
+        sp = model.update_batch(t(Gp), xp, st)[1].cpu().numpy()[:, 0]
+        sm = model.update_batch(t(Gm), xp, st)[1].cpu().numpy()[:, 0]
+        fd[:, c] = (sp - sm) / (2 * h)
+    np.testing.assert_allclose(ds, fd, rtol=1e-5, atol=1e-7 * np.abs(fd).max())
+
+
+def test_facade_error_behaviour():
+    from cmad_amd.models import DefType, SmallElasticPlastic
+    with pytest.raises(NotImplementedError):
+        SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRAIN)
+    m = SmallElasticPlastic(params_J2_voce(), DefType.FULL_3D)
+    with pytest.raises(AssertionError):
+        m.Jac()                                         # DNONE mode, reference model.py:303-314
+    with pytest.raises(AssertionError):
+        m.dSigma()

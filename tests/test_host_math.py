@@ -29,3 +29,47 @@ def test_tangent(def_type, yield_kind, kw, rot):
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_vjp(def_type, yield_kind, kw, rot):
     pc.check_vjp(BACKEND, pc.Scenario(def_type, yield_kind, kw, rot, False, B=256))
+
+
+@pytest.mark.parametrize("plastic", [True, False])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_explicit_blocks_at_arbitrary_states(def_type, yield_kind, kw, rot, plastic):
+    """cm_evaluate's blocks (C, dC/dxi, dC/dxi_prev, dC/dparams, dC/dgradu, sigma and its derivatives) at
+    non-converged states on both branches vs the oracle's dual-number Jacobians."""
+    import numpy as np
+    import host_harness_lib as hh
+    from cmad_amd.models.device import build_desc, kp_to_leaf_grad
+    from test_oracle_vs_torch_ad import _state
+    rng = np.random.default_rng(3)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng) if rot else None, **kw)
+    mat = ol.Material(values, def_type=def_type)
+    desc, info = build_desc(values, def_type=def_type)
+    V6 = [0, 1, 2, 4, 5, 8]
+    for trial in range(4):
+        for _ in range(50):                      # draw until the requested branch is hit
+            xi, xp, U = _state(rng, mat, plastic)
+            if (mat.yield_state(xi, U)[1] > 0) == plastic:
+                break
+        else:
+            raise AssertionError("could not draw a state on the requested branch")
+        g, x1, x0 = U.reshape(-1, 1), xi.reshape(-1, 1), xp.reshape(-1, 1)
+        for which_o, which_d in ((ol.W_XI, 0), (ol.W_XI_PREV, 1), (ol.W_U, 3)):
+            C, J, s, S = hh.evaluate(desc, which_d, g, x0, x1, mat.nx)
+            Jo = mat.jacobian(which_o, xi, xp, U)
+            So = mat.dcauchy(which_o, xi, xp, U)[V6, :]
+            np.testing.assert_allclose(C[:, 0], mat.residual(xi, xp, U), rtol=1e-11, atol=1e-16)
+            np.testing.assert_allclose(s[:, 0], mat.cauchy(xi, U).reshape(9)[V6], rtol=1e-11, atol=1e-10)
+            np.testing.assert_allclose(J[:, :, 0], Jo, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+            np.testing.assert_allclose(S[:, :, 0], So, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(So).max()))
+        C, J, s, S = hh.evaluate(desc, 2, g, x0, x1, mat.nx)
+        Jo = mat.jacobian(ol.W_PARAMS, xi, xp, U)
+        So = mat.dcauchy(ol.W_PARAMS, xi, xp, U)[V6, :]
+        for path in pc.param_paths(yield_kind):
+            got = kp_to_leaf_grad(path, np.moveaxis(J[:, :, 0], 1, 0), info)
+            ref = Jo[:, mat.param_index(path)]
+            np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(Jo).max()), err_msg=str(path))
+            got = kp_to_leaf_grad(path, np.moveaxis(S[:, :, 0], 1, 0), info)
+            ref = So[:, mat.param_index(path)]
+            np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(So).max()), err_msg=str(path))
