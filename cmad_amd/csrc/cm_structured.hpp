@@ -1,0 +1,364 @@
+// Structured linear algebra for the FULL_3D stress update with a pressure-independent yield surface.
+//
+// Same Newton iteration, same residual, same Jacobian as cm_device.hpp -- only the 7x7 solve is done by
+// block elimination instead of a dense LU, using what the Jacobian looks like for J2 / Hill / Hosford:
+//
+//   Ht = blk(S, t) - rho gt gt^T      S: 3x3 on the normal slots {xx,yy,zz}, t: diagonal on {xy,xz,yz}
+//        J2 / Hill: phi = sqrt(s^T A s): S = A3/phi, t = (a11,a22,a44)/phi, rho = 1/phi ; Hosford: t = rho = 0
+//   Ht d = 0, gt . d = 0              (pressure independence; d = diagonal indicator) -> every lambda term of
+//                                     Cel = 2 mu I + lambda d d^T drops out of the Jacobian
+//   A = dC/dx = [ B - eta n gt^T    -n  ]     B   = I + beta W^-1 blk(S, t), beta = 2 mu dgam  (block diagonal,
+//               [     -gt^T        j66 ]     eta = beta rho, n = W^-1 gt, j66 = -H'(alpha)/2mu   3x3 + 3 scalars)
+//
+//   A x = (bv, ba):  p = B^-1 bv, q = B^-1 n, k = 1 + j66 eta,
+//                    tau = (ba + k gt.p) / (j66 - k gt.q), s = gt.p + gt.q tau, xa = tau - eta s, xv = p + q tau
+//   A^T x = (bv, ba): the same with the roles of n and gt exchanged (B is symmetric).
+//
+// ~1/3 of the flops of the dense path (no 6x6 Hessian, no 7x7 LU); iterates agree with it to round-off, which
+// tests/test_host_math.py checks by running both against the oracle.
+#pragma once
+#include "cm_device.hpp"
+
+namespace cm {
+
+struct YieldS {
+    double phi, rho;
+    double gt[6];
+    double S[6];      // symmetric 3x3 on slots (0,3,5): S00,S03,S05,S33,S35,S55
+    double t[3];      // shear slots (1,2,4)
+};
+
+template <int YK>
+CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS& y) {
+    if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
+        const QuadForm q = quad_form<YK>(m);
+        double As[6];
+        As[0] = q.a00 * s[0] + q.a03 * s[3] + q.a05 * s[5];
+        As[3] = q.a03 * s[0] + q.a33 * s[3] + q.a35 * s[5];
+        As[5] = q.a05 * s[0] + q.a35 * s[3] + q.a55 * s[5];
+        As[1] = q.a11 * s[1]; As[2] = q.a22 * s[2]; As[4] = q.a44 * s[4];
+        double qq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) qq += s[k] * As[k];
+        y.phi = sqrt(qq);
+        const double ip = 1.0 / y.phi;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y.gt[k] = As[k] * ip;
+        y.rho = ip;
+        y.S[0] = q.a00 * ip; y.S[1] = q.a03 * ip; y.S[2] = q.a05 * ip;
+        y.S[3] = q.a33 * ip; y.S[4] = q.a35 * ip; y.S[5] = q.a55 * ip;
+        y.t[0] = q.a11 * ip; y.t[1] = q.a22 * ip; y.t[2] = q.a44 * ip;
+    } else {
+        double Ht[6][6];
+        yield_eval<YK, true>(m, s, y.phi, y.gt, Ht);          // Hosford: Ht lives on the normal block only
+        y.rho = 0.0;
+        y.S[0] = Ht[0][0]; y.S[1] = Ht[0][3]; y.S[2] = Ht[0][5];
+        y.S[3] = Ht[3][3]; y.S[4] = Ht[3][5]; y.S[5] = Ht[5][5];
+        y.t[0] = y.t[1] = y.t[2] = 0.0;
+    }
+}
+
+// blk(S, t) u
+CM_D void blk_apply(const YieldS& y, const double u[6], double out[6]) {
+    out[0] = y.S[0] * u[0] + y.S[1] * u[3] + y.S[2] * u[5];
+    out[3] = y.S[1] * u[0] + y.S[3] * u[3] + y.S[4] * u[5];
+    out[5] = y.S[2] * u[0] + y.S[4] * u[3] + y.S[5] * u[5];
+    out[1] = y.t[0] * u[1]; out[2] = y.t[1] * u[2]; out[4] = y.t[2] * u[4];
+}
+// Ht u = blk u - rho gt (gt . u)
+CM_D void hess_apply(const YieldS& y, const double u[6], double out[6]) {
+    blk_apply(y, u, out);
+    const double c = y.rho * dot<6>(y.gt, u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] -= c * y.gt[k];
+}
+
+// state evaluation, FULL_3D
+struct EvalS {
+    double e[6], s[6], tr, f, dgam;
+    bool plastic;
+    Hard hd;
+    YieldS y;
+};
+
+template <int YK>
+CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, EvalS& ev, double* C) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ev.e[k] = eg[k] - x[k];
+    ev.tr = ev.e[0] + ev.e[3] + ev.e[5];
+    const double twomu = 2.0 * m.mu, lt = m.lambda * ev.tr;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ev.s[k] = twomu * ev.e[k] + (kDiag[k] ? lt : 0.0);
+    yield_eval_s<YK>(m, ev.s, ev.y);
+    ev.hd = hardening(m, x[6]);
+    const double i2mu = 0.5 / m.mu;
+    ev.f = (ev.y.phi - (m.Y + ev.hd.H)) * i2mu;
+    ev.dgam = x[6] - xp[6];
+    ev.plastic = (ev.f > m.yield_tol) || (fabs(ev.f) < m.yield_tol);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double ce = x[k] - xp[k];
+        C[k] = ev.plastic ? (ce - ev.dgam * ev.y.gt[k] * kIW[k]) : ce;
+    }
+    C[6] = ev.plastic ? ev.f : ev.dgam;
+}
+
+// A = dC/dx in structured form at an evaluated state
+struct PlasticOp {
+    double inv3[6];   // (I + beta S)^-1, symmetric: 00,03,05,33,35,55
+    double ib[3];     // 1 / (1 + beta t_j / 2)
+    double eta, j66, k, beta;
+    bool plastic, ok;
+};
+
+CM_D void op_build(const cm_model_desc& m, const EvalS& ev, PlasticOp& op) {
+    const YieldS& y = ev.y;
+    op.plastic = ev.plastic;
+    op.beta = 2.0 * m.mu * ev.dgam;
+    const double b = op.beta;
+    const double B00 = 1.0 + b * y.S[0], B03 = b * y.S[1], B05 = b * y.S[2];
+    const double B33 = 1.0 + b * y.S[3], B35 = b * y.S[4], B55 = 1.0 + b * y.S[5];
+    const double c00 = B33 * B55 - B35 * B35, c03 = B05 * B35 - B03 * B55, c05 = B03 * B35 - B05 * B33;
+    const double c33 = B00 * B55 - B05 * B05, c35 = B03 * B05 - B00 * B35, c55 = B00 * B33 - B03 * B03;
+    const double det = B00 * c00 + B03 * c03 + B05 * c05;
+    const double b1 = 1.0 + 0.5 * b * y.t[0], b2 = 1.0 + 0.5 * b * y.t[1], b4 = 1.0 + 0.5 * b * y.t[2];
+    op.ok = (fabs(det) > 1e-300) && (fabs(b1) > 1e-300) && (fabs(b2) > 1e-300) && (fabs(b4) > 1e-300);
+    const double id = 1.0 / det;
+    op.inv3[0] = c00 * id; op.inv3[1] = c03 * id; op.inv3[2] = c05 * id;
+    op.inv3[3] = c33 * id; op.inv3[4] = c35 * id; op.inv3[5] = c55 * id;
+    op.ib[0] = 1.0 / b1; op.ib[1] = 1.0 / b2; op.ib[2] = 1.0 / b4;
+    op.eta = b * y.rho;
+    op.j66 = -ev.hd.dH * 0.5 / m.mu;
+    op.k = 1.0 + op.j66 * op.eta;
+}
+
+CM_D void binv(const PlasticOp& op, const double v[6], double out[6]) {
+    out[0] = op.inv3[0] * v[0] + op.inv3[1] * v[3] + op.inv3[2] * v[5];
+    out[3] = op.inv3[1] * v[0] + op.inv3[3] * v[3] + op.inv3[4] * v[5];
+    out[5] = op.inv3[2] * v[0] + op.inv3[4] * v[3] + op.inv3[5] * v[5];
+    out[1] = op.ib[0] * v[1]; out[2] = op.ib[1] * v[2]; out[4] = op.ib[2] * v[4];
+}
+
+// x = A^-1 b (TRANSPOSED: A^-T b); b and x may alias
+template <bool TRANSPOSED>
+CM_D void op_solve(const PlasticOp& op, const YieldS& y, const double* b, double* x) {
+    if (!op.plastic) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) x[k] = b[k];
+        return;
+    }
+    double n[6], p[6], q[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n[k] = y.gt[k] * kIW[k];
+    const double* col = TRANSPOSED ? y.gt : n;      // the vector multiplying tau
+    const double* row = TRANSPOSED ? n : y.gt;      // the vector contracted with x_v
+    binv(op, b, p);
+    binv(op, col, q);
+    const double rp = dot<6>(row, p), rq = dot<6>(row, q);
+    const double tau = (b[6] + op.k * rp) / (op.j66 - op.k * rq);
+    const double s = rp + rq * tau;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = p[k] + q[k] * tau;
+    x[6] = tau - op.eta * s;
+}
+
+// ---- local Newton, structured (same control flow as cm::newton) -----------------------------------------
+template <int YK>
+CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid) {
+    constexpr int NX = 7;
+    EvalS ev;
+    double C[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) x[k] = xp[k];
+    residual_s<YK>(m, eg, x, xp, ev, C);
+    const double norm0 = norm2<NX>(C);
+    int it = 0;
+    bool running = lane_valid;
+    uint32_t flags = 0;
+    for (;;) {
+        const double nrm = norm2<NX>(C);
+        const double rel = nrm / norm0;
+        const bool conv = (rel < m.rel_tol) || (nrm < m.abs_tol);
+        if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
+        if (running && it >= m.max_iters) running = false;
+        if (!__any(running)) break;
+        if (running) {
+            double delta[NX];
+            PlasticOp op;
+            op_build(m, ev, op);                   // ev is the evaluation at the current x (carried)
+            if (!op.ok) flags |= CM_STATUS_SINGULAR;
+            op_solve<false>(op, ev.y, C, delta);
+            if (m.ls_max_evals <= 0) {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) x[k] -= delta[k];
+                residual_s<YK>(m, eg, x, xp, ev, C);
+            } else {
+                const double cc = dot<NX>(C, C);
+                const double phi0 = 0.5 * cc, dphi0 = -cc, armijo = m.ls_c1 * dphi0;
+                int n = 0;
+                double alpha = 1.0, best_alpha = 1.0, best_phi = INFINITY;
+                bool accepted = false, have_best = false;
+                double xt[NX];
+                bool ls = true;
+                // trials are evaluated straight into (ev, C): on acceptance they already are the carried state
+                while (__any(ls)) {
+                    if (ls) {
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) xt[k] = x[k] - alpha * delta[k];
+                        residual_s<YK>(m, eg, xt, xp, ev, C);
+                        const double phi = 0.5 * dot<NX>(C, C);
+                        const bool finite = isfinite(phi);
+                        if (finite && phi < best_phi) { best_alpha = alpha; best_phi = phi; have_best = true; }
+                        accepted = finite && (phi <= phi0 + alpha * armijo);
+                        const double am = quad_min(phi0, dphi0, alpha, phi);
+                        const double ac = fmin(fmax(am, m.ls_lo * alpha), m.ls_hi * alpha);
+                        if (!accepted) alpha = finite ? ac : 0.5 * alpha;
+                        ++n;
+                        ls = (n < m.ls_max_evals) && !accepted;
+                    }
+                }
+                if (accepted) {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) x[k] -= alpha * delta[k];
+                } else if (have_best) {             // no trial accepted: lowest-merit step tried (line_search.py:181-183)
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) x[k] -= best_alpha * delta[k];
+                    residual_s<YK>(m, eg, x, xp, ev, C);
+                } else {                            // every trial non-finite: full step, base residual carried
+                    double Cb[NX], Cd[NX];
+                    residual_s<YK>(m, eg, x, xp, ev, Cb);
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) x[k] -= delta[k];
+                    residual_s<YK>(m, eg, x, xp, ev, Cd);
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) C[k] = Cb[k];
+                }
+            }
+            ++it;
+        }
+    }
+    return flags | (uint32_t)it;
+}
+
+// ---- reverse sweep, structured (same contract as cm::reverse_point, DEF = FULL_3D) ---------------------------
+template <int YK>
+CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp,
+                          const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar) {
+    EvalS ev;
+    double C[7], lam[7];
+    residual_s<YK>(m, eg, x, xp, ev, C);
+    PlasticOp op;
+    op_build(m, ev, op);
+    double csb[6];
+    apply_cel(m, sbm, csb);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lam[k] = -csb[k];
+    lam[6] = 0.0;
+    if (xin) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) lam[k] += xin[k];
+    }
+    op_solve<true>(op, ev.y, lam, lam);
+    const double i2mu = 0.5 / m.mu;
+    const YieldS& y = ev.y;
+    double u[6], hu[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = ev.plastic ? (-ev.dgam * lam[k] * kIW[k]) : 0.0;
+    hess_apply(y, u, hu);
+    const double lam6 = ev.plastic ? lam[6] : 0.0;
+    if (pbar) {
+        const double ge = dot<6>(y.gt, ev.e), hue = dot<6>(hu, ev.e);
+        const double sbd = sbm[0] + sbm[3] + sbm[5], sbe = dot<6>(sbm, ev.e);
+        // lam . dC/dlambda = 0 for a pressure-independent surface (Ht d = 0, gt . d = 0)
+        pbar[CM_P_LAMBDA] = sbd * ev.tr;
+        pbar[CM_P_MU] = 2.0 * sbe - (2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f / m.mu));
+        pbar[CM_P_Y] = lam6 * i2mu;
+        pbar[CM_P_VOCE_S] = m.has_voce ? lam6 * (1.0 - ev.hd.expo) * i2mu : 0.0;
+        pbar[CM_P_VOCE_D] = m.has_voce ? lam6 * m.voce_S * x[6] * ev.hd.expo * i2mu : 0.0;
+        pbar[CM_P_LIN_K] = m.has_linear ? lam6 * x[6] * i2mu : 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pbar[CM_P_YC0 + j] = 0.0;
+        if constexpr (YK == CM_YIELD_HILL) {
+            if (ev.plastic) {
+                const double* s = ev.s;
+                const double ip = y.rho;
+                const double d12 = s[3] - s[5], d20 = s[5] - s[0], d01 = s[0] - s[3];
+                const double qj[6] = {d12 * d12, d20 * d20, d01 * d01, 2.0 * s[4] * s[4], 2.0 * s[2] * s[2], 2.0 * s[1] * s[1]};
+                const double uAs[6] = {(u[3] - u[5]) * d12, (u[5] - u[0]) * d20, (u[0] - u[3]) * d01,
+                                       2.0 * u[4] * s[4], 2.0 * u[2] * s[2], 2.0 * u[1] * s[1]};
+                const double ug = dot<6>(u, y.gt);
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    pbar[CM_P_YC0 + j] = -(uAs[j] * ip - ug * qj[j] * 0.5 * ip * ip + lam6 * qj[j] * 0.5 * ip * i2mu);
+            }
+        }
+    }
+    if (xpbar) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xpbar[k] = lam[k];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += y.gt[k] * kIW[k] * lam[k];
+        xpbar[6] = ev.plastic ? -s : lam[6];
+    }
+    if (egbar) {
+        double t[6], ct[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = hu[k] + lam6 * y.gt[k] * i2mu;
+        apply_cel(m, t, ct);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) egbar[k] = csb[k] - ct[k];
+    }
+    return op.ok;
+}
+
+// ---- forward tangent, structured (same contract as cm::tangent_point, DEF = FULL_3D) ------------------------
+template <int YK>
+CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, double (&T)[6][6]) {
+    EvalS ev;
+    double C[7];
+    residual_s<YK>(m, eg, x, xp, ev, C);
+    PlasticOp op;
+    op_build(m, ev, op);
+    const YieldS& y = ev.y;
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        double b[7], unit[6], hcol[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) unit[k] = (k == l) ? 1.0 : 0.0;
+        hess_apply(y, unit, hcol);                             // column l of Ht
+        // b = -dC/deg_l = [ beta/w_k Ht_kl ; -gt_l ]  (plastic), 0 (elastic)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = ev.plastic ? op.beta * kIW[k] * hcol[k] : 0.0;
+        b[6] = ev.plastic ? -y.gt[l] : 0.0;
+        op_solve<false>(op, y, b, b);
+        double de[6], ds[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) de[k] = ((k == l) ? 1.0 : 0.0) - b[k];
+        apply_cel(m, de, ds);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) T[r][l] = ds[r];
+    }
+    return op.ok;
+}
+
+// ---- front doors: structured for FULL_3D, dense otherwise (STRUCT = false forces the dense path) ------------
+template <int DEF, int YK, bool STRUCT = true>
+CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid) {
+    if constexpr (STRUCT && DEF == CM_FULL_3D) return newton_s<YK>(m, eg, xp, x, valid);
+    else return newton<DEF, YK>(m, eg, z, xp, x, valid);
+}
+template <int DEF, int YK, bool STRUCT = true>
+CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
+                      const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar) {
+    if constexpr (STRUCT && DEF == CM_FULL_3D) return reverse_point_s<YK>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar);
+    else return reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, egbar);
+}
+template <int DEF, int YK, bool STRUCT = true>
+CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
+                      double (&T)[6][6]) {
+    if constexpr (STRUCT && DEF == CM_FULL_3D) return tangent_point_s<YK>(m, eg, x, xp, T);
+    else return tangent_point<DEF, YK>(m, eg, z, x, xp, T);
+}
+
+}  // namespace cm

@@ -2,7 +2,7 @@
 // gfx950 only.  One Gauss point per lane; SoA arrays so that lane b of a wavefront reads
 // element [k*B + b] -> every global access is a 512-byte contiguous row per wave instruction.
 #include <hip/hip_runtime.h>
-#include "cm_device.hpp"
+#include "cm_structured.hpp"
 
 namespace {
 
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
     load_soa<NX>(xi_prev, B, b, xp);
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<ROT>(m, z);
-    uint32_t st = newton<DEF, YK>(m, eg, z, xp, x, valid);
+    uint32_t st = newton_any<DEF, YK>(m, eg, z, xp, x, valid);
     Eval<DEF> ev;
     strain_stress<DEF>(m, eg, z, x, ev);
     if (status) {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
     }
     if constexpr (TANGENT) {
         double T[6][6];
-        const bool ok = tangent_point<DEF, YK>(m, eg, z, x, xp, T);
+        const bool ok = tangent_any<DEF, YK>(m, eg, z, x, xp, T);
         if (!ok && valid && status) status[b] = st | CM_STATUS_SINGULAR;
         // d sig_g / d G_c = Rg T Rm dE/dG_c : push each unit grad-u direction through
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<ROT>(m, z);
     if constexpr (MODE == 1 || MODE == 3) {
-        newton<DEF, YK>(m, eg, z, xp, x, valid);
+        newton_any<DEF, YK>(m, eg, z, xp, x, valid);
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
             if (sigma_out) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
             xinp = xin;
         }
     }
-    reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xinp, &red[1], (xpbar_out ? xpbar : nullptr),
+    reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, xinp, &red[1], (xpbar_out ? xpbar : nullptr),
                            (gbar_out ? egbar : nullptr));
     if (xpbar_out && valid) {
         if constexpr (MODE == 2) {

@@ -15,7 +15,7 @@ _lib = None
 
 def build(force=False, sanitize=False):
     src = os.path.join(_DIR, "host_harness.cpp")
-    deps = [src, os.path.join(_ROOT, "cmad_amd", "csrc", "cm_device.hpp"), os.path.join(_ROOT, "include", "cmad_hip.h")]
+    deps = [src, os.path.join(_ROOT, "cmad_amd", "csrc", "cm_device.hpp"), os.path.join(_ROOT, "cmad_amd", "csrc", "cm_structured.hpp"), os.path.join(_ROOT, "include", "cmad_hip.h")]
     out = _SO if not sanitize else os.path.join(_DIR, "libhost_harness_asan.so")
     stale = (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
     if force or stale:
@@ -32,6 +32,11 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
     return _lib
+
+
+def set_dense(flag):
+    """Force the dense 7x7 path also for FULL_3D (the kernels use the structured solve there)."""
+    lib().hh_set_dense(int(bool(flag)))
 
 
 def _p(a):

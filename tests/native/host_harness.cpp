@@ -5,9 +5,11 @@
 #include <cstdint>
 #include <cstring>
 #define CM_HOST_BUILD 1
-#include "../../cmad_amd/csrc/cm_device.hpp"
+#include "../../cmad_amd/csrc/cm_structured.hpp"
 
 using namespace cm;
+
+static int g_dense = 0;   // 1: force the dense 7x7 path also for FULL_3D
 
 template <int DEF, int YK, bool ROT>
 static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, const double* xi_prev,
@@ -19,7 +21,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, eg);
         strain_z<ROT>(m, z);
-        uint32_t st = newton<DEF, YK>(m, eg, z, xp, x, true);
+        uint32_t st = g_dense ? newton_any<DEF, YK, false>(m, eg, z, xp, x, true) : newton_any<DEF, YK, true>(m, eg, z, xp, x, true);
         Eval<DEF> ev;
         strain_stress<DEF>(m, eg, z, x, ev);
         double sg[6];
@@ -29,7 +31,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         if (status) status[b] = st;
         if (dsig) {
             double T[6][6];
-            tangent_point<DEF, YK>(m, eg, z, x, xp, T);
+            if (g_dense) tangent_any<DEF, YK, false>(m, eg, z, x, xp, T); else tangent_any<DEF, YK, true>(m, eg, z, x, xp, T);
             for (int c = 0; c < NU; ++c) {
                 double Gd[NU], dm[6], t[6], tg[6];
                 for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
@@ -56,7 +58,8 @@ static void run_vjp(const cm_model_desc& m, int64_t B, const double* gradu, cons
         strain_from_gradu<DEF, ROT>(m, G, eg);
         strain_z<ROT>(m, z);
         cotangent_to_material<ROT>(m, sb, sbm);
-        reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+        if (g_dense) reverse_any<DEF, YK, false>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+        else reverse_any<DEF, YK, true>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
         for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
         if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
         if (gbar) for (int c = 0; c < NU; ++c) {
@@ -115,5 +118,6 @@ int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
                 const double* xi, double* C, double* J, double* s, double* S) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_evaluate<D, Y, R>(*m, B, which, gradu, xi_prev, xi, C, J, s, S); });
 }
+void hh_set_dense(int d) { g_dense = d; }
 int hh_sizeof_desc(void) { return (int)sizeof(cm_model_desc); }
 }

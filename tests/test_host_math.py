@@ -9,6 +9,16 @@ import parity_cases as pc
 BACKEND = pc.HostBackend()
 
 
+@pytest.fixture(params=["structured", "dense"], autouse=True)
+def solver_variant(request):
+    """FULL_3D runs twice: the structured block solve the kernels use and the dense 7x7 LU (PLANE_STRESS is
+    always dense)."""
+    import host_harness_lib as hh
+    hh.set_dense(request.param == "dense")
+    yield
+    hh.set_dense(False)
+
+
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS)
