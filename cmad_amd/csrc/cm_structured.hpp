@@ -41,7 +41,7 @@ CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS& y) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) qq += s[k] * As[k];
         y.phi = sqrt(qq);
-        const double ip = 1.0 / y.phi;
+        const double ip = rcp(y.phi);
 #pragma unroll
         for (int k = 0; k < 6; ++k) y.gt[k] = As[k] * ip;
         y.rho = ip;
@@ -123,10 +123,10 @@ CM_D void op_build(const cm_model_desc& m, const EvalS& ev, PlasticOp& op) {
     const double det = B00 * c00 + B03 * c03 + B05 * c05;
     const double b1 = 1.0 + 0.5 * b * y.t[0], b2 = 1.0 + 0.5 * b * y.t[1], b4 = 1.0 + 0.5 * b * y.t[2];
     op.ok = (fabs(det) > 1e-300) && (fabs(b1) > 1e-300) && (fabs(b2) > 1e-300) && (fabs(b4) > 1e-300);
-    const double id = 1.0 / det;
+    const double id = rcp(det);
     op.inv3[0] = c00 * id; op.inv3[1] = c03 * id; op.inv3[2] = c05 * id;
     op.inv3[3] = c33 * id; op.inv3[4] = c35 * id; op.inv3[5] = c55 * id;
-    op.ib[0] = 1.0 / b1; op.ib[1] = 1.0 / b2; op.ib[2] = 1.0 / b4;
+    op.ib[0] = rcp(b1); op.ib[1] = rcp(b2); op.ib[2] = rcp(b4);
     op.eta = b * y.rho;
     op.j66 = -ev.hd.dH * 0.5 / m.mu;
     op.k = 1.0 + op.j66 * op.eta;
@@ -155,7 +155,7 @@ CM_D void op_solve(const PlasticOp& op, const YieldS& y, const double* b, double
     binv(op, b, p);
     binv(op, col, q);
     const double rp = dot<6>(row, p), rq = dot<6>(row, q);
-    const double tau = (b[6] + op.k * rp) / (op.j66 - op.k * rq);
+    const double tau = (b[6] + op.k * rp) * rcp(op.j66 - op.k * rq);
     const double s = rp + rq * tau;
 #pragma unroll
     for (int k = 0; k < 6; ++k) x[k] = p[k] + q[k] * tau;
@@ -171,14 +171,14 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
 #pragma unroll
     for (int k = 0; k < NX; ++k) x[k] = xp[k];
     residual_s<YK>(m, eg, x, xp, ev, C);
-    const double norm0 = norm2<NX>(C);
+    const double n0sq = dot<NX>(C, C);             // squared-norm form of nonlinear_solver.py:140-150, see cm::newton
+    const double rel2 = m.rel_tol * m.rel_tol * n0sq, abs2 = m.abs_tol * m.abs_tol;
     int it = 0;
     bool running = lane_valid;
     uint32_t flags = 0;
     for (;;) {
-        const double nrm = norm2<NX>(C);
-        const double rel = nrm / norm0;
-        const bool conv = (rel < m.rel_tol) || (nrm < m.abs_tol);
+        const double nsq = dot<NX>(C, C);
+        const bool conv = (nsq < rel2) || (nsq < abs2);
         if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
         if (running && it >= m.max_iters) running = false;
         if (!__any(running)) break;

@@ -11,15 +11,18 @@ constexpr int kRed = 1 + CM_NUM_PARAMS;
 
 using namespace cm;
 
+// SoA row access.  `p` is the block's base (array + blockIdx.x * kBlock, wave-uniform -> SGPR pair) and `t`
+// the lane's offset inside the block, so each access is `global_load/store v, v_off, s[base]` with the row
+// stride added on the scalar unit -- no per-lane 64-bit address arithmetic.
 template <int N>
-__device__ __forceinline__ void load_soa(const double* __restrict__ p, int64_t B, int64_t b, double* out) {
+__device__ __forceinline__ void load_soa(const double* __restrict__ p, int64_t B, unsigned t, double* out) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = p[(int64_t)k * B + b];
+    for (int k = 0; k < N; ++k) out[k] = (p + (int64_t)k * B)[t];
 }
 template <int N>
-__device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, int64_t b, const double* v) {
+__device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, unsigned t, const double* v) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) p[(int64_t)k * B + b] = v[k];
+    for (int k = 0; k < N; ++k) (p + (int64_t)k * B)[t] = v[k];
 }
 
 // ---- cm_update / cm_update_tangent ----------------------------------------------------------------
@@ -28,9 +31,13 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
-    const int64_t b0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = b0 < B;
-    const int64_t b = valid ? b0 : B - 1;          // tail lanes shadow the last point, never store
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);   // tail lanes shadow the last point, never store
+    gradu += blk0; xi_prev += blk0; xi += blk0;
+    if (sigma) sigma += blk0;
+    if (status) status += blk0;
+    if (dsig) dsig += blk0;
     double G[NU], xp[NX], x[NX], eg[6], z[6];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
             to_global<ROT>(m, t, tg);
             if (valid) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r) dsig[(int64_t)(r * NU + c) * B + b] = tg[r];
+                for (int r = 0; r < 6; ++r) (dsig + (int64_t)(r * NU + c) * B)[b] = tg[r];
             }
         }
     }
@@ -179,9 +186,16 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
         double* __restrict__ xi_out, double* __restrict__ sigma_out, double* __restrict__ xpbar_out,
         double* __restrict__ gbar_out, double* __restrict__ partials) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
-    const int64_t b0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = b0 < B;
-    const int64_t b = valid ? b0 : B - 1;
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
+    gradu += blk0; xi_prev += blk0; sbar_or_data += blk0;
+    if (xi_in) xi_in += blk0;
+    if (hist_in) hist_in += blk0;
+    if (xi_out) xi_out += blk0;
+    if (sigma_out) sigma_out += blk0;
+    if (xpbar_out) xpbar_out += blk0;
+    if (gbar_out) gbar_out += blk0;
     double G[NU], xp[NX], x[NX], eg[6], z[6], sd[6];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
@@ -226,25 +240,28 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
     }
     double sbm[6], xin[NX], xpbar[NX], egbar[6];
     cotangent_to_material<ROT>(m, sb, sbm);
-    const double* xinp = nullptr;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) xin[k] = 0.0;
     if constexpr (MODE == 2) {
         if (hist_in) {
             load_soa<NX>(hist_in, B, b, xin);
 #pragma unroll
             for (int k = 0; k < NX; ++k) xin[k] = -xin[k];       // history vector = -(cotangent of xi)
-            xinp = xin;
         }
     }
-    reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, xinp, &red[1], (xpbar_out ? xpbar : nullptr),
-                           (gbar_out ? egbar : nullptr));
-    if (xpbar_out && valid) {
+    // arrays are always passed (never a run-time null): a nullable local array would be forced into scratch
+    // (MODE 1 / 3 have no per-point cotangent outputs at all: compile-time nulls let the compiler drop that work)
+    constexpr bool BARS = (MODE == 0 || MODE == 2);
+    reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
+                         BARS ? egbar : nullptr);
+    if (BARS && xpbar_out && valid) {
         if constexpr (MODE == 2) {
 #pragma unroll
             for (int k = 0; k < NX; ++k) xpbar[k] = -xpbar[k];   // back to history-vector sign
         }
         store_soa<NX>(xpbar_out, B, b, xpbar);
     }
-    if (gbar_out) {
+    if (BARS && gbar_out) {
         // cotangent of grad u: Gbar_c = egbar . d eg / d G_c
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
 #pragma unroll
             for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
             strain_from_gradu<DEF, ROT>(m, Gd, dm);
-            if (valid) gbar_out[(int64_t)c * B + b] = dot<6>(egbar, dm);
+            if (valid) (gbar_out + (int64_t)c * B)[b] = dot<6>(egbar, dm);
         }
     }
     if (!valid) {
