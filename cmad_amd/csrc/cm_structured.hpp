@@ -21,15 +21,33 @@
 
 namespace cm {
 
+// For J2 / Hill the blocks are (constant coefficients) x rho, so they are rebuilt from rho where needed instead
+// of being carried across the Newton loop (9 doubles = 18 VGPRs less live state); Hosford stores its 3x3 block.
+template <int YK>
 struct YieldS {
+    static constexpr bool QUAD = (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL);
     double phi, rho;
     double gt[6];
-    double S[6];      // symmetric 3x3 on slots (0,3,5): S00,S03,S05,S33,S35,S55
-    double t[3];      // shear slots (1,2,4)
+    double Sst[QUAD ? 1 : 6];      // Hosford only: S00,S03,S05,S33,S35,S55
 };
 
+// S (3x3 on slots 0,3,5: S00,S03,S05,S33,S35,S55) and t (shear slots 1,2,4)
 template <int YK>
-CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS& y) {
+CM_D void yield_blocks(const cm_model_desc& m, const YieldS<YK>& y, double S[6], double t[3]) {
+    if constexpr (YieldS<YK>::QUAD) {
+        const QuadForm q = quad_form<YK>(m);
+        S[0] = q.a00 * y.rho; S[1] = q.a03 * y.rho; S[2] = q.a05 * y.rho;
+        S[3] = q.a33 * y.rho; S[4] = q.a35 * y.rho; S[5] = q.a55 * y.rho;
+        t[0] = q.a11 * y.rho; t[1] = q.a22 * y.rho; t[2] = q.a44 * y.rho;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = y.Sst[k];
+        t[0] = t[1] = t[2] = 0.0;
+    }
+}
+
+template <int YK>
+CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS<YK>& y) {
     if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
         const QuadForm q = quad_form<YK>(m);
         double As[6];
@@ -45,44 +63,45 @@ CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS& y) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) y.gt[k] = As[k] * ip;
         y.rho = ip;
-        y.S[0] = q.a00 * ip; y.S[1] = q.a03 * ip; y.S[2] = q.a05 * ip;
-        y.S[3] = q.a33 * ip; y.S[4] = q.a35 * ip; y.S[5] = q.a55 * ip;
-        y.t[0] = q.a11 * ip; y.t[1] = q.a22 * ip; y.t[2] = q.a44 * ip;
     } else {
         double Ht[6][6];
         yield_eval<YK, true>(m, s, y.phi, y.gt, Ht);          // Hosford: Ht lives on the normal block only
         y.rho = 0.0;
-        y.S[0] = Ht[0][0]; y.S[1] = Ht[0][3]; y.S[2] = Ht[0][5];
-        y.S[3] = Ht[3][3]; y.S[4] = Ht[3][5]; y.S[5] = Ht[5][5];
-        y.t[0] = y.t[1] = y.t[2] = 0.0;
+        y.Sst[0] = Ht[0][0]; y.Sst[1] = Ht[0][3]; y.Sst[2] = Ht[0][5];
+        y.Sst[3] = Ht[3][3]; y.Sst[4] = Ht[3][5]; y.Sst[5] = Ht[5][5];
     }
 }
 
 // blk(S, t) u
-CM_D void blk_apply(const YieldS& y, const double u[6], double out[6]) {
-    out[0] = y.S[0] * u[0] + y.S[1] * u[3] + y.S[2] * u[5];
-    out[3] = y.S[1] * u[0] + y.S[3] * u[3] + y.S[4] * u[5];
-    out[5] = y.S[2] * u[0] + y.S[4] * u[3] + y.S[5] * u[5];
-    out[1] = y.t[0] * u[1]; out[2] = y.t[1] * u[2]; out[4] = y.t[2] * u[4];
+template <int YK>
+CM_D void blk_apply(const cm_model_desc& m, const YieldS<YK>& y, const double u[6], double out[6]) {
+    double S[6], t[3];
+    yield_blocks<YK>(m, y, S, t);
+    out[0] = S[0] * u[0] + S[1] * u[3] + S[2] * u[5];
+    out[3] = S[1] * u[0] + S[3] * u[3] + S[4] * u[5];
+    out[5] = S[2] * u[0] + S[4] * u[3] + S[5] * u[5];
+    out[1] = t[0] * u[1]; out[2] = t[1] * u[2]; out[4] = t[2] * u[4];
 }
 // Ht u = blk u - rho gt (gt . u)
-CM_D void hess_apply(const YieldS& y, const double u[6], double out[6]) {
-    blk_apply(y, u, out);
+template <int YK>
+CM_D void hess_apply(const cm_model_desc& m, const YieldS<YK>& y, const double u[6], double out[6]) {
+    blk_apply<YK>(m, y, u, out);
     const double c = y.rho * dot<6>(y.gt, u);
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] -= c * y.gt[k];
 }
 
 // state evaluation, FULL_3D
+template <int YK>
 struct EvalS {
     double e[6], s[6], tr, f, dgam;
     bool plastic;
     Hard hd;
-    YieldS y;
+    YieldS<YK> y;
 };
 
 template <int YK>
-CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, EvalS& ev, double* C) {
+CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, EvalS<YK>& ev, double* C) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) ev.e[k] = eg[k] - x[k];
     ev.tr = ev.e[0] + ev.e[3] + ev.e[5];
@@ -111,17 +130,20 @@ struct PlasticOp {
     bool plastic, ok;
 };
 
-CM_D void op_build(const cm_model_desc& m, const EvalS& ev, PlasticOp& op) {
-    const YieldS& y = ev.y;
+template <int YK>
+CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOp& op) {
+    const YieldS<YK>& y = ev.y;
     op.plastic = ev.plastic;
     op.beta = 2.0 * m.mu * ev.dgam;
     const double b = op.beta;
-    const double B00 = 1.0 + b * y.S[0], B03 = b * y.S[1], B05 = b * y.S[2];
-    const double B33 = 1.0 + b * y.S[3], B35 = b * y.S[4], B55 = 1.0 + b * y.S[5];
+    double S[6], t[3];
+    yield_blocks<YK>(m, y, S, t);
+    const double B00 = 1.0 + b * S[0], B03 = b * S[1], B05 = b * S[2];
+    const double B33 = 1.0 + b * S[3], B35 = b * S[4], B55 = 1.0 + b * S[5];
     const double c00 = B33 * B55 - B35 * B35, c03 = B05 * B35 - B03 * B55, c05 = B03 * B35 - B05 * B33;
     const double c33 = B00 * B55 - B05 * B05, c35 = B03 * B05 - B00 * B35, c55 = B00 * B33 - B03 * B03;
     const double det = B00 * c00 + B03 * c03 + B05 * c05;
-    const double b1 = 1.0 + 0.5 * b * y.t[0], b2 = 1.0 + 0.5 * b * y.t[1], b4 = 1.0 + 0.5 * b * y.t[2];
+    const double b1 = 1.0 + 0.5 * b * t[0], b2 = 1.0 + 0.5 * b * t[1], b4 = 1.0 + 0.5 * b * t[2];
     op.ok = (fabs(det) > 1e-300) && (fabs(b1) > 1e-300) && (fabs(b2) > 1e-300) && (fabs(b4) > 1e-300);
     const double id = rcp(det);
     op.inv3[0] = c00 * id; op.inv3[1] = c03 * id; op.inv3[2] = c05 * id;
@@ -140,8 +162,8 @@ CM_D void binv(const PlasticOp& op, const double v[6], double out[6]) {
 }
 
 // x = A^-1 b (TRANSPOSED: A^-T b); b and x may alias
-template <bool TRANSPOSED>
-CM_D void op_solve(const PlasticOp& op, const YieldS& y, const double* b, double* x) {
+template <bool TRANSPOSED, int YK>
+CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, double* x) {
     if (!op.plastic) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) x[k] = b[k];
@@ -166,7 +188,7 @@ CM_D void op_solve(const PlasticOp& op, const YieldS& y, const double* b, double
 template <int YK>
 CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid) {
     constexpr int NX = 7;
-    EvalS ev;
+    EvalS<YK> ev;
     double C[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) x[k] = xp[k];
@@ -185,7 +207,7 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
         if (running) {
             double delta[NX];
             PlasticOp op;
-            op_build(m, ev, op);                   // ev is the evaluation at the current x (carried)
+            op_build<YK>(m, ev, op);               // ev is the evaluation at the current x (carried)
             if (!op.ok) flags |= CM_STATUS_SINGULAR;
             op_solve<false>(op, ev.y, C, delta);
             if (m.ls_max_evals <= 0) {
@@ -244,11 +266,11 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
 template <int YK>
 CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp,
                           const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar) {
-    EvalS ev;
+    EvalS<YK> ev;
     double C[7], lam[7];
     residual_s<YK>(m, eg, x, xp, ev, C);
     PlasticOp op;
-    op_build(m, ev, op);
+    op_build<YK>(m, ev, op);
     double csb[6];
     apply_cel(m, sbm, csb);
 #pragma unroll
@@ -260,11 +282,11 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
     }
     op_solve<true>(op, ev.y, lam, lam);
     const double i2mu = 0.5 / m.mu;
-    const YieldS& y = ev.y;
+    const YieldS<YK>& y = ev.y;
     double u[6], hu[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) u[k] = ev.plastic ? (-ev.dgam * lam[k] * kIW[k]) : 0.0;
-    hess_apply(y, u, hu);
+    hess_apply<YK>(m, y, u, hu);
     const double lam6 = ev.plastic ? lam[6] : 0.0;
     if (pbar) {
         const double ge = dot<6>(y.gt, ev.e), hue = dot<6>(hu, ev.e);
@@ -315,18 +337,18 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
 // ---- forward tangent, structured (same contract as cm::tangent_point, DEF = FULL_3D) ------------------------
 template <int YK>
 CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, double (&T)[6][6]) {
-    EvalS ev;
+    EvalS<YK> ev;
     double C[7];
     residual_s<YK>(m, eg, x, xp, ev, C);
     PlasticOp op;
-    op_build(m, ev, op);
-    const YieldS& y = ev.y;
+    op_build<YK>(m, ev, op);
+    const YieldS<YK>& y = ev.y;
 #pragma unroll
     for (int l = 0; l < 6; ++l) {
         double b[7], unit[6], hcol[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) unit[k] = (k == l) ? 1.0 : 0.0;
-        hess_apply(y, unit, hcol);                             // column l of Ht
+        hess_apply<YK>(m, y, unit, hcol);                             // column l of Ht
         // b = -dC/deg_l = [ beta/w_k Ht_kl ; -gt_l ]  (plastic), 0 (elastic)
 #pragma unroll
         for (int k = 0; k < 6; ++k) b[k] = ev.plastic ? op.beta * kIW[k] * hcol[k] : 0.0;

@@ -199,11 +199,12 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
     double G[NU], xp[NX], x[NX], eg[6], z[6], sd[6];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
-    load_soa<6>(sbar_or_data, B, b, sd);
+    if constexpr (MODE == 0 || MODE == 2) load_soa<6>(sbar_or_data, B, b, sd);
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<ROT>(m, z);
     if constexpr (MODE == 1 || MODE == 3) {
         newton_any<DEF, YK>(m, eg, z, xp, x, valid);
+        load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
             if (sigma_out) {
