@@ -18,7 +18,7 @@
 #include <cmath>
 #define CM_D inline
 static inline bool __any(bool p) { return p; }
-using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::exp; using std::pow; using std::isfinite;
+using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::exp; using std::pow; using std::isfinite; using std::log1p;
 #else
 #include <hip/hip_runtime.h>
 #define CM_D __device__ __forceinline__
@@ -120,9 +120,120 @@ CM_D QuadForm quad_form(const cm_model_desc& m) {
     return q;
 }
 
+// ---- symmetric input-convex network [6, H, 1] (one hidden layer) --------------------------------------
+// cmad/neural_networks/input_convex_neural_network.py:36-69.  Packed weights (device memory, uniform
+// addresses -> scalar loads): W0[6][H], b0[H], Wx1[6], b1, Wz[H], in_scale[6], in_min[6], out_scale, out_min, f(0).
+// f(x) = softplus(x W0 + b0) . Wz + x . Wx1 + b1 ;  value/gradient/Hessian w.r.t. the SCALED input xs.
+template <bool HESS>
+CM_D void icnn_forward(const double* __restrict__ w, int H, const double xs[6], double& f, double g[6], double Hx[6][6]) {
+    const double* W0 = w; const double* b0 = w + 6 * H; const double* Wx1 = b0 + H; const double* b1 = Wx1 + 6;
+    const double* Wz = b1 + 1;
+    f = b1[0];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { f += xs[i] * Wx1[i]; g[i] = Wx1[i]; }
+    if constexpr (HESS) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Hx[i][j] = 0.0;
+    }
+    for (int o = 0; o < H; ++o) {
+        double a = b0[o];
+        double wc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { wc[i] = W0[i * H + o]; a += xs[i] * wc[i]; }
+        const double e = exp(-fabs(a));
+        const double inv = 1.0 / (1.0 + e);
+        const double sp = fmax(a, 0.0) + log1p(e);              // jax.nn.softplus = logaddexp(a, 0)
+        const double sg = (a >= 0.0) ? inv : e * inv;           // sigmoid(a)
+        const double wz = Wz[o];
+        f += sp * wz;
+        const double c1 = sg * wz;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] += c1 * wc[i];
+        if constexpr (HESS) {
+            const double c2 = sg * (1.0 - sg) * wz;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) Hx[i][j] += c2 * wc[i] * wc[j];
+        }
+    }
+    if constexpr (HESS) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j) Hx[i][j] = Hx[j][i];
+    }
+}
+
+// NN(flat dev s) of hybrid_hill_effective_stress (cmad/models/effective_stress.py:149-163) in the 6-vector
+// basis: value, d/ds6, d2/ds6 ds6.  NN input order is [xx,yy,zz,xy,xz,yz] of the deviator.
+template <bool HESS>
+CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val, double g6[6], double H6[6][6]) {
+    const double* __restrict__ w = m.nn_weights;
+    const int H = m.nn_widths[1];
+    const double* sc = w + 6 * H + H + 6 + 1 + H;             // in_scale[6], in_min[6], out_scale, out_min, f0
+    const double h = (s[0] + s[3] + s[5]) * (1.0 / 3.0);
+    const double x[6] = {s[0] - h, s[3] - h, s[5] - h, s[1], s[2], s[4]};
+    double xp[6], xn[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { xp[i] = sc[i] * x[i] + sc[6 + i]; xn[i] = -xp[i]; }
+    double fp, fn, gp[6], gn[6], Hp[6][6], Hn[6][6];
+    icnn_forward<HESS>(w, H, xp, fp, gp, Hp);
+    icnn_forward<HESS>(w, H, xn, fn, gn, Hn);
+    const double ios = 1.0 / sc[12];
+    val = (0.5 * (fp + fn) - sc[14] - sc[13]) * ios;           // (1/2 (f(x)+f(-x)) - f(0) - out_min) / out_scale
+    double gx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gx[i] = 0.5 * (gp[i] - gn[i]) * sc[i] * ios;
+    // chain through x(s6): normal slots k -> x index (0,1,2) minus the mean; shear slots 1,2,4 -> x index 3,4,5
+    constexpr int XI[6] = {0, 3, 4, 1, 5, 2};
+    const double gm = (gx[0] + gx[1] + gx[2]) * (1.0 / 3.0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g6[k] = gx[XI[k]] - (kDiag[k] ? gm : 0.0);
+    if constexpr (HESS) {
+        double Hx[6][6], rm[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Hx[i][j] = 0.5 * (Hp[i][j] + Hn[i][j]) * sc[i] * sc[j] * ios;
+        // J = d x / d s6: H6 = J^T Hx J with J_ik = delta(i, XI[k]) - (i < 3 && diag k) / 3
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { rm[i] = (Hx[i][0] + Hx[i][1] + Hx[i][2]) * (1.0 / 3.0); }   // row means over normal cols
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tot += rm[i];
+        tot *= (1.0 / 3.0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int l = 0; l < 6; ++l) {
+                double v = Hx[XI[k]][XI[l]];
+                if (kDiag[l]) v -= rm[XI[k]];
+                if (kDiag[k]) v -= rm[XI[l]];
+                if (kDiag[k] && kDiag[l]) v += tot;
+                H6[k][l] = v;
+            }
+    }
+}
+
 template <int YK, bool HESS>
 CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
-    if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
+    if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
+        yield_eval<CM_YIELD_HILL, HESS>(m, s, phi, gt, Ht);
+        double v, g6[6], H6[6][6];
+        icnn_yield_term<HESS>(m, s, v, g6, H6);
+        phi += v;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gt[k] += g6[k];
+        if constexpr (HESS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int l = 0; l < 6; ++l) Ht[k][l] += H6[k][l];
+        }
+    } else if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
         const QuadForm q = quad_form<YK>(m);
         double As[6];
         As[0] = q.a00 * s[0] + q.a03 * s[3] + q.a05 * s[5];

@@ -367,19 +367,19 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
 // ---- front doors: structured for FULL_3D, dense otherwise (STRUCT = false forces the dense path) ------------
 template <int DEF, int YK, bool STRUCT = true>
 CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid) {
-    if constexpr (STRUCT && DEF == CM_FULL_3D) return newton_s<YK>(m, eg, xp, x, valid);
+    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) return newton_s<YK>(m, eg, xp, x, valid);
     else return newton<DEF, YK>(m, eg, z, xp, x, valid);
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
                       const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar) {
-    if constexpr (STRUCT && DEF == CM_FULL_3D) return reverse_point_s<YK>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar);
+    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) return reverse_point_s<YK>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar);
     else return reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, egbar);
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
                       double (&T)[6][6]) {
-    if constexpr (STRUCT && DEF == CM_FULL_3D) return tangent_point_s<YK>(m, eg, x, xp, T);
+    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) return tangent_point_s<YK>(m, eg, x, xp, T);
     else return tangent_point<DEF, YK>(m, eg, z, x, xp, T);
 }
 

@@ -309,23 +309,30 @@ inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 inline bool supported(const cm_model_desc* m) {
     if (m->model_kind != CM_SMALL_ELASTIC_PLASTIC) return false;
     if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS) return false;
+    if (m->yield_kind == CM_YIELD_HYBRID_HILL_NN)      // one hidden layer [6, H, 1], weights resident on the device
+        return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
+               m->nn_widths[1] >= 1 && m->nn_widths[1] <= 256;
     if (m->yield_kind != CM_YIELD_J2 && m->yield_kind != CM_YIELD_HILL && m->yield_kind != CM_YIELD_HOSFORD) return false;
     return true;
 }
 
 // calls F.template operator()<DEF, YK, ROT>() for the runtime (def_type, yield_kind, rotation) triple
+// returns false when no specialisation exists (the caller reports CM_ERR_UNSUPPORTED -- never a silent no-op)
 template <class F>
-inline void dispatch(const cm_model_desc* m, F&& f) {
+inline bool dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity;
 #define CM_CASE(D, Y) \
-    if (m->def_type == D && m->yield_kind == Y) { if (rot) f.template operator()<D, Y, true>(); else f.template operator()<D, Y, false>(); return; }
+    if (m->def_type == D && m->yield_kind == Y) { if (rot) f.template operator()<D, Y, true>(); else f.template operator()<D, Y, false>(); return true; }
     CM_CASE(CM_FULL_3D, CM_YIELD_J2)
     CM_CASE(CM_FULL_3D, CM_YIELD_HILL)
     CM_CASE(CM_FULL_3D, CM_YIELD_HOSFORD)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_J2)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HILL)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
+    CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
 #undef CM_CASE
+    return false;
 }
 
 int g_last_hip_error = 0;
@@ -346,9 +353,10 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
-    dispatch(m, [&]<int D, int Y, bool R>() {
+    const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
         hipLaunchKernelGGL((k_update<D, Y, R, TANGENT>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
     });
+    if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
 }
 
@@ -371,10 +379,11 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
-        dispatch(m, [&]<int D, int Y, bool R>() {
+        const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
             hipLaunchKernelGGL((k_reverse<D, Y, R, MODE>), grid, block, 0, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                hist_in, xi_out, sigma_out, xpbar, gbar, partials);
         });
+        if (!found) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     double* stage = partials + nb * kRed;
@@ -465,9 +474,10 @@ int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
     (void)hipGetLastError();
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    dispatch(m, [&]<int D, int Y, bool R>() {
+    const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
         hipLaunchKernelGGL((k_evaluate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, xi_prev, xi, C, jac, sigma, dsigma);
     });
+    if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
 }
 

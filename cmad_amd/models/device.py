@@ -47,8 +47,31 @@ def _first_key(d):
     return next(iter(d))
 
 
+class HybridHillEffectiveStress:
+    """Selector for the hybrid yield surface phi = phi_hill(sigma) + ICNN(dev sigma)
+    (`hybrid_hill_effective_stress`, cmad/models/effective_stress.py:149-163).  Pass an instance as
+    `SmallElasticPlastic(..., effective_stress_fun=HybridHillEffectiveStress(icnn))` where the reference passes
+    `partial(hybrid_hill_effective_stress, nn_fun=icnn.evaluate)`; the network weights are read from
+    params["plastic"]["effective stress"]["neural network"] like the reference does.
+    The HIP kernel supports one hidden layer ([6, H, 1]); the beta-rescaled variant
+    (`scaled_effective_stress`, :130-146) is not built."""
+
+    def __init__(self, icnn):
+        if len(icnn.layer_widths) != 3 or icnn.layer_widths[0] != 6 or icnn.layer_widths[-1] != 1:
+            raise NotImplementedError("the HIP kernel supports ICNN layer widths [6, H, 1]")
+        self.icnn = icnn
+
+    def packed(self, values):
+        """Device layout: the oracle/ICNN packing + f(0) of the scaled network appended."""
+        from ..neural_networks.input_convex_neural_network import forward
+        nn_params = values["plastic"]["effective stress"].get("neural network", self.icnn.params)
+        widths, w = self.icnn.pack_for_device(nn_params)
+        f0 = float(np.asarray(forward(np.zeros(widths[0]), nn_params)).ravel()[0])
+        return widths, np.concatenate([w, [f0]])
+
+
 def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, uniaxial_stress_idx=0,
-               newton: NewtonSettings | None = None, effective_stress_type: str | None = None):
+               newton: NewtonSettings | None = None, effective_stress_type: str | None = None, hybrid=None):
     """Flatten a CMAD parameter tree into a `cm_model_desc`.
 
     Returns (desc, info) where info carries what the sensitivity mapping needs:
@@ -59,9 +82,11 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     d.def_type = int(def_type)
     plastic = values["plastic"]
     ytype = effective_stress_type or _first_key(plastic["effective stress"])     # small_elastic_plastic.py:190-195
+    if hybrid is not None:
+        ytype = "hill"
     if ytype not in YIELD_KINDS:
         raise NotImplementedError(f"effective stress '{ytype}' has no HIP kernel")
-    d.yield_kind = YIELD_KINDS[ytype]
+    d.yield_kind = 3 if hybrid is not None else YIELD_KINDS[ytype]
     Q = np.asarray(values.get("rotation matrix", np.eye(3)), dtype=np.float64).reshape(3, 3)
     for i in range(9):
         d.Q[i] = float(Q.reshape(9)[i])
@@ -96,6 +121,13 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     d.ls_lo = float(ls.get("min backtrack factor", 0.5))
     d.ls_hi = float(ls.get("max backtrack factor", 0.9))
     info = {"elastic_names": names, "lame_jac": J, "yield_type": ytype}
+    if hybrid is not None:
+        widths, packed = hybrid.packed(values)
+        d.nn_nlayers = len(widths)
+        for i, w in enumerate(widths):
+            d.nn_widths[i] = int(w)
+        info["yield_type"] = "hybrid"
+        info["nn_packed"] = np.ascontiguousarray(packed, dtype=np.float64)   # the caller places it and sets d.nn_weights
     return d, info
 
 
@@ -117,7 +149,11 @@ def kp_to_leaf_grad(path, g_kp, info):
     if parent == "linear":
         return g_kp[_lib.P_LIN_K]
     if parent == "hill":
+        if info.get("yield_type") == "hybrid":
+            raise NotImplementedError("Hill-coefficient sensitivities of the hybrid Hill+NN surface are not available")
         return g_kp[_lib.P_YC0 + HILL_NAMES.index(leaf)]
+    if "neural network" in path:
+        raise NotImplementedError("sensitivities w.r.t. network weights are not available in the HIP path")
     if parent == "effective stress" and leaf == "J2":
         return g_kp[0] * 0.0
     if parent == "hosford":
@@ -179,6 +215,11 @@ class DeviceEvaluator:
         if self.nx < 0 or self.nu < 0:
             raise NotImplementedError("def_type not available in the HIP library")
         self._ws = None
+        self._nn_dev = None
+        if "nn_packed" in info:                    # network weights live in device memory for the kernels
+            torch = _torch()
+            self._nn_dev = torch.from_numpy(info["nn_packed"]).cuda()
+            desc.nn_weights = self._nn_dev.data_ptr()
 
     # -- helpers
     def _stream(self):

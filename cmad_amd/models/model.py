@@ -50,6 +50,7 @@ class Model(ABC):
     _model_kind: int = 0
     _yield_tol: float = 1e-14
     _uniaxial_stress_idx: int = 0
+    _hybrid = None                       # HybridHillEffectiveStress or None
 
     @classmethod
     def from_deck(cls, model_section: dict, parameters: Parameters, def_type: int) -> "Model":
@@ -73,7 +74,8 @@ class Model(ABC):
     def _desc(self, params=None, newton: NewtonSettings | None = None):
         return build_desc(self.parameters.values if params is None else params, def_type=self._def_type,
                           model_kind=self._model_kind, yield_tol=self._yield_tol,
-                          uniaxial_stress_idx=self._uniaxial_stress_idx, newton=newton or self.newton_settings)
+                          uniaxial_stress_idx=self._uniaxial_stress_idx, newton=newton or self.newton_settings,
+                          hybrid=self._hybrid)
 
     def device_evaluator(self, newton: NewtonSettings | None = None) -> DeviceEvaluator:
         """A `DeviceEvaluator` for the CURRENT parameter values (rebuilt per call: parameters change between
@@ -93,6 +95,9 @@ class Model(ABC):
         if nx < 0:
             raise NotImplementedError("def_type not available in the HIP library")
         dev = torch.device("cuda")
+        if "nn_packed" in info:
+            nn_dev = torch.from_numpy(info["nn_packed"]).to(dev)
+            desc.nn_weights = nn_dev.data_ptr()
         G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).to(dev)
         g, x1, x0 = t(G), t(self._flat(xi)), t(self._flat(xi_prev))

@@ -26,6 +26,9 @@ class SmallElasticPlastic(Model):
     def __init__(self, parameters: Parameters, def_type: int = DefType.FULL_3D,
                  elastic_stress_fun=None, effective_stress_fun=None, hardening_funs=None,
                  yield_tol: float = 1e-14, uniaxial_stress_idx: int = 0, is_complex: bool = False) -> None:
+        from .device import HybridHillEffectiveStress
+        if isinstance(effective_stress_fun, HybridHillEffectiveStress):
+            self._hybrid, effective_stress_fun = effective_stress_fun, None
         if elastic_stress_fun is not None or effective_stress_fun is not None or hardening_funs is not None:
             # the reference lets callers inject JAX callables (:112-115); the HIP path has a fixed kernel menu
             raise NotImplementedError("custom elastic/effective-stress/hardening callables have no HIP kernel; "

@@ -101,6 +101,8 @@ static int dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_J2)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HILL)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
+    CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
 #undef CM_CASE
     return -2;
 }

@@ -108,12 +108,19 @@ def check_vjp(backend, sc, incoming=False):
 class HostBackend:
     """Host build of cm_device.hpp (tests/native) -- CPU CI coverage of the kernel arithmetic."""
 
+    @staticmethod
+    def _nn(sc):
+        if "nn_packed" in sc.info:                       # host build reads the weights from host memory
+            sc.desc.nn_weights = sc.info["nn_packed"].ctypes.data
+
     def update(self, sc, gradu, xi_prev, tangent=False):
         import host_harness_lib as hh
+        self._nn(sc)
         return hh.update(sc.desc, gradu, xi_prev, sc.mat.nx, tangent=tangent)
 
     def vjp(self, sc, gradu, xi_prev, xi, sbar):
         import host_harness_lib as hh
+        self._nn(sc)
         return hh.vjp(sc.desc, gradu, xi_prev, xi, sbar)
 
 
@@ -141,3 +148,94 @@ class GpuBackend:
         g, xb, ub = self.ev(sc).update_vjp(self.t(gradu), self.t(xi_prev), self.t(xi), self.t(sbar),
                                            want_xi_prev_bar=True, want_gradu_bar=True)
         return g.cpu().numpy(), xb.cpu().numpy(), ub.cpu().numpy()
+
+
+def check_hosford_a100(backend, B=2048):
+    """BASELINE.json configs[2]: near-Tresca Hosford (a = 100) with the notch deck's material and solver
+    settings (examples/notch_hosford.yaml:29-42: E 1000, nu 0.25, Y 2, Voce S 10 D 2; 500 local iterations,
+    tol 1e-12, line search 100 evals).  Parity unpinned by the reference (no test uses a = 100): oracle only."""
+    from cmad_amd.models.device import NewtonSettings, build_desc
+    from cmad_amd.synthetic import gauss_point_batch, hosford_values
+
+    class S:                       # minimal scenario shim for the backends
+        pass
+    sc = S()
+    vals = hosford_values()
+    sc.mat = ol.Material(vals)
+    st_o = ol.newton_settings(max_iters=500, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=100)
+    sc.desc, sc.info = build_desc(vals, newton=NewtonSettings.traced(max_iters=500, abs_tol=1e-12, rel_tol=1e-12,
+                                                                      line_search_settings={"max evals": 100}))
+    g = gauss_point_batch(B, eps_y=2e-3, seed=22, skew=True)
+    xp = np.zeros((7, B))
+    for step in range(2):
+        xi_o, sig_o, it_o, cv_o = sc.mat.update_batch(st_o, g, xp)
+        xi_d, sig_d, status = backend.update(sc, g, xp)
+        status = status.astype(np.uint32)
+        assert cv_o.all() and ((status >> 16) & 1).all()
+        np.testing.assert_allclose(xi_d, xi_o, rtol=1e-10, atol=1e-11)      # Newton tol 1e-12, |xi| ~ 1e-3
+        np.testing.assert_allclose(sig_d, sig_o, rtol=1e-10, atol=1e-8)
+        assert np.mean((status & 0xFFFF) == it_o) > 0.97
+        assert (it_o > 0).mean() > 0.2 and it_o.max() > 5
+        xp, g = xi_o, 1.3 * g
+
+
+def al7079_hybrid_setup():
+    """BASELINE.json configs[3]: hybrid Hill + symmetric ICNN [6, 16, 1] yield surface with the Al7079 elastic
+    constants and Hill coefficients (cmad/calibrations/al7079/support.py:76-78,
+    nn_hill_uniaxial_stress_forward.py:84), weights from the seeded initialiser (seed 22), input scaler on
+    (0, 1) with zero offset and output scaler on the +/- sigma_c range as in
+    fit_hybrid_icnn_effective_stress.py:46-63,258-263.  The trained pickle is not in the reference repo."""
+    from cmad_amd.neural_networks import AffineScaler, InputConvexNeuralNetwork
+    sig_c = np.array([525., 512., 515., 505., 493., 511., 530., 510., 544., 523., 486., 485.])
+    feats = np.abs(np.random.default_rng(22).normal(size=(24, 6))) * 300.0 + 50.0      # stand-in deviator samples
+    in_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.vstack([feats, np.zeros((1, 6))]))
+    in_sc.min_ = in_sc.min_ * 0.0
+    out_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.r_[-sig_c, sig_c].reshape(-1, 1))
+    icnn = InputConvexNeuralNetwork([6, 16, 1], in_sc, out_sc, seed=22)
+    values = ol.j2_voce_values(E=70.22857142857143e3, nu=0.33396551724137924, Y=525.0, S=200., D=20.,
+                               yield_kind="hill", hill=HILL)
+    values["plastic"]["effective stress"]["neural network"] = icnn.params
+    return icnn, values
+
+
+def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False):
+    from cmad_amd.models.device import HybridHillEffectiveStress, NewtonSettings, build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+
+    class S:
+        pass
+    sc = S()
+    icnn, values = al7079_hybrid_setup()
+    if rot:
+        values["rotation matrix"] = rand_rot(np.random.default_rng(4))
+    widths, packed = icnn.pack_for_device()
+    sc.mat = ol.Material(values, def_type=def_type, nn=(widths, packed))
+    st_o = ol.newton_settings(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=10)
+    st_d = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})
+    hyb = HybridHillEffectiveStress(icnn)
+    sc.desc, sc.info = build_desc(values, def_type=def_type, newton=st_d, hybrid=hyb)
+    sc._keep = sc.info["nn_packed"]
+    nd = 3 if def_type == ol.FULL_3D else 2
+    eps_y = 525.0 / 70.2e3
+    g = gauss_point_batch(B, eps_y=eps_y, seed=22, skew=True, ndims=nd, dev_scale=5.0)
+    xp = np.tile(sc.mat.init_xi()[:, None], (1, B))
+    for step in range(2):
+        xi_o, sig_o, it_o, cv_o = sc.mat.update_batch(st_o, g, xp)
+        xi_d, sig_d, status = backend.update(sc, g, xp)
+        status = status.astype(np.uint32)
+        ok = cv_o.astype(bool) & ((status >> 16) & 1).astype(bool)
+        assert ok.mean() > 0.99, (cv_o.mean(), ((status >> 16) & 1).mean())
+        np.testing.assert_allclose(xi_d[:, ok], xi_o[:, ok], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(sig_d[:, ok], sig_o[:, ok], rtol=1e-9, atol=1e-7)
+        assert (it_o > 0).mean() > 0.1
+        xp, g = xi_o, 1.3 * g
+    # sensitivities at the converged state
+    sbar = np.random.default_rng(5).normal(size=(6, B))
+    g_o, xb_o, ub_o = sc.mat.update_vjp_batch(g / 1.3, xp, xi_o, sbar)
+    g_d, xb_d, ub_d = backend.vjp(sc, g / 1.3, xp, xi_o, sbar)
+    np.testing.assert_allclose(xb_d, xb_o, rtol=1e-8, atol=1e-8 * np.abs(xb_o).max())
+    np.testing.assert_allclose(ub_d, ub_o, rtol=1e-8, atol=1e-8 * np.abs(ub_o).max())
+    from cmad_amd.models.device import kp_to_leaf_grad
+    for path in param_paths("J2"):
+        np.testing.assert_allclose(kp_to_leaf_grad(path, g_d, sc.info), g_o[sc.mat.param_index(path)], rtol=1e-8,
+                                   atol=1e-10 * np.abs(g_o).max())

@@ -72,3 +72,31 @@ def test_bad_arguments_raise():
         ev.update(g.float(), torch.zeros((7, 8), dtype=torch.float64, device="cuda"))
     with pytest.raises(ValueError):
         ev.update(g.cpu(), torch.zeros((7, 8), dtype=torch.float64))
+
+
+def test_hosford_a100_notch_material(backend):
+    pc.check_hosford_a100(backend, B=4096)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_hybrid_hill_icnn(backend, def_type):
+    """BASELINE.json configs[3]: neural-network yield surface plugged into the return mapping."""
+    pc.check_hybrid_nn(backend, def_type, B=2048, rot=(def_type == ol.FULL_3D))
+
+
+def test_hybrid_through_the_facade():
+    import torch
+    from cmad_amd.models import DefType, HybridHillEffectiveStress, SmallElasticPlastic
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.synthetic import gauss_point_batch
+    icnn, values = pc.al7079_hybrid_setup()
+    model = SmallElasticPlastic(Parameters(values), DefType.FULL_3D, effective_stress_fun=HybridHillEffectiveStress(icnn))
+    B = 256
+    g = gauss_point_batch(B, eps_y=525.0 / 70.2e3, dev_scale=5.0)
+    xi, sig, st = model.update_batch(torch.from_numpy(g).cuda(), torch.zeros((7, B), dtype=torch.float64, device="cuda"))
+    mat = ol.Material(values, nn=icnn.pack_for_device())
+    xi_o, sig_o, it_o, cv = mat.update_batch(ol.newton_settings(), g, np.zeros((7, B)))
+    ok = cv.astype(bool)
+    np.testing.assert_allclose(xi.cpu().numpy()[:, ok], xi_o[:, ok], rtol=1e-9, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        SmallElasticPlastic(Parameters(values), DefType.FULL_3D, effective_stress_fun=lambda c, p: 0.0)

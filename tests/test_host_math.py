@@ -83,3 +83,13 @@ def test_explicit_blocks_at_arbitrary_states(def_type, yield_kind, kw, rot, plas
             got = kp_to_leaf_grad(path, np.moveaxis(S[:, :, 0], 1, 0), info)
             ref = So[:, mat.param_index(path)]
             np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(So).max()), err_msg=str(path))
+
+
+def test_hosford_a100_notch_material():
+    pc.check_hosford_a100(BACKEND, B=1024)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_hybrid_hill_icnn(def_type, rot):
+    pc.check_hybrid_nn(BACKEND, def_type, B=192, rot=rot)
