@@ -18,7 +18,7 @@
 #include <cmath>
 #define CM_D inline
 static inline bool __any(bool p) { return p; }
-using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::exp; using std::pow; using std::isfinite; using std::log1p;
+using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::exp; using std::pow; using std::isfinite; using std::log1p; using std::log;
 #else
 #include <hip/hip_runtime.h>
 #define CM_D __device__ __forceinline__
@@ -267,15 +267,20 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
         const double t0 = fabs(dd[0]), t1 = fabs(dd[1]), t2 = fabs(dd[2]);
         const double mx = fmax(t0, fmax(t1, t2));
         const double u[3] = {t0 / mx, t1 / mx, t2 / mx};
-        const double S = 0.5 * (pow(u[0], a) + pow(u[1], a) + pow(u[2], a));
-        const double Sr = pow(S, 1.0 / a);
+        // u_i^a = exp(a log u_i) (u_i in [0,1]); (|d_i|/phi)^(a-2) = u_i^a Sr^2 / (u_i^2 S) -- no further pow
+        double ua[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ua[i] = (u[i] > 0.0) ? exp(a * log(u[i])) : 0.0;
+        const double S = 0.5 * (ua[0] + ua[1] + ua[2]);
+        const double Sr = exp(log(S) / a);
         phi = mx * Sr;
         double p[3], r[3], sg[3], ram2[3];
+        const double c2 = Sr * Sr / S;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             r[i] = u[i] / Sr;                                  // |d_i| / phi
             sg[i] = (dd[i] > 0.0) ? 1.0 : ((dd[i] < 0.0) ? -1.0 : 0.0);
-            ram2[i] = pow(r[i], a - 2.0);
+            ram2[i] = (u[i] > 0.0) ? ua[i] * c2 / (u[i] * u[i]) : ((a == 2.0) ? 1.0 : 0.0);
             p[i] = 0.5 * ram2[i] * r[i] * sg[i];               // d phi / d d_i
         }
 #pragma unroll
@@ -440,6 +445,116 @@ CM_D void jacobian_x(const cm_model_desc& m, const double z[6], const Eval<DEF>&
 #undef CM_A
 }
 
+// ---- rate-form model: unknown is the material Cauchy stress ------------------------------------------------
+// cmad/models/small_rate_elastic_plastic.py:249-346.  x = [sigma(6), alpha (, F33)]; `deg` is the material-frame
+// total-strain increment V(Q^T (eps - eps_prev) Q) (:34-76; PLANE_STRESS adds (F33 - F33_prev) z).
+//   C_e = [ (sigma - sigma_prev - Cel de) / 2mu , dgam ]
+//   C_p = [ (sigma - sigma_prev - Cel de + dgam Cel n) / 2mu , f(sigma, alpha) ],  n = W^-1 gt(sigma)
+//   PLANE_STRESS row: (w o z) . (Cel de [- dgam Cel n]) / 2mu
+template <int DEF, int YK, bool HESS>
+CM_D void residual_rate(const cm_model_desc& m, const double deg[6], const double z[6],
+                        const double* x, const double* xp, Eval<DEF>& ev, double* C, double Ht[6][6]) {
+    constexpr int NX = Dims<DEF>::NX;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        ev.s[k] = x[k];
+        double e = deg[k];
+        if constexpr (DEF == CM_PLANE_STRESS) e += (x[7] - xp[7]) * z[k];
+        ev.e[k] = e;                                             // strain increment
+    }
+    ev.tr = ev.e[0] + ev.e[3] + ev.e[5];
+    yield_eval<YK, HESS>(m, ev.s, ev.phi, ev.gt, Ht);
+    ev.hd = hardening(m, x[6]);
+    const double i2mu = 0.5 / m.mu, twomu = 2.0 * m.mu;
+    ev.f = (ev.phi - (m.Y + ev.hd.H)) * i2mu;
+    ev.dgam = x[6] - xp[6];
+    ev.plastic = (ev.f > m.yield_tol) || (fabs(ev.f) < m.yield_tol);
+    const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
+    double r7 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double tdc = twomu * ev.e[k] + (kDiag[k] ? m.lambda * ev.tr : 0.0);
+        const double cn = twomu * ev.gt[k] * kIW[k] + (kDiag[k] ? m.lambda * gd : 0.0);
+        const double dc = ev.plastic ? (tdc - ev.dgam * cn) : tdc;   // select, not multiply: the normal is NaN at sigma = 0
+        C[k] = (x[k] - xp[k] - dc) * i2mu;
+        if constexpr (DEF == CM_PLANE_STRESS) r7 += kW[k] * z[k] * dc;
+    }
+    C[6] = ev.plastic ? ev.f : ev.dgam;
+    if constexpr (DEF == CM_PLANE_STRESS) C[NX - 1] = r7 * i2mu;
+}
+
+template <int DEF, bool TRANSPOSED>
+CM_D void jacobian_rate(const cm_model_desc& m, const double z[6], const Eval<DEF>& ev, const double Ht[6][6],
+                        double (&A)[Dims<DEF>::NX][Dims<DEF>::NX]) {
+    constexpr int NX = Dims<DEF>::NX;
+    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+#define CM_A(r, c) (TRANSPOSED ? A[c][r] : A[r][c])
+#pragma unroll
+    for (int r = 0; r < NX; ++r)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) CM_A(r, c) = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) CM_A(k, k) = i2mu;
+    CM_A(6, 6) = 1.0;
+    double M[6][6];                                  // dgam Cel W^-1 Ht (plastic) -- also feeds the PS row
+    const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
+    if (ev.plastic) {
+        double hd[6];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) hd[l] = Ht[0][l] + Ht[3][l] + Ht[5][l];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int l = 0; l < 6; ++l) {
+                M[k][l] = ev.dgam * (twomu * Ht[k][l] * kIW[k] + (kDiag[k] ? lam * hd[l] : 0.0));
+                CM_A(k, l) += M[k][l] * i2mu;
+            }
+            CM_A(k, 6) = (twomu * ev.gt[k] * kIW[k] + (kDiag[k] ? lam * gd : 0.0)) * i2mu;
+            CM_A(6, k) = ev.gt[k] * i2mu;
+        }
+        CM_A(6, 6) = -ev.hd.dH * i2mu;
+    }
+    if constexpr (DEF == CM_PLANE_STRESS) {
+        const double zt = z[0] + z[3] + z[5];
+        double zcz = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double cz = twomu * z[k] + (kDiag[k] ? lam * zt : 0.0);
+            CM_A(k, 7) = -cz * i2mu;
+            zcz += kW[k] * z[k] * cz;
+        }
+        CM_A(7, 7) = zcz * i2mu;
+        if (ev.plastic) {
+            double cnz = 0.0;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) {
+                double sM = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sM += kW[k] * z[k] * M[k][l];
+                CM_A(7, l) = -sM * i2mu;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cnz += kW[k] * z[k] * (twomu * ev.gt[k] * kIW[k] + (kDiag[k] ? lam * gd : 0.0));
+            CM_A(7, 6) = -cnz * i2mu;
+        }
+    }
+#undef CM_A
+}
+
+// model-kind front doors used by the generic (dense) Newton
+template <int MK, int DEF, int YK, bool HESS>
+CM_D void residual_mk(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
+                      Eval<DEF>& ev, double* C, double Ht[6][6]) {
+    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) residual_rate<DEF, YK, HESS>(m, eg, z, x, xp, ev, C, Ht);
+    else residual<DEF, YK, HESS>(m, eg, z, x, xp, ev, C, Ht);
+}
+template <int MK, int DEF>
+CM_D void jacobian_mk(const cm_model_desc& m, const double z[6], const Eval<DEF>& ev, const double Ht[6][6],
+                      double (&A)[Dims<DEF>::NX][Dims<DEF>::NX]) {
+    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) jacobian_rate<DEF, false>(m, z, ev, Ht, A);
+    else jacobian_x<DEF, false>(m, z, ev, Ht, A);
+}
+
 // ---- dense N x N solves, fully unrolled, no pivoting ---------------------------------------------
 // (the leading 6x6 block is I + dgam * (PSD-like); a vanishing pivot is reported)
 template <int N>
@@ -504,7 +619,7 @@ CM_D double quad_min(double phi0, double dphi0, double a, double phi) {
 // (:14-85, ls_max_evals == 0).  One point per lane; wave-level ballots (__any) drive the loops so an
 // all-elastic / all-converged wavefront leaves at once and the rest iterate under the exec mask.
 // Returns the status word.
-template <int DEF, int YK>
+template <int DEF, int YK, int MK = CM_SMALL_ELASTIC_PLASTIC>
 CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x,
                      bool lane_valid) {
     constexpr int NX = Dims<DEF>::NX;
@@ -512,7 +627,7 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
     double C[NX], Ht[6][6];
 #pragma unroll
     for (int k = 0; k < NX; ++k) x[k] = xp[k];
-    residual<DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
+    residual_mk<MK, DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
     // ||C||/||C0|| < rel_tol or ||C|| < abs_tol (nonlinear_solver.py:140-150), tested on squared norms
     // (no sqrt, no division; 0/0 -> NaN -> false in the reference == 0 < 0 -> false here)
     const double n0sq = dot<NX>(C, C);
@@ -528,8 +643,8 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
         if (!__any(running)) break;
         if (running) {
             double A[NX][NX], delta[NX];
-            residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
-            jacobian_x<DEF, false>(m, z, ev, Ht, A);
+            residual_mk<MK, DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
+            jacobian_mk<MK, DEF>(m, z, ev, Ht, A);
             if (!lu_factor<NX>(A)) flags |= CM_STATUS_SINGULAR;
 #pragma unroll
             for (int k = 0; k < NX; ++k) delta[k] = C[k];
@@ -537,7 +652,7 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
             if (m.ls_max_evals <= 0) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k) x[k] -= delta[k];
-                residual<DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
+                residual_mk<MK, DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
             } else {
                 const double cc = dot<NX>(C, C);
                 const double phi0 = 0.5 * cc, dphi0 = -cc, armijo = m.ls_c1 * dphi0;
@@ -553,7 +668,7 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
 #pragma unroll
                         for (int k = 0; k < NX; ++k) xt[k] = x[k] - alpha * delta[k];
                         Eval<DEF> et;
-                        residual<DEF, YK, false>(m, eg, z, xt, xp, et, Ct, Ht);
+                        residual_mk<MK, DEF, YK, false>(m, eg, z, xt, xp, et, Ct, Ht);
                         const double phi = 0.5 * dot<NX>(Ct, Ct);
                         const bool finite = isfinite(phi);
                         if (finite && phi < best_phi) {

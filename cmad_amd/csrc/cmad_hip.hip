@@ -87,6 +87,42 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
     }
 }
 
+// ---- cm_update_rate: rate-form model (small_rate_elastic_plastic) ------------------------------------------
+template <int DEF, int YK, bool ROT>
+__global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
+        double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
+    gradu += blk0; gradu_prev += blk0; xi_prev += blk0; xi += blk0;
+    if (sigma) sigma += blk0;
+    if (status) status += blk0;
+    double G[NU], Gp[NU], xp[NX], x[NX], deg[6], z[6];
+    load_soa<NU>(gradu, B, b, G);
+    load_soa<NU>(gradu_prev, B, b, Gp);
+    load_soa<NX>(xi_prev, B, b, xp);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) G[k] -= Gp[k];                  // eps - eps_prev is linear in grad u
+    strain_from_gradu<DEF, ROT>(m, G, deg);
+    strain_z<ROT>(m, z);
+    uint32_t st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC>(m, deg, z, xp, x, valid);
+    double sg[6];
+    to_global<ROT>(m, x, sg);                                    // small_rate_elastic_plastic.py:351-359
+    if (status) {
+        double phi, gt[6], Ht[6][6];
+        yield_eval<YK, false>(m, x, phi, gt, Ht);
+        const double f = (phi - (m.Y + hardening(m, x[6]).H)) * 0.5 / m.mu;
+        if ((f > m.yield_tol) || (fabs(f) < m.yield_tol)) st |= CM_STATUS_PLASTIC;
+    }
+    if (valid) {
+        store_soa<NX>(xi, B, b, x);
+        if (sigma) store_soa<6>(sigma, B, b, sg);
+        if (status) status[b] = st;
+    }
+}
+
 // ---- block reduction of NV doubles per lane into partials[blockIdx][NV] ----------------------------
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(double* v, double* __restrict__ partials) {
@@ -306,8 +342,8 @@ __global__ __launch_bounds__(64) void k_evaluate(cm_model_desc m, int64_t B, int
 // ---- dispatch --------------------------------------------------------------------------------------
 inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 
-inline bool supported(const cm_model_desc* m) {
-    if (m->model_kind != CM_SMALL_ELASTIC_PLASTIC) return false;
+inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_PLASTIC) {
+    if (m->model_kind != model_kind) return false;
     if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS) return false;
     if (m->yield_kind == CM_YIELD_HYBRID_HILL_NN)      // one hidden layer [6, H, 1], weights resident on the device
         return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
@@ -424,6 +460,23 @@ int64_t cm_workspace_bytes(int64_t B) {
 int cm_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
               double* xi, double* sigma, uint32_t* status, void* stream) {
     return launch_update<false>(m, B, gradu, xi_prev, xi, sigma, nullptr, status, stream);
+}
+
+int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                   const double* xi_prev, double* xi, double* sigma, uint32_t* status, void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC)) return CM_ERR_UNSUPPORTED;
+    if (B == 0) return CM_OK;
+    if (!gradu || !gradu_prev || !xi_prev || !xi) return CM_ERR_BAD_ARG;
+    const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
+        hipLaunchKernelGGL((k_update_rate<D, Y, R>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma, status);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
 }
 
 int cm_update_tangent(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,

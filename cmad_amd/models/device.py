@@ -256,6 +256,21 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_update")
         return xi, sigma, status
 
+    def update_rate(self, gradu, gradu_prev, xi_prev, want_sigma=True, want_status=True):
+        """Rate-form model (`small_rate_elastic_plastic`): xi = [sigma(6), alpha (, F33)]."""
+        torch = _torch()
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(gradu_prev, self.nu, B, "gradu_prev")
+        _check_soa(xi_prev, self.nx, B, "xi_prev")
+        dev = gradu.device
+        xi = torch.empty((self.nx, B), dtype=torch.float64, device=dev)
+        sigma = torch.empty((6, B), dtype=torch.float64, device=dev) if want_sigma else None
+        status = torch.empty((B,), dtype=torch.int32, device=dev) if want_status else None
+        rc = self.L.cm_update_rate(C.byref(self.desc), B, _ptr(gradu), _ptr(gradu_prev), _ptr(xi_prev), _ptr(xi),
+                                   _ptr(sigma), _ptr(status), self._stream())
+        _lib.check(rc, "cm_update_rate")
+        return xi, sigma, status
+
     def update_vjp(self, gradu, xi_prev, xi, sigma_bar, want_xi_prev_bar=False, want_gradu_bar=False):
         torch = _torch()
         B = gradu.shape[1]

@@ -110,6 +110,19 @@ int cm_update(const cm_model_desc* m, int64_t B,
               double* xi, double* sigma, uint32_t* status, void* stream);
 
 /*
+ * cm_update_rate: the same update for the rate-form model (m->model_kind = CM_SMALL_RATE_ELASTIC_PLASTIC), whose
+ * unknown is the material Cauchy stress and whose residual needs the previous grad u as well.
+ * Replaces make_newton_solve / newton_solve on SmallRateElasticPlastic._residual_fn
+ * (cmad/models/small_rate_elastic_plastic.py:249-346) followed by its _cauchy_fn (:351-359).
+ *   in : gradu[n_gradu][B], gradu_prev[n_gradu][B], xi_prev[n_xi][B] (xi = [sigma(6), alpha (, F33)])
+ *   out: xi[n_xi][B], sigma[6][B] (global axes, may be NULL), status[B] (may be NULL)
+ * Sensitivity entry points for the rate form are not built yet (they return CM_ERR_UNSUPPORTED).
+ */
+int cm_update_rate(const cm_model_desc* m, int64_t B,
+                   const double* gradu, const double* gradu_prev, const double* xi_prev,
+                   double* xi, double* sigma, uint32_t* status, void* stream);
+
+/*
  * cm_update_tangent: cm_update plus the IFT-consistent tangent d sigma / d gradu.
  * Replaces jacfwd through the custom_jvp rule (cmad/models/nonlinear_solver.py:158-171) as used by
  * GlobalResidual._for_model_coupled (cmad/global_residuals/global_residual.py:373-394).

@@ -78,3 +78,14 @@ def evaluate(desc, which, gradu, xi_prev, xi, nx):
     rc = L.hh_evaluate(C.byref(desc), C.c_int64(B), C.c_int(which), _p(gradu), _p(xi_prev), _p(xi), _p(Cc), _p(J), _p(s), _p(S))
     assert rc == 0
     return Cc, J.reshape(nx, ncols, B), s, S.reshape(6, ncols, B)
+
+
+def update_rate(desc, gradu, gradu_prev, xi_prev, nx):
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu, gradu_prev, xi_prev = c(gradu), c(gradu_prev), c(xi_prev)
+    B = gradu.shape[1]
+    xi = np.zeros((nx, B)); sig = np.zeros((6, B)); st = np.zeros(B, dtype=np.uint32)
+    rc = L.hh_update_rate(C.byref(desc), C.c_int64(B), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi), _p(sig), _p(st))
+    assert rc == 0
+    return xi, sig, st

@@ -90,6 +90,24 @@ static void run_evaluate(const cm_model_desc& m, int64_t B, int which, const dou
     }
 }
 
+template <int DEF, int YK, bool ROT>
+static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev,
+                            const double* xi_prev, double* xi, double* sigma, uint32_t* status) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    for (int64_t b = 0; b < B; ++b) {
+        double G[NU], xp[NX], x[NX], deg[6], z[6], sg[6];
+        for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
+        for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
+        strain_from_gradu<DEF, ROT>(m, G, deg);
+        strain_z<ROT>(m, z);
+        uint32_t st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC>(m, deg, z, xp, x, true);
+        to_global<ROT>(m, x, sg);
+        for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
+        for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
+        status[b] = st;
+    }
+}
+
 template <class F>
 static int dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity;
@@ -115,6 +133,10 @@ int hh_update(const cm_model_desc* m, int64_t B, const double* gradu, const doub
 int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
            const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_vjp<D, Y, R>(*m, B, gradu, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
+}
+int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
+                   double* xi, double* sigma, uint32_t* status) {
+    return dispatch(m, [&]<int D, int Y, bool R>() { run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
 }
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {

@@ -239,3 +239,34 @@ def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False):
     for path in param_paths("J2"):
         np.testing.assert_allclose(kp_to_leaf_grad(path, g_d, sc.info), g_o[sc.mat.param_index(path)], rtol=1e-8,
                                    atol=1e-10 * np.abs(g_o).max())
+
+
+def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed=22):
+    """small_rate_elastic_plastic on the device path vs the oracle: three load steps (the residual needs the
+    previous grad u), state = [sigma(6), alpha (, F33)].  `update_rate(desc, info, gradu, gradu_prev, xi_prev)`."""
+    from cmad_amd.models.device import build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+    rng = np.random.default_rng(seed)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+    nd = 3 if def_type == ol.FULL_3D else 2
+    st_o, st_d = settings_pair(ls)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d)
+    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
+    g_prev = np.zeros_like(g0)
+    xp = np.tile(mat.init_xi()[:, None], (1, B))
+    plastic_seen = 0.0
+    for step, scale in enumerate((0.6, 1.0, 1.5)):
+        g = scale * g0
+        xi_o, sig_o, it_o, cv_o = mat.update_batch(st_o, g, xp, gradu_prev=g_prev)
+        xi_d, sig_d, status = update_rate(desc, info, g, g_prev, xp)
+        status = status.astype(np.uint32)
+        assert cv_o.all() and ((status >> 16) & 1).all()
+        # stresses ~1e2 with 1/2mu-scaled residual tolerance 1e-14 -> ~1e-9 absolute
+        np.testing.assert_allclose(xi_d[:6], xi_o[:6], rtol=1e-10, atol=1e-7)
+        np.testing.assert_allclose(xi_d[6:], xi_o[6:], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(sig_d, sig_o, rtol=1e-10, atol=1e-7)
+        assert np.abs((status & 0xFFFF).astype(int) - it_o).max() <= 1
+        plastic_seen = max(plastic_seen, (it_o > 0).mean())
+        xp, g_prev = xi_o, g
+    assert plastic_seen > 0.2

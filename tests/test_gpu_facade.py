@@ -208,3 +208,28 @@ def test_facade_error_behaviour():
         m.Jac()                                         # DNONE mode, reference model.py:303-314
     with pytest.raises(AssertionError):
         m.dSigma()
+
+
+@pytest.mark.parametrize("def_name", ["FULL_3D", "PLANE_STRESS"])
+def test_rate_model_reproduces_analytical_fields(golden_dir, def_name):
+    """`small rate` leg of tests/models/test_elastic_plastic_models.py:15-125 through the facade."""
+    from cmad_amd.models import DefType, SmallRateElasticPlastic, mp_U_from_F, newton_solve
+    def_type = getattr(DefType, def_name)
+    nd = 3 if def_type == DefType.FULL_3D else 2
+    g = np.load(os.path.join(golden_dir, "j2_voce_analytical.npz"))
+    for name in ("uniaxial", "biaxial"):
+        stress, strain, alpha = g[f"{name}_stress"], g[f"{name}_strain"], g[f"{name}_alpha"]
+        F = np.repeat(np.eye(nd)[:, :, None], 101, axis=2)
+        F[:, :, 1:] += strain[:nd, :nd, :]
+        model = SmallRateElasticPlastic(params_J2_voce(), def_type)
+        cauchy = np.zeros((3, 3, 101)); alphas = []
+        model.set_xi_to_init_vals()
+        for step in range(1, 101):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            newton_solve(model)
+            alphas.append(model.xi()[1][0])
+            model.evaluate_cauchy()
+            cauchy[:, :, step] = model.Sigma().copy()
+            model.advance_xi()
+        assert np.linalg.norm(np.array(alphas) - alpha) < 1e-6
+        assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6

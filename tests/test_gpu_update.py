@@ -100,3 +100,18 @@ def test_hybrid_through_the_facade():
     np.testing.assert_allclose(xi.cpu().numpy()[:, ok], xi_o[:, ok], rtol=1e-9, atol=1e-12)
     with pytest.raises(NotImplementedError):
         SmallElasticPlastic(Parameters(values), DefType.FULL_3D, effective_stress_fun=lambda c, p: 0.0)
+
+
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_model_update(def_type, yield_kind, kw, ls):
+    """small_rate_elastic_plastic (cm_update_rate) vs the oracle, three load steps."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator
+
+    def run(desc, info, g, gp, xp):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        out = DeviceEvaluator(desc, info).update_rate(t(g), t(gp), t(xp))
+        return out[0].cpu().numpy(), out[1].cpu().numpy(), out[2].cpu().numpy().astype(np.uint32)
+    pc.check_rate_model(run, def_type, yield_kind, kw, True, ls, B=2048)

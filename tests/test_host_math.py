@@ -15,7 +15,7 @@ def solver_variant(request):
     always dense)."""
     import host_harness_lib as hh
     hh.set_dense(request.param == "dense")
-    yield
+    yield request.param
     hh.set_dense(False)
 
 
@@ -93,3 +93,15 @@ def test_hosford_a100_notch_material():
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_hybrid_hill_icnn(def_type, rot):
     pc.check_hybrid_nn(BACKEND, def_type, B=192, rot=rot)
+
+
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_model_update(def_type, yield_kind, kw, rot, ls, solver_variant):
+    import host_harness_lib as hh
+    if hh.lib() and solver_variant == "dense":
+        pytest.skip("rate form always uses the dense path")
+    pc.check_rate_model(lambda desc, info, g, gp, xp: hh.update_rate(desc, g, gp, xp, desc.def_type == 2 and 8 or 7),
+                        def_type, yield_kind, kw, rot, ls, B=256)
