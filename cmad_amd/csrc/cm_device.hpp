@@ -619,7 +619,7 @@ CM_D double quad_min(double phi0, double dphi0, double a, double phi) {
 // (:14-85, ls_max_evals == 0).  One point per lane; wave-level ballots (__any) drive the loops so an
 // all-elastic / all-converged wavefront leaves at once and the rest iterate under the exec mask.
 // Returns the status word.
-template <int DEF, int YK, int MK = CM_SMALL_ELASTIC_PLASTIC>
+template <int DEF, int YK, int MK, bool LS>
 CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x,
                      bool lane_valid) {
     constexpr int NX = Dims<DEF>::NX;
@@ -649,7 +649,7 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
 #pragma unroll
             for (int k = 0; k < NX; ++k) delta[k] = C[k];
             lu_subst<NX>(A, delta);
-            if (m.ls_max_evals <= 0) {
+            if constexpr (!LS) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k) x[k] -= delta[k];
                 residual_mk<MK, DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);

@@ -130,12 +130,25 @@ struct PlasticOp {
     bool plastic, ok;
 };
 
+// J2: A3 = 3/2 I - 1/2 1 1^T and a11 = a22 = a44 = 3, so B = a I - c (1 1^T on the normal block) with
+// a = 1 + 3/2 beta rho, c = 1/2 beta rho, and B^-1 v = (v + c (v0+v3+v5) d) / a   (Sherman-Morrison, a - 3c = 1).
+// Stored as inv3[0] = 1/a, inv3[1] = c.
 template <int YK>
 CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOp& op) {
     const YieldS<YK>& y = ev.y;
     op.plastic = ev.plastic;
     op.beta = 2.0 * m.mu * ev.dgam;
     const double b = op.beta;
+    if constexpr (YK == CM_YIELD_J2) {
+        const double br = b * y.rho;
+        const double a = 1.0 + 1.5 * br;
+        op.ok = fabs(a) > 1e-300;
+        op.inv3[0] = rcp(a); op.inv3[1] = 0.5 * br;
+        op.eta = br;
+        op.j66 = -ev.hd.dH * 0.5 / m.mu;
+        op.k = 1.0 + op.j66 * op.eta;
+        return;
+    }
     double S[6], t[3];
     yield_blocks<YK>(m, y, S, t);
     const double B00 = 1.0 + b * S[0], B03 = b * S[1], B05 = b * S[2];
@@ -154,7 +167,14 @@ CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOp& op) {
     op.k = 1.0 + op.j66 * op.eta;
 }
 
+template <int YK>
 CM_D void binv(const PlasticOp& op, const double v[6], double out[6]) {
+    if constexpr (YK == CM_YIELD_J2) {
+        const double ia = op.inv3[0], cs = op.inv3[1] * (v[0] + v[3] + v[5]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = ia * (v[k] + (kDiag[k] ? cs : 0.0));
+        return;
+    }
     out[0] = op.inv3[0] * v[0] + op.inv3[1] * v[3] + op.inv3[2] * v[5];
     out[3] = op.inv3[1] * v[0] + op.inv3[3] * v[3] + op.inv3[4] * v[5];
     out[5] = op.inv3[2] * v[0] + op.inv3[4] * v[3] + op.inv3[5] * v[5];
@@ -174,8 +194,8 @@ CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, do
     for (int k = 0; k < 6; ++k) n[k] = y.gt[k] * kIW[k];
     const double* col = TRANSPOSED ? y.gt : n;      // the vector multiplying tau
     const double* row = TRANSPOSED ? n : y.gt;      // the vector contracted with x_v
-    binv(op, b, p);
-    binv(op, col, q);
+    binv<YK>(op, b, p);
+    binv<YK>(op, col, q);
     const double rp = dot<6>(row, p), rq = dot<6>(row, q);
     const double tau = (b[6] + op.k * rp) * rcp(op.j66 - op.k * rq);
     const double s = rp + rq * tau;
@@ -185,10 +205,13 @@ CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, do
 }
 
 // ---- local Newton, structured (same control flow as cm::newton) -----------------------------------------
-template <int YK>
-CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid) {
+// `ev` is left holding the evaluation at the returned x (the one that passed the convergence test), so the
+// reverse sweep of the fused kernels does not have to redo it.
+// LS: the line-search branch is a compile-time variant (it roughly doubles the live registers of the loop).
+template <int YK, bool LS>
+CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
+                       EvalS<YK>& ev) {
     constexpr int NX = 7;
-    EvalS<YK> ev;
     double C[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) x[k] = xp[k];
@@ -210,7 +233,7 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
             op_build<YK>(m, ev, op);               // ev is the evaluation at the current x (carried)
             if (!op.ok) flags |= CM_STATUS_SINGULAR;
             op_solve<false>(op, ev.y, C, delta);
-            if (m.ls_max_evals <= 0) {
+            if constexpr (!LS) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k) x[k] -= delta[k];
                 residual_s<YK>(m, eg, x, xp, ev, C);
@@ -263,12 +286,14 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
 }
 
 // ---- reverse sweep, structured (same contract as cm::reverse_point, DEF = FULL_3D) ---------------------------
-template <int YK>
+template <int YK, bool HAVE_EV = false>
 CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp,
-                          const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar) {
-    EvalS<YK> ev;
+                          const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar,
+                          EvalS<YK>* evp = nullptr) {
+    EvalS<YK> evl;
     double C[7], lam[7];
-    residual_s<YK>(m, eg, x, xp, ev, C);
+    if constexpr (!HAVE_EV) residual_s<YK>(m, eg, x, xp, evl, C);
+    const EvalS<YK>& ev = HAVE_EV ? *evp : evl;
     PlasticOp op;
     op_build<YK>(m, ev, op);
     double csb[6];
@@ -365,10 +390,13 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
 }
 
 // ---- front doors: structured for FULL_3D, dense otherwise (STRUCT = false forces the dense path) ------------
-template <int DEF, int YK, bool STRUCT = true>
+template <int DEF, int YK, bool LS, bool STRUCT = true>
 CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid) {
-    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) return newton_s<YK>(m, eg, xp, x, valid);
-    else return newton<DEF, YK>(m, eg, z, xp, x, valid);
+    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) {
+        EvalS<YK> ev;
+        return newton_s<YK, LS>(m, eg, xp, x, valid, ev);
+    }
+    else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, valid);
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,

@@ -2,6 +2,7 @@
 // gfx950 only.  One Gauss point per lane; SoA arrays so that lane b of a wavefront reads
 // element [k*B + b] -> every global access is a 512-byte contiguous row per wave instruction.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "cm_structured.hpp"
 
 namespace {
@@ -26,7 +27,7 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 }
 
 // ---- cm_update / cm_update_tangent ----------------------------------------------------------------
-template <int DEF, int YK, bool ROT, bool TANGENT>
+template <int DEF, int YK, bool ROT, bool LS, bool TANGENT>
 __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
     load_soa<NX>(xi_prev, B, b, xp);
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<ROT>(m, z);
-    uint32_t st = newton_any<DEF, YK>(m, eg, z, xp, x, valid);
+    uint32_t st = newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
     Eval<DEF> ev;
     strain_stress<DEF>(m, eg, z, x, ev);
     if (status) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
 }
 
 // ---- cm_update_rate: rate-form model (small_rate_elastic_plastic) ------------------------------------------
-template <int DEF, int YK, bool ROT>
+template <int DEF, int YK, bool ROT, bool LS>
 __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
     for (int k = 0; k < NU; ++k) G[k] -= Gp[k];                  // eps - eps_prev is linear in grad u
     strain_from_gradu<DEF, ROT>(m, G, deg);
     strain_z<ROT>(m, z);
-    uint32_t st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC>(m, deg, z, xp, x, valid);
+    uint32_t st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
     double sg[6];
     to_global<ROT>(m, x, sg);                                    // small_rate_elastic_plastic.py:351-359
     if (status) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_stage2(const double* __restri
 // MODE 3: fused update + vjp for a given sigma_bar (xi and sigma computed and stored here)
 struct Wsq { double w[6]; };
 
-template <int DEF, int YK, bool ROT, int MODE>
+template <int DEF, int YK, bool ROT, bool LS, int MODE>
 __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi_in,
         const double* __restrict__ sbar_or_data, Wsq wsq, const double* __restrict__ hist_in,
@@ -238,8 +239,12 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
     if constexpr (MODE == 0 || MODE == 2) load_soa<6>(sbar_or_data, B, b, sd);
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<ROT>(m, z);
+    // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
+    constexpr bool SFAST = (DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN && (MODE == 1 || MODE == 3));
+    EvalS<SFAST ? YK : CM_YIELD_J2> evs;
     if constexpr (MODE == 1 || MODE == 3) {
-        newton_any<DEF, YK>(m, eg, z, xp, x, valid);
+        if constexpr (SFAST) newton_s<YK, LS>(m, eg, xp, x, valid, evs);
+        else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
@@ -289,8 +294,9 @@ __global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
     // arrays are always passed (never a run-time null): a nullable local array would be forced into scratch
     // (MODE 1 / 3 have no per-point cotangent outputs at all: compile-time nulls let the compiler drop that work)
     constexpr bool BARS = (MODE == 0 || MODE == 2);
-    reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
-                         BARS ? egbar : nullptr);
+    if constexpr (SFAST) reverse_point_s<YK, true>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs);
+    else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
+                              BARS ? egbar : nullptr);
     if (BARS && xpbar_out && valid) {
         if constexpr (MODE == 2) {
 #pragma unroll
@@ -356,9 +362,12 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
 // returns false when no specialisation exists (the caller reports CM_ERR_UNSUPPORTED -- never a silent no-op)
 template <class F>
 inline bool dispatch(const cm_model_desc* m, F&& f) {
-    const bool rot = !m->rotation_is_identity;
+    const bool rot = !m->rotation_is_identity, ls = m->ls_max_evals > 0;
 #define CM_CASE(D, Y) \
-    if (m->def_type == D && m->yield_kind == Y) { if (rot) f.template operator()<D, Y, true>(); else f.template operator()<D, Y, false>(); return true; }
+    if (m->def_type == D && m->yield_kind == Y) { \
+        if (rot) { if (ls) f.template operator()<D, Y, true, true>(); else f.template operator()<D, Y, true, false>(); } \
+        else { if (ls) f.template operator()<D, Y, false, true>(); else f.template operator()<D, Y, false, false>(); } \
+        return true; }
     CM_CASE(CM_FULL_3D, CM_YIELD_J2)
     CM_CASE(CM_FULL_3D, CM_YIELD_HILL)
     CM_CASE(CM_FULL_3D, CM_YIELD_HOSFORD)
@@ -389,8 +398,8 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
-    const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
-        hipLaunchKernelGGL((k_update<D, Y, R, TANGENT>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
+    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+        hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
@@ -415,8 +424,10 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
-        const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
-            hipLaunchKernelGGL((k_reverse<D, Y, R, MODE>), grid, block, 0, s, md, B, gradu, xi_prev, xi_in, sd, w,
+        // CM_DEBUG_DYN_LDS=<bytes>: occupancy experiments only (extra dynamic LDS per block limits blocks per CU)
+        static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+        const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+            hipLaunchKernelGGL((k_reverse<D, Y, R, (MODE == 1 || MODE == 3) ? LS : false, MODE>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                hist_in, xi_out, sigma_out, xpbar, gbar, partials);
         });
         if (!found) return CM_ERR_UNSUPPORTED;
@@ -472,8 +483,8 @@ int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();
-    const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
-        hipLaunchKernelGGL((k_update_rate<D, Y, R>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma, status);
+    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+        hipLaunchKernelGGL((k_update_rate<D, Y, R, LS>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
@@ -527,7 +538,7 @@ int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
     (void)hipGetLastError();
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    const bool found = dispatch(m, [&]<int D, int Y, bool R>() {
+    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
         hipLaunchKernelGGL((k_evaluate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, xi_prev, xi, C, jac, sigma, dsigma);
     });
     if (!found) return CM_ERR_UNSUPPORTED;

@@ -21,7 +21,9 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, eg);
         strain_z<ROT>(m, z);
-        uint32_t st = g_dense ? newton_any<DEF, YK, false>(m, eg, z, xp, x, true) : newton_any<DEF, YK, true>(m, eg, z, xp, x, true);
+        const bool ls = m.ls_max_evals > 0;
+        uint32_t st = g_dense ? (ls ? newton_any<DEF, YK, true, false>(m, eg, z, xp, x, true) : newton_any<DEF, YK, false, false>(m, eg, z, xp, x, true))
+                              : (ls ? newton_any<DEF, YK, true, true>(m, eg, z, xp, x, true) : newton_any<DEF, YK, false, true>(m, eg, z, xp, x, true));
         Eval<DEF> ev;
         strain_stress<DEF>(m, eg, z, x, ev);
         double sg[6];
@@ -100,7 +102,8 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, deg);
         strain_z<ROT>(m, z);
-        uint32_t st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC>(m, deg, z, xp, x, true);
+        uint32_t st = (m.ls_max_evals > 0) ? newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, true)
+                                           : newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, true);
         to_global<ROT>(m, x, sg);
         for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
         for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
