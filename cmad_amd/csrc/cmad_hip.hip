@@ -216,8 +216,13 @@ __global__ __launch_bounds__(kBlock) void k_reduce_stage2(const double* __restri
 // MODE 3: fused update + vjp for a given sigma_bar (xi and sigma computed and stored here)
 struct Wsq { double w[6]; };
 
+// minimum waves per SIMD requested from the register allocator: the J2 FULL_3D plain-Newton variants sit at
+// ~130 VGPRs, two above the 4-wave limit (128); every other variant is left unconstrained.
+template <int DEF, int YK, bool LS, int MODE>
+constexpr int min_waves() { return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1; }
+
 template <int DEF, int YK, bool ROT, bool LS, int MODE>
-__global__ __launch_bounds__(kBlock) void k_reverse(cm_model_desc m, int64_t B,
+__global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_reverse(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi_in,
         const double* __restrict__ sbar_or_data, Wsq wsq, const double* __restrict__ hist_in,
         double* __restrict__ xi_out, double* __restrict__ sigma_out, double* __restrict__ xpbar_out,
