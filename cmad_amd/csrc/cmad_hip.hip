@@ -197,14 +197,16 @@ __global__ __launch_bounds__(kBlock) void k_reduce_stage1(const double* __restri
     if (threadIdx.x < NV) stage[(int64_t)blockIdx.x * NV + threadIdx.x] = res[threadIdx.x];
 }
 
+// out[k - first] (+)= total[k] for k >= first (first = 1 drops the objective slot: the vjp entry points
+// return only the 12 gradient entries, written straight to the caller's array -- no device-to-device copy)
 template <int NV>
 __global__ __launch_bounds__(kBlock) void k_reduce_stage2(const double* __restrict__ stage, double* __restrict__ out,
-                                                          int out_offset, int accumulate) {
+                                                          int first, int accumulate) {
     __shared__ double res[NV];
     reduce_rows<NV>(stage, 0, kRedBlocks, res);
     __syncthreads();
-    if (threadIdx.x < NV) {
-        const int o = out_offset + threadIdx.x;
+    if ((int)threadIdx.x < NV && (int)threadIdx.x >= first) {
+        const int o = (int)threadIdx.x - first;
         out[o] = accumulate ? out[o] + res[threadIdx.x] : res[threadIdx.x];
     }
 }
@@ -505,14 +507,8 @@ int cm_update_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const 
                   void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p) return CM_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
-    // reduce into the workspace's result row {J=0, grad[12]}, then copy grad out on the stream
-    double* tail = (double*)((char*)workspace + cm_workspace_bytes(B)) - kRed;
-    int rc = launch_reverse<0>(m, B, gradu, xi_prev, xi, sigma_bar, nullptr, nullptr, nullptr, nullptr, xi_prev_bar,
-                               gradu_bar, tail, 0, 0, workspace, workspace_bytes, stream);
-    if (rc != CM_OK) return rc;
-    if (hipMemcpyAsync(grad_p, tail + 1, CM_NUM_PARAMS * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-        return CM_ERR_LAUNCH;
-    return CM_OK;
+    return launch_reverse<0>(m, B, gradu, xi_prev, xi, sigma_bar, nullptr, nullptr, nullptr, nullptr, xi_prev_bar,
+                             gradu_bar, grad_p, 1, 0, workspace, workspace_bytes, stream);
 }
 
 int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
@@ -520,13 +516,8 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
                       void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p || !xi) return CM_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
-    double* tail = (double*)((char*)workspace + cm_workspace_bytes(B)) - kRed;
-    int rc = launch_reverse<3>(m, B, gradu, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr, nullptr,
-                               tail, 0, 0, workspace, workspace_bytes, stream);
-    if (rc != CM_OK) return rc;
-    if (hipMemcpyAsync(grad_p, tail + 1, CM_NUM_PARAMS * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-        return CM_ERR_LAUNCH;
-    return CM_OK;
+    return launch_reverse<3>(m, B, gradu, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr, nullptr,
+                             grad_p, 1, 0, workspace, workspace_bytes, stream);
 }
 
 int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
