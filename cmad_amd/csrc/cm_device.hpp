@@ -44,8 +44,10 @@ constexpr double kW[6] = {1.0, 2.0, 2.0, 1.0, 2.0, 1.0};
 constexpr bool kDiag[6] = {true, false, false, true, false, true};
 
 template <int DEF> struct Dims;
-template <> struct Dims<CM_FULL_3D> { static constexpr int NX = 7, NU = 9, NE = 0; };
-template <> struct Dims<CM_PLANE_STRESS> { static constexpr int NX = 8, NU = 4, NE = 1; };
+// NZ: length of the per-kernel frame array `z` (see strain_z)
+template <> struct Dims<CM_FULL_3D> { static constexpr int NX = 7, NU = 9, NE = 0, NZ = 6; };
+template <> struct Dims<CM_PLANE_STRESS> { static constexpr int NX = 8, NU = 4, NE = 1, NZ = 6; };
+template <> struct Dims<CM_UNIAXIAL_STRESS> { static constexpr int NX = 9, NU = 1, NE = 2, NZ = 18; };
 
 // ---- symmetric 3x3 congruences on 6-vectors --------------------------------------------------
 // out = V(M^T T(a) M) (TRANSPOSE_FIRST) or V(M T(a) M^T)
@@ -75,10 +77,40 @@ CM_D void congruence(const double* M, const double a[6], double out[6]) {
 // total strain 6-vector in the material frame from grad u
 // (cmad/models/small_elastic_plastic.py:38-62, kinematics.py:10-26; the out-of-plane stretch of
 //  PLANE_STRESS enters separately through z, see strain_z)
+// UNIAXIAL_STRESS frame vectors: Z^i = V(q_i q_i^T), q_i = row i of Q, ordered [on-axis, first off-axis,
+// second off-axis] (cmad/models/kinematics.py:35-50,62-65).  With them the constrained kinematics of
+// small_elastic_plastic.py:47-60 (off-axis shear of the global total strain := that of the global plastic strain)
+// collapse to  e = sum_i Z^i (eps_i - (w o Z^i) . v): the global elastic strain is diagonal.
+template <bool ROT>
+CM_D void uniaxial_frame(const cm_model_desc& m, double z[18]) {
+    const int on = m.uniaxial_idx, a = (on == 0) ? 1 : 0, b = (on == 2) ? 1 : 2;
+    const int rows[3] = {on, a, b};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int i = rows[r];
+        double q0, q1, q2;
+        if constexpr (ROT) {
+            q0 = (i == 0) ? m.Q[0] : ((i == 1) ? m.Q[3] : m.Q[6]);
+            q1 = (i == 0) ? m.Q[1] : ((i == 1) ? m.Q[4] : m.Q[7]);
+            q2 = (i == 0) ? m.Q[2] : ((i == 1) ? m.Q[5] : m.Q[8]);
+        } else {
+            q0 = (i == 0) ? 1.0 : 0.0; q1 = (i == 1) ? 1.0 : 0.0; q2 = (i == 2) ? 1.0 : 0.0;
+        }
+        double* Z = z + 6 * r;
+        Z[0] = q0 * q0; Z[1] = q0 * q1; Z[2] = q0 * q2; Z[3] = q1 * q1; Z[4] = q1 * q2; Z[5] = q2 * q2;
+    }
+}
+
 template <int DEF, bool ROT>
 CM_D void strain_from_gradu(const cm_model_desc& m, const double* G, double eg[6]) {
     double E[6];
-    if constexpr (DEF == CM_FULL_3D) {
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        double z[18];
+        uniaxial_frame<ROT>(m, z);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) eg[k] = G[0] * z[k];       // on-axis strain along Z^on
+        return;
+    } else if constexpr (DEF == CM_FULL_3D) {
         E[0] = G[0]; E[1] = 0.5 * (G[1] + G[3]); E[2] = 0.5 * (G[2] + G[6]);
         E[3] = G[4]; E[4] = 0.5 * (G[5] + G[7]); E[5] = G[8];
     } else {
@@ -92,9 +124,11 @@ CM_D void strain_from_gradu(const cm_model_desc& m, const double* G, double eg[6
 }
 
 // PLANE_STRESS: d(material strain)/d F33 = V(Q^T e3 e3^T Q) = V(q3 q3^T), q3 = third row of Q
-template <bool ROT>
-CM_D void strain_z(const cm_model_desc& m, double z[6]) {
-    if constexpr (ROT) {
+template <int DEF, bool ROT>
+CM_D void strain_z(const cm_model_desc& m, double* z /* Dims<DEF>::NZ */) {
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        uniaxial_frame<ROT>(m, z);
+    } else if constexpr (ROT) {
         const double a = m.Q[6], b = m.Q[7], c = m.Q[8];
         z[0] = a * a; z[1] = a * b; z[2] = a * c; z[3] = b * b; z[4] = b * c; z[5] = c * c;
     } else {
@@ -329,6 +363,13 @@ CM_D Hard hardening(const cm_model_desc& m, double alpha) {
     return h;
 }
 
+// Cel a = 2 mu a + lambda (a0+a3+a5) d
+CM_D void apply_cel(const cm_model_desc& m, const double a[6], double out[6]) {
+    const double t = m.lambda * (a[0] + a[3] + a[5]), twomu = 2.0 * m.mu;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] = twomu * a[k] + (kDiag[k] ? t : 0.0);
+}
+
 // ---- state evaluation ----------------------------------------------------------------------
 // Everything the residual and its derivatives need at one iterate.
 template <int DEF>
@@ -345,11 +386,25 @@ struct Eval {
 // e = eg (+ (F33-1) z) - v ; s = lambda tr(e) d + 2 mu e   (elastic_stress.py:14-21)
 template <int DEF>
 CM_D void strain_stress(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, Eval<DEF>& ev) {
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        // e = eg + (x7 - 1) Z^a + (x8 - 1) Z^b - Pi v,  Pi v = sum_i Z^i ((w o Z^i) . v)
+        double t[3] = {0.0, x[7] - 1.0, x[8] - 1.0};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        double e = eg[k] - x[k];
-        if constexpr (DEF == CM_PLANE_STRESS) e += (x[7] - 1.0) * z[k];
-        ev.e[k] = e;
+        for (int i = 0; i < 3; ++i) {
+            double pv = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pv += kW[k] * z[6 * i + k] * x[k];
+            t[i] -= pv;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ev.e[k] = eg[k] + t[0] * z[k] + t[1] * z[6 + k] + t[2] * z[12 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double e = eg[k] - x[k];
+            if constexpr (DEF == CM_PLANE_STRESS) e += (x[7] - 1.0) * z[k];
+            ev.e[k] = e;
+        }
     }
     ev.tr = ev.e[0] + ev.e[3] + ev.e[5];
     const double twomu = 2.0 * m.mu;
@@ -383,6 +438,13 @@ CM_D void residual(const cm_model_desc& m, const double eg[6], const double z[6]
         for (int k = 0; k < 6; ++k) r += kW[k] * z[k] * ev.s[k];
         C[NX - 1] = r * i2mu;
     }
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        // off-axis normal stresses (Q s Q^T)[a][a], [b][b] / 2mu  (small_elastic_plastic.py:291-297)
+        double ra = 0.0, rb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ra += kW[k] * z[6 + k] * ev.s[k]; rb += kW[k] * z[12 + k] * ev.s[k]; }
+        C[7] = ra * i2mu; C[8] = rb * i2mu;
+    }
 }
 
 // A = dC/dx at the evaluated state (needs Ht).  TRANSPOSED stores A^T (for adjoint solves).
@@ -396,6 +458,64 @@ CM_D void jacobian_x(const cm_model_desc& m, const double z[6], const Eval<DEF>&
     for (int r = 0; r < NX; ++r)
 #pragma unroll
         for (int c = 0; c < NX; ++c) CM_A(r, c) = (r == c) ? 1.0 : 0.0;
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        // d s / d v = -Cel Pi, d s / d x7 = Cel Z^a, d s / d x8 = Cel Z^b ; constraint rows (w o Z^c) . s / 2mu
+        double cz[2][6];
+        apply_cel(m, z + 6, cz[0]);
+        apply_cel(m, z + 12, cz[1]);
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            double pl[6], cp[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pl[k] = kW[l] * (z[k] * z[l] + z[6 + k] * z[6 + l] + z[12 + k] * z[12 + l]);   // Pi[:, l]
+            apply_cel(m, pl, cp);
+            double ra = 0.0, rb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { ra += kW[k] * z[6 + k] * cp[k]; rb += kW[k] * z[12 + k] * cp[k]; }
+            CM_A(7, l) = -ra * i2mu; CM_A(8, l) = -rb * i2mu;
+            if (ev.plastic) {
+                double gcp = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    double h = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) h += Ht[k][q] * cp[q];
+                    CM_A(k, l) += ev.dgam * kIW[k] * h;
+                    gcp += ev.gt[k] * cp[k];
+                }
+                CM_A(6, l) = -gcp * i2mu;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double ra = 0.0, rb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { ra += kW[k] * z[6 + k] * cz[j][k]; rb += kW[k] * z[12 + k] * cz[j][k]; }
+            CM_A(7, 7 + j) = ra * i2mu; CM_A(8, 7 + j) = rb * i2mu;
+            CM_A(7, 6) = 0.0; CM_A(8, 6) = 0.0;
+            if (ev.plastic) {
+                double gcz = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    double h = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) h += Ht[k][q] * cz[j][q];
+                    CM_A(k, 7 + j) = -ev.dgam * kIW[k] * h;
+                    gcz += ev.gt[k] * cz[j][k];
+                }
+                CM_A(6, 7 + j) = gcz * i2mu;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) CM_A(k, 7 + j) = 0.0;
+            }
+        }
+        if (ev.plastic) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) CM_A(k, 6) = -ev.gt[k] * kIW[k];
+            CM_A(6, 6) = -ev.hd.dH * i2mu;
+        }
+        return;
+    }
     if (ev.plastic) {
         double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
 #pragma unroll
@@ -720,13 +840,6 @@ CM_D void cotangent_to_material(const cm_model_desc& m, const double sb[6], doub
     }
 }
 
-// Cel a = 2 mu a + lambda (a0+a3+a5) d
-CM_D void apply_cel(const cm_model_desc& m, const double a[6], double out[6]) {
-    const double t = m.lambda * (a[0] + a[3] + a[5]), twomu = 2.0 * m.mu;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) out[k] = twomu * a[k] + (kDiag[k] ? t : 0.0);
-}
-
 // ---- reverse sweep at a converged state -------------------------------------------------------------
 // Given the cotangent sbar_m of the MATERIAL stress 6-vector and an incoming cotangent xin of xi
 // (NULL = 0), solve  lam = A^-T ( (d s/d x)^T sbar_m + xin )  and return
@@ -739,6 +852,7 @@ template <int DEF, int YK>
 CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double z[6],
                         const double* x, const double* xp, const double sbm[6], const double* xin,
                         double* pbar, double* xpbar, double* egbar) {
+    static_assert(DEF != CM_UNIAXIAL_STRESS, "batched reverse sweep not built for UNIAXIAL_STRESS (use cm_evaluate blocks)");
     constexpr int NX = Dims<DEF>::NX;
     Eval<DEF> ev;
     double C[NX], Ht[6][6], At[NX][NX], lam[NX];
@@ -844,6 +958,7 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
 template <int DEF, int YK>
 CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double z[6],
                         const double* x, const double* xp, double (&T)[6][6]) {
+    static_assert(DEF != CM_UNIAXIAL_STRESS, "batched tangent not built for UNIAXIAL_STRESS");
     constexpr int NX = Dims<DEF>::NX;
     Eval<DEF> ev;
     double C[NX], Ht[6][6], A[NX][NX];
@@ -892,10 +1007,10 @@ template <int DEF, int YK, bool ROT>
 CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double* x, const double* xp, int which,
                           double* C, double* J /* NX x ncols or null */, double* sg /* 6 */, double* S /* 6 x ncols or null */) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
-    double eg[6], z[6], Ht[6][6];
+    double eg[6], z[Dims<DEF>::NZ], Ht[6][6];
     Eval<DEF> ev;
     strain_from_gradu<DEF, ROT>(m, G, eg);
-    strain_z<ROT>(m, z);
+    strain_z<DEF, ROT>(m, z);
     residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
     to_global<ROT>(m, ev.s, sg);
     const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
@@ -915,12 +1030,19 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
         if (J) for (int r = 0; r < NX; ++r) for (int c = 0; c < NX; ++c) J[r * NX + c] = A[r][c];
         for (int c = 0; c < 6; ++c) {
             double de[6] = {0, 0, 0, 0, 0, 0}, ds[6];
-            de[c] = -1.0;
+            if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+                for (int k = 0; k < 6; ++k) de[k] = -kW[c] * (z[k] * z[c] + z[6 + k] * z[6 + c] + z[12 + k] * z[12 + c]);   // -Pi[:, c]
+            } else de[c] = -1.0;
             apply_cel(m, de, ds);
             put_S(c, ds);
         }
         put_S(6, zero6);
         if constexpr (DEF == CM_PLANE_STRESS) { double ds[6]; apply_cel(m, z, ds); put_S(7, ds); }
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+            double ds[6];
+            apply_cel(m, z + 6, ds); put_S(7, ds);
+            apply_cel(m, z + 12, ds); put_S(8, ds);
+        }
     } else if (which == CM_W_XI_PREV) {
         if (J) {
             for (int r = 0; r < NX; ++r) for (int c = 0; c < NX; ++c) J[r * NX + c] = 0.0;
@@ -981,6 +1103,18 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
                 J[7 * NP_ + CM_P_MU] = 2.0 * zwe * i2mu - C[7] / m.mu;
             }
         }
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+            if (J) {
+                for (int j = 0; j < 2; ++j) {
+                    const double* Z = z + 6 * (1 + j);
+                    const double zt = Z[0] + Z[3] + Z[5];
+                    double zwe = 0.0;
+                    for (int k = 0; k < 6; ++k) zwe += kW[k] * Z[k] * ev.e[k];
+                    J[(7 + j) * NP_ + CM_P_LAMBDA] = zt * ev.tr * i2mu;
+                    J[(7 + j) * NP_ + CM_P_MU] = 2.0 * zwe * i2mu - C[7 + j] / m.mu;
+                }
+            }
+        }
         for (int c = 0; c < NP_; ++c) {
             double ds[6] = {0, 0, 0, 0, 0, 0};
             if (c == CM_P_LAMBDA) for (int k = 0; k < 6; ++k) ds[k] = dvec[k] * ev.tr;
@@ -1005,6 +1139,11 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
                     double r = 0.0;
                     for (int k = 0; k < 6; ++k) r += kW[k] * z[k] * cd[k];
                     J[7 * NU + c] = r * i2mu;
+                }
+                if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+                    double ra = 0.0, rb = 0.0;
+                    for (int k = 0; k < 6; ++k) { ra += kW[k] * z[6 + k] * cd[k]; rb += kW[k] * z[12 + k] * cd[k]; }
+                    J[7 * NU + c] = ra * i2mu; J[8 * NU + c] = rb * i2mu;
                 }
             }
         }

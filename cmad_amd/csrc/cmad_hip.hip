@@ -39,11 +39,11 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
     if (sigma) sigma += blk0;
     if (status) status += blk0;
     if (dsig) dsig += blk0;
-    double G[NU], xp[NX], x[NX], eg[6], z[6];
+    double G[NU], xp[NX], x[NX], eg[6], z[Dims<DEF>::NZ];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
     strain_from_gradu<DEF, ROT>(m, G, eg);
-    strain_z<ROT>(m, z);
+    strain_z<DEF, ROT>(m, z);
     uint32_t st = newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
     Eval<DEF> ev;
     strain_stress<DEF>(m, eg, z, x, ev);
@@ -100,14 +100,14 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
     gradu += blk0; gradu_prev += blk0; xi_prev += blk0; xi += blk0;
     if (sigma) sigma += blk0;
     if (status) status += blk0;
-    double G[NU], Gp[NU], xp[NX], x[NX], deg[6], z[6];
+    double G[NU], Gp[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NU>(gradu_prev, B, b, Gp);
     load_soa<NX>(xi_prev, B, b, xp);
 #pragma unroll
     for (int k = 0; k < NU; ++k) G[k] -= Gp[k];                  // eps - eps_prev is linear in grad u
     strain_from_gradu<DEF, ROT>(m, G, deg);
-    strain_z<ROT>(m, z);
+    strain_z<DEF, ROT>(m, z);
     uint32_t st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
     double sg[6];
     to_global<ROT>(m, x, sg);                                    // small_rate_elastic_plastic.py:351-359
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     if (sigma_out) sigma_out += blk0;
     if (xpbar_out) xpbar_out += blk0;
     if (gbar_out) gbar_out += blk0;
-    double G[NU], xp[NX], x[NX], eg[6], z[6], sd[6];
+    double G[NU], xp[NX], x[NX], eg[6], z[Dims<DEF>::NZ], sd[6];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
     if constexpr (MODE == 0 || MODE == 2) load_soa<6>(sbar_or_data, B, b, sd);
     strain_from_gradu<DEF, ROT>(m, G, eg);
-    strain_z<ROT>(m, z);
+    strain_z<DEF, ROT>(m, z);
     // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
     constexpr bool SFAST = (DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN && (MODE == 1 || MODE == 3));
     EvalS<SFAST ? YK : CM_YIELD_J2> evs;
@@ -357,7 +357,8 @@ inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 
 inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_PLASTIC) {
     if (m->model_kind != model_kind) return false;
-    if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS) return false;
+    if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS && m->def_type != CM_UNIAXIAL_STRESS) return false;
+    if (m->def_type == CM_UNIAXIAL_STRESS && (m->uniaxial_idx < 0 || m->uniaxial_idx > 2)) return false;
     if (m->yield_kind == CM_YIELD_HYBRID_HILL_NN)      // one hidden layer [6, H, 1], weights resident on the device
         return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
                m->nn_widths[1] >= 1 && m->nn_widths[1] <= 256;
@@ -367,7 +368,8 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
 
 // calls F.template operator()<DEF, YK, ROT>() for the runtime (def_type, yield_kind, rotation) triple
 // returns false when no specialisation exists (the caller reports CM_ERR_UNSUPPORTED -- never a silent no-op)
-template <class F>
+// UNIAXIAL_STRESS is built for cm_update and cm_evaluate only (`uni` = the caller has those specialisations)
+template <bool UNI = false, class F>
 inline bool dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity, ls = m->ls_max_evals > 0;
 #define CM_CASE(D, Y) \
@@ -383,6 +385,11 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
     CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
+    if constexpr (UNI) {
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_J2)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)
+    }
 #undef CM_CASE
     return false;
 }
@@ -405,7 +412,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
-    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<!TANGENT>(m, [&]<int D, int Y, bool R, bool LS>() {
         hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -534,7 +541,7 @@ int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
     (void)hipGetLastError();
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
         hipLaunchKernelGGL((k_evaluate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, xi_prev, xi, C, jac, sigma, dsigma);
     });
     if (!found) return CM_ERR_UNSUPPORTED;

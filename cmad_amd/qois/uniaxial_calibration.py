@@ -1,0 +1,66 @@
+"""`UniaxialCalibration` QoI: compares [sigma_aa, stretch_1 - 1, stretch_2 - 1] with data, per-step weights.
+Host mirror of /root/reference/cmad/qois/uniaxial_calibration.py:21-85."""
+from __future__ import annotations
+
+import numpy as np
+
+from ..models.deriv_types import DerivType
+from .qoi import QoI
+
+
+class UniaxialCalibration(QoI):
+    registry_name = "uniaxial_calibration"
+
+    def __init__(self, model, data, weight, uniaxial_stress_idx: int, stretch_var_idx: int) -> None:
+        self._model = model
+        assert data.shape == weight.shape
+        self._data, self._weight = data, weight
+        self._idx, self._svar = int(uniaxial_stress_idx), int(stretch_var_idx)
+        self._J = None
+        self._dJ = None
+
+    @classmethod
+    def from_deck(cls, qoi_section, model, data, weight) -> "UniaxialCalibration":
+        return cls(model=model, data=data, weight=weight, uniaxial_stress_idx=qoi_section["uniaxial_stress_idx"],
+                   stretch_var_idx=qoi_section["stretch_var_idx"])
+
+    def update_data(self, data) -> None:
+        assert data.shape == self._data.shape
+        self._data = data
+
+    def data_at_step(self, step):
+        return self._data[..., step]
+
+    def weight_at_step(self, step):
+        return self._weight[:, step]
+
+    def evaluate(self, step) -> None:
+        """reference qoi.py:80-110 with `_qoi` of uniaxial_calibration.py:70-85."""
+        model = self._model
+        mode = model.deriv_mode()
+        d, w = self.data_at_step(step), self.weight_at_step(step)
+        a = self._idx
+        model.seed_none()
+        model.evaluate_cauchy()
+        stretches = np.asarray(model.xi()[self._svar], dtype=float)
+        pred = np.r_[model.Sigma()[a, a], stretches[0] - 1., stretches[1] - 1.]
+        mismatch = (pred - d) * w
+        model._deriv_mode = mode
+        if mode == DerivType.DNONE:
+            self._J = np.asarray(0.5 * np.sum(mismatch * mismatch), dtype=model.dtype)
+            self._dJ = None
+            return
+        if mode == DerivType.DU_PREV:
+            self._dJ = np.zeros((1, model.ndims ** 2))
+            return
+        model.evaluate_cauchy()
+        ds = model.dSigma()
+        if mode == DerivType.DPARAMS:
+            ds = ds.reshape(3, 3, -1)
+        dpred = np.zeros((3, ds.shape[-1]))
+        dpred[0] = ds[a, a]
+        if mode == DerivType.DXI:                               # the stretches are state variables
+            off = model.delta_xi_offset(self._svar, 0)
+            dpred[1, off] = 1.0
+            dpred[2, off + 1] = 1.0
+        self._dJ = np.atleast_2d((mismatch * w) @ dpred)

@@ -16,11 +16,11 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
                        double* xi, double* sigma, uint32_t* status, double* dsig) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
     for (int64_t b = 0; b < B; ++b) {
-        double G[NU], xp[NX], x[NX], eg[6], z[6];
+        double G[NU], xp[NX], x[NX], eg[6], z[Dims<DEF>::NZ];
         for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b];
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, eg);
-        strain_z<ROT>(m, z);
+        strain_z<DEF, ROT>(m, z);
         const bool ls = m.ls_max_evals > 0;
         uint32_t st = g_dense ? (ls ? newton_any<DEF, YK, true, false>(m, eg, z, xp, x, true) : newton_any<DEF, YK, false, false>(m, eg, z, xp, x, true))
                               : (ls ? newton_any<DEF, YK, true, true>(m, eg, z, xp, x, true) : newton_any<DEF, YK, false, true>(m, eg, z, xp, x, true));
@@ -31,7 +31,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
         if (sigma) for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
         if (status) status[b] = st;
-        if (dsig) {
+        if constexpr (DEF != CM_UNIAXIAL_STRESS) if (dsig) {
             double T[6][6];
             if (g_dense) tangent_any<DEF, YK, false>(m, eg, z, x, xp, T); else tangent_any<DEF, YK, true>(m, eg, z, x, xp, T);
             for (int c = 0; c < NU; ++c) {
@@ -53,12 +53,12 @@ static void run_vjp(const cm_model_desc& m, int64_t B, const double* gradu, cons
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
     for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] = 0.0;
     for (int64_t b = 0; b < B; ++b) {
-        double G[NU], xp[NX], x[NX], eg[6], z[6], sb[6], sbm[6], pb[CM_NUM_PARAMS], xb[NX], eb[6], xi_in[NX];
+        double G[NU], xp[NX], x[NX], eg[6], z[Dims<DEF>::NZ], sb[6], sbm[6], pb[CM_NUM_PARAMS], xb[NX], eb[6], xi_in[NX];
         for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b];
         for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; if (xin) xi_in[k] = xin[k * B + b]; }
         for (int k = 0; k < 6; ++k) sb[k] = sbar[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, eg);
-        strain_z<ROT>(m, z);
+        strain_z<DEF, ROT>(m, z);
         cotangent_to_material<ROT>(m, sb, sbm);
         if (g_dense) reverse_any<DEF, YK, false>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
         else reverse_any<DEF, YK, true>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
@@ -97,11 +97,11 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
                             const double* xi_prev, double* xi, double* sigma, uint32_t* status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
     for (int64_t b = 0; b < B; ++b) {
-        double G[NU], xp[NX], x[NX], deg[6], z[6], sg[6];
+        double G[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], sg[6];
         for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, deg);
-        strain_z<ROT>(m, z);
+        strain_z<DEF, ROT>(m, z);
         uint32_t st = (m.ls_max_evals > 0) ? newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, true)
                                            : newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, true);
         to_global<ROT>(m, x, sg);
@@ -111,7 +111,7 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
     }
 }
 
-template <class F>
+template <bool UNI = false, class F>
 static int dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity;
 #define CM_CASE(D, Y) \
@@ -124,6 +124,11 @@ static int dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
     CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
+    if constexpr (UNI) {
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_J2)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)
+    }
 #undef CM_CASE
     return -2;
 }
@@ -131,7 +136,7 @@ static int dispatch(const cm_model_desc* m, F&& f) {
 extern "C" {
 int hh_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
               double* xi, double* sigma, uint32_t* status, double* dsig) {
-    return dispatch(m, [&]<int D, int Y, bool R>() { run_update<D, Y, R>(*m, B, gradu, xi_prev, xi, sigma, status, dsig); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_update<D, Y, R>(*m, B, gradu, xi_prev, xi, sigma, status, dsig); });
 }
 int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
            const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
@@ -143,7 +148,7 @@ int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
 }
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {
-    return dispatch(m, [&]<int D, int Y, bool R>() { run_evaluate<D, Y, R>(*m, B, which, gradu, xi_prev, xi, C, J, s, S); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_evaluate<D, Y, R>(*m, B, which, gradu, xi_prev, xi, C, J, s, S); });
 }
 void hh_set_dense(int d) { g_dense = d; }
 int hh_sizeof_desc(void) { return (int)sizeof(cm_model_desc); }

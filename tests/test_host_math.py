@@ -105,3 +105,49 @@ def test_rate_model_update(def_type, yield_kind, kw, rot, ls, solver_variant):
         pytest.skip("rate form always uses the dense path")
     pc.check_rate_model(lambda desc, info, g, gp, xp: hh.update_rate(desc, g, gp, xp, desc.def_type == 2 and 8 or 7),
                         def_type, yield_kind, kw, rot, ls, B=256)
+
+
+@pytest.mark.parametrize("uidx", [0, 1, 2])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+def test_uniaxial_stress_update_and_blocks(yield_kind, kw, rot, uidx, solver_variant):
+    """UNIAXIAL_STRESS (n_xi = 9): 12-step uniaxial ramp through the device math vs the oracle, plus every
+    explicit derivative block at the visited states."""
+    import numpy as np
+    import host_harness_lib as hh
+    from cmad_amd.models.device import build_desc, kp_to_leaf_grad
+    if solver_variant == "dense":
+        pytest.skip("always dense")
+    rng = np.random.default_rng(8)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng) if rot else None, **kw)
+    mat = ol.Material(values, def_type=ol.UNIAXIAL_STRESS, uniaxial_idx=uidx)
+    desc, info = build_desc(values, def_type=ol.UNIAXIAL_STRESS, uniaxial_stress_idx=uidx)
+    B = 16
+    amp = rng.uniform(0.5, 1.5, B) * rng.choice([-1.0, 1.0], B)
+    xp = np.tile(mat.init_xi()[:, None], (1, B))
+    V6 = [0, 1, 2, 4, 5, 8]
+    for step in range(1, 13):
+        g = (amp * 4e-4 * step)[None, :]
+        xi_o, sig_o, it_o, cv = mat.update_batch(ol.newton_settings(), g, xp)
+        xi_h, sig_h, st = hh.update(desc, g, xp, 9)
+        assert cv.all() and ((st >> 16) & 1).all()
+        np.testing.assert_allclose(xi_h, xi_o, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(sig_h, sig_o, rtol=1e-10, atol=1e-8)
+        if step in (2, 6, 12):
+            for b in (0, 5):
+                for which_o, which_d in ((ol.W_XI, 0), (ol.W_XI_PREV, 1), (ol.W_U, 3)):
+                    C, J, s, S = hh.evaluate(desc, which_d, g[:, b:b + 1], xp[:, b:b + 1], xi_o[:, b:b + 1], 9)
+                    Jo = mat.jacobian(which_o, xi_o[:, b], xp[:, b], g[:, b])
+                    So = mat.dcauchy(which_o, xi_o[:, b], xp[:, b], g[:, b])[V6, :]
+                    np.testing.assert_allclose(J[:, :, 0], Jo, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+                    np.testing.assert_allclose(S[:, :, 0], So, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(So).max()))
+                C, J, s, S = hh.evaluate(desc, 2, g[:, b:b + 1], xp[:, b:b + 1], xi_o[:, b:b + 1], 9)
+                Jo = mat.jacobian(ol.W_PARAMS, xi_o[:, b], xp[:, b], g[:, b])
+                So = mat.dcauchy(ol.W_PARAMS, xi_o[:, b], xp[:, b], g[:, b])[V6, :]
+                for path in pc.param_paths(yield_kind):
+                    np.testing.assert_allclose(kp_to_leaf_grad(path, np.moveaxis(J[:, :, 0], 1, 0), info), Jo[:, mat.param_index(path)],
+                                               rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(Jo).max()), err_msg=str(path))
+                    np.testing.assert_allclose(kp_to_leaf_grad(path, np.moveaxis(S[:, :, 0], 1, 0), info), So[:, mat.param_index(path)],
+                                               rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(So).max()), err_msg=str(path))
+        xp = xi_o
+    assert (it_o > 0).any()
