@@ -95,7 +95,8 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    distributed = world > 1
+    # CMAD_BENCH_FORCE_DIST=1 exercises the process-group path with a single rank (rehearsal on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("CMAD_BENCH_FORCE_DIST") == "1"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

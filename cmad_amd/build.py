@@ -24,16 +24,37 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+NPARTS = 4          # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
+
+
+def build(force=False, verbose=False, jobs=None):
+    """hipcc --offload-arch=gfx950: the four parts of cmad_hip.hip are compiled concurrently, then linked."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    hipcc = hipcc_path()
+    src = os.path.join(CSRC, SOURCES[0])
+    objs = [os.path.join(CSRC, f"cmad_hip_part{k}.o") for k in range(NPARTS)]
+    cmds = [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-c", src, "-o", objs[k]]
+            for k in range(NPARTS)]
+    jobs = jobs or min(NPARTS, os.cpu_count() or 1)
+    procs, failed = [], []
+    pending = list(cmds)
+    while pending or procs:
+        while pending and len(procs) < jobs:
+            c = pending.pop(0)
+            procs.append((c, subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        c, p = procs.pop(0)
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed.append(" ".join(c) + "\n" + out)
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     if verbose:
-        print(" ".join(cmd))
+        print("\n".join(" ".join(c) for c in cmds + [link]))
     return LIB
 
 

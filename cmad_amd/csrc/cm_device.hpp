@@ -1150,4 +1150,125 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
     }
 }
 
+
+// ---- explicit derivative blocks of the rate-form model at an arbitrary state ----------------------------
+// Same contract as evaluate_blocks (model.py:168-190, :273-293) for small_rate_elastic_plastic.py:249-359;
+// `which` may also be CM_W_U_PREV = 4 (d/d grad u_prev = - d/d grad u).  sigma_global = Q x[0:6] Q^T.
+enum { CM_W_U_PREV = 4 };
+
+template <int DEF, int YK, bool ROT>
+CM_D void evaluate_blocks_rate(const cm_model_desc& m, const double* G, const double* Gp, const double* x, const double* xp,
+                               int which, double* C, double* J, double* sg, double* S) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    double deg[6], z[Dims<DEF>::NZ], Ht[6][6], Gd[NU];
+    Eval<DEF> ev;
+    for (int k = 0; k < NU; ++k) Gd[k] = G[k] - Gp[k];
+    strain_from_gradu<DEF, ROT>(m, Gd, deg);
+    strain_z<DEF, ROT>(m, z);
+    residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
+    to_global<ROT>(m, x, sg);
+    if (which == CM_W_NONE) return;
+    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? NP_ : NU);
+    if (S) for (int i = 0; i < 6 * ncols; ++i) S[i] = 0.0;
+    if (J) for (int i = 0; i < NX * ncols; ++i) J[i] = 0.0;
+    const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
+    double n[6], cn[6];
+    for (int k = 0; k < 6; ++k) n[k] = ev.gt[k] * kIW[k];
+    apply_cel(m, n, cn);
+    if (which == CM_W_XI) {
+        double A[NX][NX];
+        jacobian_rate<DEF, false>(m, z, ev, Ht, A);
+        if (J) for (int r = 0; r < NX; ++r) for (int c = 0; c < NX; ++c) J[r * NX + c] = A[r][c];
+        if (S) for (int c = 0; c < 6; ++c) {
+            double un[6] = {0, 0, 0, 0, 0, 0}, dg[6];
+            un[c] = 1.0;
+            to_global<ROT>(m, un, dg);
+            for (int r = 0; r < 6; ++r) S[r * ncols + c] = dg[r];
+        }
+    } else if (which == CM_W_XI_PREV) {
+        if (J) {
+            for (int k = 0; k < 6; ++k) {
+                J[k * NX + k] = -i2mu;
+                if (ev.plastic) J[k * NX + 6] = -cn[k] * i2mu;
+            }
+            if (!ev.plastic) J[6 * NX + 6] = -1.0;
+            if constexpr (DEF == CM_PLANE_STRESS) {
+                double cz[6], zcz = 0.0, zcn = 0.0;
+                apply_cel(m, z, cz);
+                for (int k = 0; k < 6; ++k) { J[k * NX + 7] = cz[k] * i2mu; zcz += kW[k] * z[k] * cz[k]; zcn += kW[k] * z[k] * cn[k]; }
+                J[7 * NX + 7] = -zcz * i2mu;
+                if (ev.plastic) J[7 * NX + 6] = zcn * i2mu;
+            }
+        }
+    } else if (which == CM_W_PARAMS) {
+        if (J) {
+            const double dgp = ev.plastic ? ev.dgam : 0.0;
+            const double trn = ev.plastic ? gd : 0.0;
+            for (int k = 0; k < 6; ++k) {
+                const double nk = ev.plastic ? n[k] : 0.0;
+                J[k * NP_ + CM_P_LAMBDA] = (kDiag[k] ? (-ev.tr + dgp * trn) : 0.0) * i2mu;
+                J[k * NP_ + CM_P_MU] = (-2.0 * ev.e[k] + dgp * 2.0 * nk) * i2mu - C[k] / m.mu;
+            }
+            if (ev.plastic) {
+                J[6 * NP_ + CM_P_MU] = -ev.f / m.mu;
+                J[6 * NP_ + CM_P_Y] = -i2mu;
+                if (m.has_voce) {
+                    J[6 * NP_ + CM_P_VOCE_S] = -(1.0 - ev.hd.expo) * i2mu;
+                    J[6 * NP_ + CM_P_VOCE_D] = -m.voce_S * x[6] * ev.hd.expo * i2mu;
+                }
+                if (m.has_linear) J[6 * NP_ + CM_P_LIN_K] = -x[6] * i2mu;
+            }
+            double dndc[6][6] = {{0}};        // [j][k] = d n_k / d c_j (Hill)
+            if constexpr (YK == CM_YIELD_HILL) {
+                if (ev.plastic) {
+                    const double* s = ev.s;
+                    const double ip = 1.0 / ev.phi;
+                    const double d12 = s[3] - s[5], d20 = s[5] - s[0], d01 = s[0] - s[3];
+                    const double qj[6] = {d12 * d12, d20 * d20, d01 * d01, 2.0 * s[4] * s[4], 2.0 * s[2] * s[2], 2.0 * s[1] * s[1]};
+                    double dAs[6][6] = {{0}};
+                    dAs[0][3] = d12; dAs[0][5] = -d12; dAs[1][5] = d20; dAs[1][0] = -d20; dAs[2][0] = d01; dAs[2][3] = -d01;
+                    dAs[3][4] = 2.0 * s[4]; dAs[4][2] = 2.0 * s[2]; dAs[5][1] = 2.0 * s[1];
+                    for (int j = 0; j < 6; ++j) {
+                        double cdn[6];
+                        for (int k = 0; k < 6; ++k) dndc[j][k] = (dAs[j][k] * ip - ev.gt[k] * qj[j] * 0.5 * ip * ip) * kIW[k];
+                        apply_cel(m, dndc[j], cdn);
+                        for (int k = 0; k < 6; ++k) J[k * NP_ + CM_P_YC0 + j] = ev.dgam * cdn[k] * i2mu;
+                        J[6 * NP_ + CM_P_YC0 + j] = qj[j] * 0.5 * ip * i2mu;
+                    }
+                }
+            }
+            if constexpr (DEF == CM_PLANE_STRESS) {
+                const double zt = z[0] + z[3] + z[5];
+                double zwe = 0.0, zwn = 0.0;
+                for (int k = 0; k < 6; ++k) { zwe += kW[k] * z[k] * ev.e[k]; zwn += kW[k] * z[k] * n[k]; }
+                J[7 * NP_ + CM_P_LAMBDA] = zt * (ev.tr - dgp * trn) * i2mu;
+                J[7 * NP_ + CM_P_MU] = (2.0 * zwe - dgp * 2.0 * zwn) * i2mu - C[7] / m.mu;
+                if constexpr (YK == CM_YIELD_HILL) {
+                    if (ev.plastic) for (int j = 0; j < 6; ++j) {
+                        double cdn[6], r = 0.0;
+                        apply_cel(m, dndc[j], cdn);
+                        for (int k = 0; k < 6; ++k) r += kW[k] * z[k] * cdn[k];
+                        J[7 * NP_ + CM_P_YC0 + j] = -ev.dgam * r * i2mu;
+                    }
+                }
+            }
+        }
+    } else if (which == CM_W_U || which == CM_W_U_PREV) {
+        const double sgn = (which == CM_W_U) ? 1.0 : -1.0;
+        if (J) for (int c = 0; c < NU; ++c) {
+            double Gu[NU], dm[6], cd[6];
+            for (int k = 0; k < NU; ++k) Gu[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gu, dm);
+            apply_cel(m, dm, cd);
+            for (int k = 0; k < 6; ++k) J[k * NU + c] = -sgn * cd[k] * i2mu;
+            if constexpr (DEF == CM_PLANE_STRESS) {
+                double r = 0.0;
+                for (int k = 0; k < 6; ++k) r += kW[k] * z[k] * cd[k];
+                J[7 * NU + c] = sgn * r * i2mu;
+            }
+        }
+    }
+}
+
 }  // namespace cm

@@ -5,6 +5,20 @@
 #include <cstdlib>
 #include "cm_structured.hpp"
 
+// The library can be built from this one file in four independent pieces (hipcc -DCM_PART=0..3, see
+// cmad_amd/build.py) so the template instantiations compile in parallel; without CM_PART everything is one TU.
+//   0: cm_update, cm_update_tangent            2: cm_update_vjp, cm_adjoint_step
+//   1: cm_update_rate, cm_evaluate, info calls 3: cm_update_and_vjp, cm_objective_grad
+#ifndef CM_PART
+#define CM_PART (-1)
+#endif
+#define CM_HAS_PART(k) (CM_PART == -1 || CM_PART == (k))
+
+extern int g_cm_last_hip_error;
+#if CM_HAS_PART(1)
+int g_cm_last_hip_error = 0;
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;           // 4 wavefronts
@@ -352,6 +366,27 @@ __global__ __launch_bounds__(64) void k_evaluate(cm_model_desc m, int64_t B, int
     }
 }
 
+template <int DEF, int YK, bool ROT>
+__global__ __launch_bounds__(64) void k_evaluate_rate(cm_model_desc m, int64_t B, int which,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
+        const double* __restrict__ xi, double* __restrict__ C_out, double* __restrict__ J_out,
+        double* __restrict__ s_out, double* __restrict__ S_out) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double G[NU], Gp[NU], xp[NX], x[NX], C[NX], sg[6], J[NX * CM_NUM_PARAMS], S[6 * CM_NUM_PARAMS];
+    for (int k = 0; k < NU; ++k) { G[k] = gradu[(int64_t)k * B + b]; Gp[k] = gradu_prev[(int64_t)k * B + b]; }
+    for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + b]; x[k] = xi[(int64_t)k * B + b]; }
+    evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, which, C, J_out ? J : nullptr, sg, S_out ? S : nullptr);
+    const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
+    if (C_out) for (int k = 0; k < NX; ++k) C_out[(int64_t)k * B + b] = C[k];
+    if (s_out) for (int k = 0; k < 6; ++k) s_out[(int64_t)k * B + b] = sg[k];
+    if (which != CM_W_NONE) {
+        if (J_out) for (int i = 0; i < NX * ncols; ++i) J_out[(int64_t)i * B + b] = J[i];
+        if (S_out) for (int i = 0; i < 6 * ncols; ++i) S_out[(int64_t)i * B + b] = S[i];
+    }
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 
@@ -394,10 +429,9 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
     return false;
 }
 
-int g_last_hip_error = 0;
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return CM_ERR_LAUNCH; }
+    if (e != hipSuccess) { g_cm_last_hip_error = (int)e; return CM_ERR_LAUNCH; }
     return CM_OK;
 }
 
@@ -457,9 +491,16 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
 
 extern "C" {
 
-int cm_abi_version(void) { return 1; }
-const char* cm_last_hip_error(void) { return hipGetErrorName((hipError_t)g_last_hip_error); }
 
+#if CM_HAS_PART(1)
+int cm_abi_version(void) { return 1; }
+#endif
+
+#if CM_HAS_PART(1)
+const char* cm_last_hip_error(void) { return hipGetErrorName((hipError_t)g_cm_last_hip_error); }
+#endif
+
+#if CM_HAS_PART(1)
 int cm_num_xi(const cm_model_desc* m) {
     if (!m) return CM_ERR_BAD_ARG;
     if (m->def_type == CM_FULL_3D) return 7;
@@ -467,7 +508,9 @@ int cm_num_xi(const cm_model_desc* m) {
     if (m->def_type == CM_UNIAXIAL_STRESS) return m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC ? 12 : 9;
     return CM_ERR_UNSUPPORTED;
 }
+#endif
 
+#if CM_HAS_PART(1)
 int cm_num_gradu(const cm_model_desc* m) {
     if (!m) return CM_ERR_BAD_ARG;
     if (m->def_type == CM_FULL_3D) return 9;
@@ -475,18 +518,24 @@ int cm_num_gradu(const cm_model_desc* m) {
     if (m->def_type == CM_UNIAXIAL_STRESS) return 1;
     return CM_ERR_UNSUPPORTED;
 }
+#endif
 
+#if CM_HAS_PART(1)
 int64_t cm_workspace_bytes(int64_t B) {
     if (B < 0) return CM_ERR_BAD_ARG;
     const int64_t nb = B == 0 ? 1 : nblocks_of(B);
     return (nb + kRedBlocks + 1) * kRed * (int64_t)sizeof(double);   // block partials + stage rows + one result row
 }
+#endif
 
+#if CM_HAS_PART(0)
 int cm_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
               double* xi, double* sigma, uint32_t* status, void* stream) {
     return launch_update<false>(m, B, gradu, xi_prev, xi, sigma, nullptr, status, stream);
 }
+#endif
 
+#if CM_HAS_PART(1)
 int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
                    const double* xi_prev, double* xi, double* sigma, uint32_t* status, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
@@ -503,12 +552,16 @@ int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
 }
+#endif
 
+#if CM_HAS_PART(0)
 int cm_update_tangent(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream) {
     return launch_update<true>(m, B, gradu, xi_prev, xi, sigma, dsigma_dgradu, status, stream);
 }
+#endif
 
+#if CM_HAS_PART(2)
 int cm_update_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                   const double* sigma_bar, double* grad_p, double* xi_prev_bar, double* gradu_bar,
                   void* workspace, int64_t workspace_bytes, void* stream) {
@@ -517,7 +570,9 @@ int cm_update_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const 
     return launch_reverse<0>(m, B, gradu, xi_prev, xi, sigma_bar, nullptr, nullptr, nullptr, nullptr, xi_prev_bar,
                              gradu_bar, grad_p, 1, 0, workspace, workspace_bytes, stream);
 }
+#endif
 
+#if CM_HAS_PART(3)
 int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       const double* sigma_bar, double* xi, double* sigma, double* grad_p,
                       void* workspace, int64_t workspace_bytes, void* stream) {
@@ -526,9 +581,13 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
     return launch_reverse<3>(m, B, gradu, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr, nullptr,
                              grad_p, 1, 0, workspace, workspace_bytes, stream);
 }
+#endif
 
+#if CM_HAS_PART(1)
 int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
+#endif
 
+#if CM_HAS_PART(1)
 int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* jac, double* sigma, double* dsigma, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
@@ -547,14 +606,41 @@ int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
 }
+#endif
 
+#if CM_HAS_PART(1)
+int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
+                     const double* xi_prev, const double* xi, double* C, double* jac, double* sigma, double* dsigma,
+                     void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC)) return CM_ERR_UNSUPPORTED;
+    if (which != CM_W_XI && which != CM_W_XI_PREV && which != CM_W_PARAMS && which != CM_W_U && which != CM_W_U_PREV &&
+        which != CM_W_NONE) return CM_ERR_BAD_ARG;
+    if (B == 0) return CM_OK;
+    if (!gradu || !gradu_prev || !xi_prev || !xi) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+        hipLaunchKernelGGL((k_evaluate_rate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, gradu_prev, xi_prev, xi,
+                           C, jac, sigma, dsigma);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+#endif
+
+#if CM_HAS_PART(3)
 int cm_objective_grad(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       const double* data, const double* wsq6, double* out, double* xi,
                       void* workspace, int64_t workspace_bytes, void* stream) {
     return launch_reverse<1>(m, B, gradu, xi_prev, nullptr, data, wsq6, nullptr, xi, nullptr, nullptr, nullptr,
                              out, 0, 0, workspace, workspace_bytes, stream);
 }
+#endif
 
+#if CM_HAS_PART(2)
 int cm_adjoint_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                     const double* data, const double* wsq6, const double* hist_in, double* hist_out, double* out,
                     int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -562,5 +648,6 @@ int cm_adjoint_step(const cm_model_desc* m, int64_t B, const double* gradu, cons
     return launch_reverse<2>(m, B, gradu, xi_prev, xi, data, wsq6, hist_in, nullptr, nullptr, hist_out, nullptr,
                              out, 0, accumulate, workspace, workspace_bytes, stream);
 }
+#endif
 
 }  // extern "C"

@@ -86,8 +86,8 @@ class Model(ABC):
     def _flat(blocks) -> np.ndarray:
         return np.concatenate([np.atleast_1d(np.asarray(b, dtype=np.float64)).ravel() for b in blocks])
 
-    def _point_evaluate(self, which, xi, xi_prev, params, U, want_jac=True):
-        """cm_evaluate for one point -> (C, J, sigma6, S) as numpy."""
+    def _point_evaluate(self, which, xi, xi_prev, params, U, want_jac=True, U_prev=None):
+        """cm_evaluate (cm_evaluate_rate for the rate form) for one point -> (C, J, sigma6, S) as numpy."""
         import torch
         desc, info = self._desc(params)
         L = _lib.lib()
@@ -101,14 +101,21 @@ class Model(ABC):
         G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).to(dev)
         g, x1, x0 = t(G), t(self._flat(xi)), t(self._flat(xi_prev))
-        ncols = {0: nx, 1: nx, 2: _lib.CM_NUM_PARAMS, 3: nu, 5: 1}[int(which)]
+        ncols = {0: nx, 1: nx, 2: _lib.CM_NUM_PARAMS, 3: nu, 4: nu, 5: 1}[int(which)]
         Cd = torch.empty((nx, 1), dtype=torch.float64, device=dev)
         s = torch.empty((6, 1), dtype=torch.float64, device=dev)
         J = torch.empty((nx * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
         S = torch.empty((6 * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
-        rc = L.cm_evaluate(C.byref(desc), 1, int(which), _ptr(g), _ptr(x0), _ptr(x1), _ptr(Cd), _ptr(J), _ptr(s), _ptr(S),
-                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        _lib.check(rc, "cm_evaluate")
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self._model_kind == 1:
+            Gp = np.zeros_like(G) if U_prev is None else np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
+            rc = L.cm_evaluate_rate(C.byref(desc), 1, int(which), _ptr(g), _ptr(t(Gp)), _ptr(x0), _ptr(x1), _ptr(Cd),
+                                    _ptr(J), _ptr(s), _ptr(S), stream)
+            _lib.check(rc, "cm_evaluate_rate")
+        else:
+            rc = L.cm_evaluate(C.byref(desc), 1, int(which), _ptr(g), _ptr(x0), _ptr(x1), _ptr(Cd), _ptr(J), _ptr(s),
+                               _ptr(S), stream)
+            _lib.check(rc, "cm_evaluate")
         out_J = J.cpu().numpy().reshape(nx, ncols) if want_jac and which != DerivType.DNONE else None
         out_S = S.cpu().numpy().reshape(6, ncols) if want_jac and which != DerivType.DNONE else None
         return Cd.cpu().numpy()[:, 0], out_J, s.cpu().numpy()[:, 0], out_S, info
@@ -126,17 +133,17 @@ class Model(ABC):
         xi, xi_prev, params, U, U_prev = self.variables()
         mode = self._deriv_mode
         if mode == DerivType.DNONE:
-            Cv, _, _, _, _ = self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)
+            Cv, _, _, _, _ = self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False, U_prev=U_prev)
             self._C = np.asarray(Cv, dtype=self.dtype)
             self._Jac = None
         elif mode == DerivType.DPARAMS:
-            _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U)
+            _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U, U_prev=U_prev)
             self._Jac = np.asarray(self._active_columns(J, info), dtype=np.float64)
-        elif mode == DerivType.DU_PREV:
+        elif mode == DerivType.DU_PREV and self._model_kind == 0:
             nu = self._ndims ** 2
-            self._Jac = np.zeros((self.num_dofs, nu))          # the small-strain residual ignores U_prev
+            self._Jac = np.zeros((self.num_dofs, nu))          # the total-form residual ignores U_prev
         else:
-            _, J, _, _, _ = self._point_evaluate(mode, xi, xi_prev, params, U)
+            _, J, _, _, _ = self._point_evaluate(mode, xi, xi_prev, params, U, U_prev=U_prev)
             self._Jac = J
 
     def evaluate_hessians(self) -> None:
@@ -148,17 +155,17 @@ class Model(ABC):
         xi, xi_prev, params, U, U_prev = self.variables()
         mode = self._deriv_mode
         if mode == DerivType.DNONE:
-            _, _, s6, _, _ = self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)
+            _, _, s6, _, _ = self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False, U_prev=U_prev)
             self._Sigma = np.asarray(_sym3(s6), dtype=np.float64)
             self._dSigma = None
         elif mode == DerivType.DU_PREV:
             self._dSigma = np.zeros((3, 3, self._ndims ** 2))
         elif mode == DerivType.DPARAMS:
-            _, _, _, S, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U)
+            _, _, _, S, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U, U_prev=U_prev)
             S9 = _sym3(S).reshape(9, -1)                                   # (9, KP)
             self._dSigma = np.asarray(self._active_columns(S9, info), dtype=np.float64)
         else:
-            _, _, _, S, _ = self._point_evaluate(mode, xi, xi_prev, params, U)
+            _, _, _, S, _ = self._point_evaluate(mode, xi, xi_prev, params, U, U_prev=U_prev)
             self._dSigma = _sym3(S)                                         # (3, 3, n_xi) == np.dstack of blocks
 
     def set_xi_to_init_vals(self) -> None:
@@ -189,10 +196,10 @@ class Model(ABC):
         return out
 
     def _residual(self, xi, xi_prev, params, U, U_prev):
-        return self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)[0]
+        return self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False, U_prev=U_prev)[0]
 
     def cauchy(self, xi, xi_prev, params, U, U_prev):
-        return _sym3(self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False)[2])
+        return _sym3(self._point_evaluate(DerivType.DNONE, xi, xi_prev, params, U, want_jac=False, U_prev=U_prev)[2])
 
     def _block_list(self, J):
         """(n_xi, n_xi) -> list over variable blocks of (n_xi, n_block) arrays, the pytree jacfwd returns."""
@@ -203,25 +210,29 @@ class Model(ABC):
         return out
 
     def dC_dxi(self, xi, xi_prev, params, U, U_prev):
-        return self._block_list(self._point_evaluate(DerivType.DXI, xi, xi_prev, params, U)[1])
+        return self._block_list(self._point_evaluate(DerivType.DXI, xi, xi_prev, params, U, U_prev=U_prev)[1])
 
     def dC_dxi_prev(self, xi, xi_prev, params, U, U_prev):
-        return self._block_list(self._point_evaluate(DerivType.DXI_PREV, xi, xi_prev, params, U)[1])
+        return self._block_list(self._point_evaluate(DerivType.DXI_PREV, xi, xi_prev, params, U, U_prev=U_prev)[1])
 
     def dC_dp(self, xi, xi_prev, params, U, U_prev):
         """Active-parameter columns (n_xi, num_active); the reference returns the full params pytree and
         slices with `model_active_params_jacobian` -- callers only ever use the active slice."""
-        _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U)
+        _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U, U_prev=U_prev)
         return self._active_columns(J, info)
 
     def dC_dU(self, xi, xi_prev, params, U, U_prev):
-        J = self._point_evaluate(DerivType.DU, xi, xi_prev, params, U)[1]
+        J = self._point_evaluate(DerivType.DU, xi, xi_prev, params, U, U_prev=U_prev)[1]
         n = self._ndims
         return GlobalFieldsAtPoint(fields={"u": np.zeros((self.num_dofs, n))},
                                    grad_fields={"u": J.reshape(self.num_dofs, n, n)})
 
     def dC_dU_prev(self, xi, xi_prev, params, U, U_prev):
         n = self._ndims
+        if self._model_kind == 1:
+            J = self._point_evaluate(DerivType.DU_PREV, xi, xi_prev, params, U, U_prev=U_prev)[1]
+            return GlobalFieldsAtPoint(fields={"u": np.zeros((self.num_dofs, n))},
+                                       grad_fields={"u": J.reshape(self.num_dofs, n, n)})
         return GlobalFieldsAtPoint(fields={"u": np.zeros((self.num_dofs, n))},
                                    grad_fields={"u": np.zeros((self.num_dofs, n, n))})
 

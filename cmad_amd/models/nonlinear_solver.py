@@ -19,10 +19,8 @@ def newton_solve(model, max_iters: int = 10, abs_tol: float = 1e-14, rel_tol: fl
     if max_ls_evals == 0 and hasattr(model, "device_newton"):
         iters, _ = model.device_newton(max_iters, abs_tol, rel_tol)
         model.seed_none()
-        if getattr(model, "_model_kind", 0) == 0:
-            model.evaluate()
-            return iters, float(np.linalg.norm(model.C()))
-        return iters, float("nan")            # rate form: no residual evaluation entry point yet
+        model.evaluate()
+        return iters, float(np.linalg.norm(model.C()))
 
     converged = False
     ii = 0

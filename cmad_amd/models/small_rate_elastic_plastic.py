@@ -3,9 +3,10 @@ material Cauchy stress.  Host mirror of /root/reference/cmad/models/small_rate_e
 (constructor contract and state layout: "cauchy" sym tensor, "alpha", plane-stress stretch); the residual
 (:249-346) runs in `cm_update_rate`.
 
-Built so far on the device: the stress update (local Newton) and the Cauchy stress for FULL_3D and
-PLANE_STRESS.  The derivative blocks (`evaluate()` with a seed, `dSigma`) of the rate form are not built yet
-and raise NotImplementedError."""
+Built on the device for FULL_3D and PLANE_STRESS: the stress update (`cm_update_rate`) and the stateful
+evaluate surface (`cm_evaluate_rate`: residual, every Jacobian block including d/dU_prev, Sigma, dSigma), so
+the material-point objectives run on it unchanged.  The batched tangent / reverse kernels of the rate form
+are not built yet."""
 from __future__ import annotations
 
 from typing import ClassVar
@@ -60,7 +61,6 @@ class SmallRateElasticPlastic(Model):
         self.set_xi_to_init_vals()
         self.parameters = parameters
         super().__init__()
-        self._Sigma_cache = None
 
     @classmethod
     def from_deck(cls, model_section, parameters, def_type):
@@ -83,20 +83,5 @@ class SmallRateElasticPlastic(Model):
         Gp = np.asarray(self._U_prev.grad_fields["u"], dtype=np.float64)
         xi, sig, status = ev.update_rate(t(G), t(Gp), t(self._flat(self._xi_prev)))
         self._xi = [b.astype(self.dtype) for b in self._split(xi.cpu().numpy()[:, 0])]
-        self._Sigma_cache = (self._flat(self._xi).copy(), _sym3(sig.cpu().numpy()[:, 0]))
         s = int(status.cpu().numpy().astype(np.uint32)[0])
         return s & _lib.STATUS_ITERS_MASK, bool(s & _lib.STATUS_CONVERGED)
-
-    def evaluate(self) -> None:
-        if self._deriv_mode != DerivType.DNONE:
-            raise NotImplementedError("derivative blocks of the rate-form residual are not built yet")
-        raise NotImplementedError("residual evaluation at arbitrary states is not built for the rate form; "
-                                  "use newton_solve(model)")
-
-    def evaluate_cauchy(self) -> None:
-        if self._deriv_mode != DerivType.DNONE:
-            raise NotImplementedError("derivative blocks of the rate-form Cauchy stress are not built yet")
-        if self._Sigma_cache is None or not np.array_equal(self._Sigma_cache[0], self._flat(self._xi)):
-            raise NotImplementedError("Sigma() of the rate form is available for the state returned by newton_solve")
-        self._Sigma = self._Sigma_cache[1]
-        self._dSigma = None

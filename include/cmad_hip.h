@@ -200,6 +200,14 @@ int cm_evaluate(const cm_model_desc* m, int64_t B, int which,
                 const double* gradu, const double* xi_prev, const double* xi,
                 double* C, double* jac, double* sigma, double* dsigma, void* stream);
 
+/*
+ * cm_evaluate_rate: cm_evaluate for the rate-form model (small_rate_elastic_plastic.py:249-359), whose residual
+ * also depends on the previous grad u; `which` may additionally be CM_DU_PREV (= minus the CM_DU block).
+ */
+int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which,
+                     const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
+                     double* C, double* jac, double* sigma, double* dsigma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,3 +89,16 @@ def update_rate(desc, gradu, gradu_prev, xi_prev, nx):
     rc = L.hh_update_rate(C.byref(desc), C.c_int64(B), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi), _p(sig), _p(st))
     assert rc == 0
     return xi, sig, st
+
+
+def evaluate_rate(desc, which, gradu, gradu_prev, xi_prev, xi, nx):
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu, gradu_prev, xi_prev, xi = c(gradu), c(gradu_prev), c(xi_prev), c(xi)
+    B, nu = gradu.shape[1], gradu.shape[0]
+    ncols = {0: nx, 1: nx, 2: 12, 3: nu, 4: nu, 5: 1}[which]
+    Cc = np.zeros((nx, B)); J = np.zeros((nx * ncols, B)); s = np.zeros((6, B)); S = np.zeros((6 * ncols, B))
+    rc = L.hh_evaluate_rate(C.byref(desc), C.c_int64(B), C.c_int(which), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi),
+                            _p(Cc), _p(J), _p(s), _p(S))
+    assert rc == 0
+    return Cc, J.reshape(nx, ncols, B), s, S.reshape(6, ncols, B)

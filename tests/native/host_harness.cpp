@@ -111,6 +111,25 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
     }
 }
 
+template <int DEF, int YK, bool ROT>
+static void run_evaluate_rate(const cm_model_desc& m, int64_t B, int which, const double* gradu, const double* gradu_prev,
+                              const double* xi_prev, const double* xi, double* C_out, double* J_out, double* s_out, double* S_out) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
+    for (int64_t b = 0; b < B; ++b) {
+        double G[NU], Gp[NU], xp[NX], x[NX], C[NX], sg[6], J[NX * CM_NUM_PARAMS], S[6 * CM_NUM_PARAMS];
+        for (int k = 0; k < NU; ++k) { G[k] = gradu[k * B + b]; Gp[k] = gradu_prev[k * B + b]; }
+        for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; }
+        evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, which, C, J, sg, S);
+        for (int k = 0; k < NX; ++k) C_out[k * B + b] = C[k];
+        for (int k = 0; k < 6; ++k) s_out[k * B + b] = sg[k];
+        if (which != CM_W_NONE) {
+            for (int i = 0; i < NX * ncols; ++i) J_out[(int64_t)i * B + b] = J[i];
+            for (int i = 0; i < 6 * ncols; ++i) S_out[(int64_t)i * B + b] = S[i];
+        }
+    }
+}
+
 template <bool UNI = false, class F>
 static int dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity;
@@ -145,6 +164,10 @@ int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double*
 int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
+}
+int hh_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
+                     const double* xi_prev, const double* xi, double* C, double* J, double* s, double* S) {
+    return dispatch(m, [&]<int D, int Y, bool R>() { run_evaluate_rate<D, Y, R>(*m, B, which, gradu, gradu_prev, xi_prev, xi, C, J, s, S); });
 }
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {

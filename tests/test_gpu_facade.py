@@ -320,3 +320,27 @@ def test_uniaxial_calibration_direct_equals_adjoint_and_fd():
         Jp = MPDirectObjective(qoi, F).evaluate(xp_).J
         Jm = MPDirectObjective(qoi, F).evaluate(xm_).J
         np.testing.assert_allclose((Jp - Jm) / (2 * h), ga[k], rtol=2e-5, atol=1e-7 * np.abs(ga).max())
+
+
+def test_rate_model_calibration_recovers_truth():
+    """tests/objectives/test_calibrations.py:57-109 as written in the reference: SmallRateElasticPlastic,
+    PLANE_STRESS, Calibration QoI, L-BFGS-B from canonical 0.1 with the adjoint and the direct objectives."""
+    from scipy.optimize import fmin_l_bfgs_b
+    from cmad_amd.models import DefType, SmallRateElasticPlastic
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectObjective
+    from cmad_amd.qois import Calibration
+    F = plane_stress_F(0.01, 8)                        # 16 steps (the reference uses 100 on the same path)
+    model = SmallRateElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+    true_params = model.parameters.flat_active_values()
+    cauchy = _compute_cauchy(model, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    qoi = Calibration(model, cauchy, weight)
+    x0 = 0.1 * np.ones(3)
+    ra = MPAdjointObjective(qoi, F).evaluate(x0)
+    rd = MPDirectObjective(qoi, F).evaluate(x0)
+    assert abs(ra.J - rd.J) <= 1e-12 * abs(ra.J)
+    np.testing.assert_allclose(ra.grad, rd.grad, rtol=1e-8, atol=1e-10 * np.abs(ra.grad).max())
+    obj = MPAdjointObjective(qoi, F)
+    opt, fval, info = fmin_l_bfgs_b(lambda x: tuple(obj.evaluate(x)), x0, bounds=model.parameters.opt_bounds, factr=10)
+    model.parameters.set_active_values_from_flat(opt)
+    assert np.linalg.norm(model.parameters.flat_active_values() - true_params) < 1e-6

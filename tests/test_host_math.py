@@ -151,3 +151,49 @@ def test_uniaxial_stress_update_and_blocks(yield_kind, kw, rot, uidx, solver_var
                                                rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(So).max()), err_msg=str(path))
         xp = xi_o
     assert (it_o > 0).any()
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_model_explicit_blocks(def_type, yield_kind, kw, rot, solver_variant):
+    """cm_evaluate_rate's blocks vs the oracle's dual-number Jacobians of the rate-form residual, at the states
+    visited by a three-step history (elastic and plastic points)."""
+    import numpy as np
+    import host_harness_lib as hh
+    from cmad_amd.models.device import build_desc, kp_to_leaf_grad
+    from cmad_amd.synthetic import gauss_point_batch
+    if solver_variant == "dense":
+        pytest.skip("always dense")
+    rng = np.random.default_rng(3)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng) if rot else None, **kw)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1)
+    nd = 3 if def_type == ol.FULL_3D else 2
+    B = 12
+    g0 = gauss_point_batch(B, seed=4, skew=True, ndims=nd)
+    gp = np.zeros_like(g0); xp = np.tile(mat.init_xi()[:, None], (1, B))
+    V6 = [0, 1, 2, 4, 5, 8]
+    nplastic = 0
+    for scale in (0.5, 1.0, 1.4):
+        g = scale * g0
+        xi, sig, it, cv = mat.update_batch(ol.newton_settings(), g, xp, gradu_prev=gp)
+        nplastic += int((it > 0).sum())
+        for which_o, which_d in ((ol.W_XI, 0), (ol.W_XI_PREV, 1), (ol.W_U, 3), (ol.W_U_PREV, 4)):
+            C, J, s, S = hh.evaluate_rate(desc, which_d, g, gp, xp, xi, mat.nx)
+            for b in range(B):
+                U, Up = g[:, b].reshape(nd, nd), gp[:, b].reshape(nd, nd)
+                Jo = mat.jacobian(which_o, xi[:, b], xp[:, b], U, Up)
+                So = mat.dcauchy(which_o, xi[:, b], xp[:, b], U, Up)[V6, :]
+                np.testing.assert_allclose(C[:, b], mat.residual(xi[:, b], xp[:, b], U, Up), rtol=1e-9, atol=1e-15)
+                np.testing.assert_allclose(J[:, :, b], Jo, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+                np.testing.assert_allclose(S[:, :, b], So, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(So).max()))
+        C, J, s, S = hh.evaluate_rate(desc, 2, g, gp, xp, xi, mat.nx)
+        for b in range(B):
+            U, Up = g[:, b].reshape(nd, nd), gp[:, b].reshape(nd, nd)
+            Jo = mat.jacobian(ol.W_PARAMS, xi[:, b], xp[:, b], U, Up)
+            for path in pc.param_paths(yield_kind):
+                np.testing.assert_allclose(kp_to_leaf_grad(path, np.moveaxis(J[:, :, b], 1, 0), info), Jo[:, mat.param_index(path)],
+                                           rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(Jo).max()), err_msg=str(path))
+        xp, gp = xi, g
+    assert nplastic > 0
