@@ -59,7 +59,9 @@ CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS<YK>& y)
 #pragma unroll
         for (int k = 0; k < 6; ++k) qq += s[k] * As[k];
         y.phi = sqrt(qq);
-        const double ip = rcp(y.phi);
+        // at zero stress the reference's normal is NaN and masked by the branch select (phi = 0 is always
+        // elastic); here the normal is defined as 0 there so that arithmetic masking can replace the selects
+        const double ip = (qq > 0.0) ? rcp(y.phi) : 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) y.gt[k] = As[k] * ip;
         y.rho = ip;
@@ -114,10 +116,16 @@ CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x
     ev.f = (ev.y.phi - (m.Y + ev.hd.H)) * i2mu;
     ev.dgam = x[6] - xp[6];
     ev.plastic = (ev.f > m.yield_tol) || (fabs(ev.f) < m.yield_tol);
+    if constexpr (YieldS<YK>::QUAD) {
+        const double dgp = ev.plastic ? ev.dgam : 0.0;           // one select instead of six (gt is finite, see above)
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double ce = x[k] - xp[k];
-        C[k] = ev.plastic ? (ce - ev.dgam * ev.y.gt[k] * kIW[k]) : ce;
+        for (int k = 0; k < 6; ++k) C[k] = (x[k] - xp[k]) - dgp * kIW[k] * ev.y.gt[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double ce = x[k] - xp[k];
+            C[k] = ev.plastic ? (ce - ev.dgam * ev.y.gt[k] * kIW[k]) : ce;
+        }
     }
     C[6] = ev.plastic ? ev.f : ev.dgam;
 }

@@ -21,7 +21,11 @@ int g_cm_last_hip_error = 0;
 
 namespace {
 
-constexpr int kBlock = 256;           // 4 wavefronts
+#ifndef CM_BLOCK
+#define CM_BLOCK 256
+#endif
+constexpr int kBlock = CM_BLOCK;      // threads per workgroup of the per-point kernels
+constexpr int kRBlock = 256;          // threads per workgroup of the reduction kernels
 constexpr int kRed = 1 + CM_NUM_PARAMS;
 
 using namespace cm;
@@ -173,11 +177,11 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int
     double acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.0;
-    for (int64_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    for (int64_t i = begin + threadIdx.x; i < end; i += kRBlock) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) acc[k] += rows[i * NV + k];
     }
-    __shared__ double sh[kBlock / 64][NV];
+    __shared__ double sh[kRBlock / 64][NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         double a = acc[k];
@@ -194,13 +198,13 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int
     if (threadIdx.x < NV) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
+        for (int w = 0; w < kRBlock / 64; ++w) s += sh[w][threadIdx.x];
         res[threadIdx.x] = s;
     }
 }
 
 template <int NV>
-__global__ __launch_bounds__(kBlock) void k_reduce_stage1(const double* __restrict__ partials, int64_t nrows,
+__global__ __launch_bounds__(kRBlock) void k_reduce_stage1(const double* __restrict__ partials, int64_t nrows,
                                                           double* __restrict__ stage) {
     const int64_t per = (nrows + kRedBlocks - 1) / kRedBlocks;
     const int64_t begin = (int64_t)blockIdx.x * per;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_stage1(const double* __restri
 // out[k - first] (+)= total[k] for k >= first (first = 1 drops the objective slot: the vjp entry points
 // return only the 12 gradient entries, written straight to the caller's array -- no device-to-device copy)
 template <int NV>
-__global__ __launch_bounds__(kBlock) void k_reduce_stage2(const double* __restrict__ stage, double* __restrict__ out,
+__global__ __launch_bounds__(kRBlock) void k_reduce_stage2(const double* __restrict__ stage, double* __restrict__ out,
                                                           int first, int accumulate) {
     __shared__ double res[NV];
     reduce_rows<NV>(stage, 0, kRedBlocks, res);
@@ -482,8 +486,8 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     double* stage = partials + nb * kRed;
-    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kBlock), 0, s, partials, B > 0 ? nb : 0, stage);
-    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kBlock), 0, s, stage, out, out_offset, accumulate);
+    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
+    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, accumulate);
     return check_launch();
 }
 
