@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000, help="Gauss points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--j2-radial-line", action="store_true",
+                    help="opt into CM_SOLVER_J2_RADIAL_LINE (same Newton iterates restricted to the radial line); "
+                         "side measurement, never the default")
     ap.add_argument("--workload", default="j2_update_vjp",
                     choices=["j2_update_vjp", "j2_update", "j2_objective_grad", "hosford_update", "hybrid_update"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
@@ -107,7 +110,7 @@ def main():
     B = args.points
     wl = args.workload
     values = j2_voce_values()
-    newton = NewtonSettings()                      # newton_solve defaults: 10 iters, 1e-14, no line search
+    newton = NewtonSettings(j2_radial_line=args.j2_radial_line)   # newton_solve defaults: 10 iters, 1e-14, no line search
     eps_y, hybrid, bytes_per_update = 1e-3, None, BYTES_PER_UPDATE
     if wl == "hosford_update":                     # configs[2]: notch_hosford.yaml material + solver settings
         from cmad_amd.synthetic import hosford_values
@@ -216,7 +219,9 @@ def main():
                              "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])"}[wl],
                 "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
                 "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
-                           "line_search_max_evals": newton.line_search["max evals"]},
+                           "line_search_max_evals": newton.line_search["max evals"],
+                           "solver": "J2 radial-line restriction of the 7-dof Newton (opt-in)" if args.j2_radial_line
+                                     else "general 7-dof Newton, structured block solve"},
                 "parallelism": f"dp{n}: disjoint point shards; one RCCL all-reduce of the 12 fp64 gradient entries per "
                                "step, double-buffered so it overlaps the next step's kernel",
             },

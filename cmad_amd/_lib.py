@@ -7,6 +7,7 @@ from .build import LIB
 
 CM_NUM_PARAMS = 12
 P_LAMBDA, P_MU, P_Y, P_VOCE_S, P_VOCE_D, P_LIN_K, P_YC0 = 0, 1, 2, 3, 4, 5, 6
+SOLVER_J2_RADIAL_LINE = 1
 STATUS_ITERS_MASK, STATUS_CONVERGED, STATUS_PLASTIC, STATUS_SINGULAR = 0xFFFF, 1 << 16, 1 << 17, 1 << 18
 CM_OK, CM_ERR_BAD_ARG, CM_ERR_UNSUPPORTED, CM_ERR_LAUNCH, CM_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -19,7 +20,7 @@ class ModelDesc(C.Structure):
     _fields_ = [
         ("model_kind", C.c_int32), ("def_type", C.c_int32), ("yield_kind", C.c_int32),
         ("has_voce", C.c_int32), ("has_linear", C.c_int32), ("uniaxial_idx", C.c_int32),
-        ("rotation_is_identity", C.c_int32), ("reserved0", C.c_int32),
+        ("rotation_is_identity", C.c_int32), ("solver_flags", C.c_int32),
         ("yield_tol", C.c_double), ("Q", C.c_double * 9), ("lmbda", C.c_double), ("mu", C.c_double),
         ("Y", C.c_double), ("voce_S", C.c_double), ("voce_D", C.c_double), ("lin_K", C.c_double),
         ("yc", C.c_double * 6),

@@ -293,6 +293,54 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
     return flags | (uint32_t)it;
 }
 
+// ---- J2, FULL_3D, plain Newton: the same iteration restricted to its invariant subspace ---------------------
+// Opt-in (cm_model_desc.solver_flags & CM_SOLVER_J2_RADIAL_LINE).  For J2 the 7-dof Newton iterates started at
+// x_prev never leave the radial line v = v_prev + dgam n_trial: C[0:6] vanishes on it, dC/dx maps it to itself,
+// and the step reduces *exactly* to the scalar Newton step on f(alpha):
+//     phi(dgam) = phi_trial - 3 mu dgam ,  f = (phi - Y - H(alpha)) / 2mu ,  d alpha = f / ( -(3 mu + H') / 2mu )
+// (derivation in DESIGN.md section 3).  Same iterates, same iteration counts, same convergence test (||C|| = |f|)
+// as newton_s; ~50 instead of ~275 instructions per iteration.  An iterate that falls on the elastic side of the
+// branch select (cannot happen for concave hardening) sends the lane to the general path.
+CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
+                             EvalS<CM_YIELD_J2>& ev) {
+    double C[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = xp[k];
+    residual_s<CM_YIELD_J2>(m, eg, x, xp, ev, C);              // trial state: phi_trial, normal, f0
+    const double n0sq = dot<7>(C, C);
+    const double rel2 = m.rel_tol * m.rel_tol * n0sq, abs2 = m.abs_tol * m.abs_tol;
+    const double phi_tr = ev.y.phi, i2mu = 0.5 / m.mu, three_mu = 3.0 * m.mu, alpha_p = xp[6];
+    double alpha = alpha_p, f = C[6], dH = ev.hd.dH;
+    int it = 0;
+    bool running = lane_valid, fallback = false;
+    uint32_t flags = 0;
+    for (;;) {
+        const double nsq = ev.plastic ? f * f : n0sq;            // elastic at the trial state: C_e(x_prev) = 0
+        const bool conv = (nsq < rel2) || (nsq < abs2);
+        if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
+        if (running && it >= m.max_iters) running = false;
+        if (!__any(running)) break;
+        if (running) {
+            alpha -= f * rcp(-(three_mu + dH) * i2mu);
+            const Hard hd = hardening(m, alpha);
+            f = (phi_tr - three_mu * (alpha - alpha_p) - (m.Y + hd.H)) * i2mu;
+            dH = hd.dH;
+            if (!((f > m.yield_tol) || (fabs(f) < m.yield_tol))) { fallback = true; running = false; }
+            ++it;
+        }
+    }
+    const double dgam = alpha - alpha_p;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = xp[k] + dgam * ev.y.gt[k] * kIW[k];
+    x[6] = alpha;
+    uint32_t st = flags | (uint32_t)it;
+    if (__any(fallback)) {
+        if (fallback) st = newton_s<CM_YIELD_J2, false>(m, eg, xp, x, lane_valid, ev);
+    }
+    if (!fallback) residual_s<CM_YIELD_J2>(m, eg, x, xp, ev, C);   // evaluation at the returned state (reverse sweep)
+    return st;
+}
+
 // ---- reverse sweep, structured (same contract as cm::reverse_point, DEF = FULL_3D) ---------------------------
 template <int YK, bool HAVE_EV = false>
 CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp,
@@ -410,6 +458,9 @@ template <int DEF, int YK, bool LS, bool STRUCT = true>
 CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid) {
     if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) {
         EvalS<YK> ev;
+        if constexpr (YK == CM_YIELD_J2 && !LS) {
+            if (m.solver_flags & CM_SOLVER_J2_RADIAL_LINE) return newton_j2_line(m, eg, xp, x, valid, ev);
+        }
         return newton_s<YK, LS>(m, eg, xp, x, valid, ev);
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, valid);

@@ -268,7 +268,13 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     constexpr bool SFAST = (DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN && (MODE == 1 || MODE == 3));
     EvalS<SFAST ? YK : CM_YIELD_J2> evs;
     if constexpr (MODE == 1 || MODE == 3) {
-        if constexpr (SFAST) newton_s<YK, LS>(m, eg, xp, x, valid, evs);
+        if constexpr (SFAST) {
+            bool done = false;
+            if constexpr (YK == CM_YIELD_J2 && !LS) {
+                if (m.solver_flags & CM_SOLVER_J2_RADIAL_LINE) { newton_j2_line(m, eg, xp, x, valid, evs); done = true; }
+            }
+            if (!done) newton_s<YK, LS>(m, eg, xp, x, valid, evs);
+        }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);

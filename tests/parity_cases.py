@@ -270,3 +270,16 @@ def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed
         plastic_seen = max(plastic_seen, (it_o > 0).mean())
         xp, g_prev = xi_o, g
     assert plastic_seen > 0.2
+
+
+def check_j2_radial_line(backend, B=4096, rot=False):
+    """Opt-in J2 radial-line Newton (CM_SOLVER_J2_RADIAL_LINE): same states, stresses AND iteration counts as
+    the general 7-dof Newton of the oracle, two load steps from a hardened previous state."""
+    sc = Scenario(ol.FULL_3D, "J2", {}, rot, False, B=B)
+    sc.desc.solver_flags = 1
+    check_update(backend, sc)
+    for gradu, xp, it_o in ((sc.gradu0, sc.xi0, sc.it1), (sc.gradu, sc.xi1, sc.it2)):
+        _, _, status = backend.update(sc, gradu, xp)
+        it_d = (status.astype(np.uint32) & 0xFFFF).astype(np.int32)
+        assert np.mean(it_d == it_o) > 0.99, np.bincount(np.abs(it_d - it_o))
+    check_vjp(backend, sc)

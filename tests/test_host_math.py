@@ -197,3 +197,10 @@ def test_rate_model_explicit_blocks(def_type, yield_kind, kw, rot, solver_varian
                                            rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(Jo).max()), err_msg=str(path))
         xp, gp = xi, g
     assert nplastic > 0
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_j2_radial_line_newton_matches_general_path(rot, solver_variant):
+    if solver_variant == "dense":
+        pytest.skip("specialisation of the structured path")
+    pc.check_j2_radial_line(BACKEND, B=2048, rot=rot)
