@@ -278,7 +278,9 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 #pragma unroll
         for (int k = 0; k < 6; ++k) qq += s[k] * As[k];
         phi = sqrt(qq);
-        const double ip = rcp(phi);
+        // zero stress: the reference's normal is NaN there and hidden by the branch select (phi = 0 is always
+        // elastic); it is defined as 0 here so that nothing downstream has to be guarded
+        const double ip = (qq > 0.0) ? rcp(phi) : 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) gt[k] = As[k] * ip;
         if constexpr (HESS) {
@@ -300,19 +302,20 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
         const double dd[3] = {s[0] - s[3], s[3] - s[5], s[5] - s[0]};
         const double t0 = fabs(dd[0]), t1 = fabs(dd[1]), t2 = fabs(dd[2]);
         const double mx = fmax(t0, fmax(t1, t2));
-        const double u[3] = {t0 / mx, t1 / mx, t2 / mx};
+        const double imx = (mx > 0.0) ? 1.0 / mx : 0.0;             // equal normal stresses: phi = 0, normal := 0
+        const double u[3] = {t0 * imx, t1 * imx, t2 * imx};
         // u_i^a = exp(a log u_i) (u_i in [0,1]); (|d_i|/phi)^(a-2) = u_i^a Sr^2 / (u_i^2 S) -- no further pow
         double ua[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) ua[i] = (u[i] > 0.0) ? exp(a * log(u[i])) : 0.0;
         const double S = 0.5 * (ua[0] + ua[1] + ua[2]);
-        const double Sr = exp(log(S) / a);
+        const double Sr = (S > 0.0) ? exp(log(S) / a) : 0.0;
         phi = mx * Sr;
         double p[3], r[3], sg[3], ram2[3];
-        const double c2 = Sr * Sr / S;
+        const double c2 = (S > 0.0) ? Sr * Sr / S : 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            r[i] = u[i] / Sr;                                  // |d_i| / phi
+            r[i] = (S > 0.0) ? u[i] / Sr : 0.0;                 // |d_i| / phi
             sg[i] = (dd[i] > 0.0) ? 1.0 : ((dd[i] < 0.0) ? -1.0 : 0.0);
             ram2[i] = (u[i] > 0.0) ? ua[i] * c2 / (u[i] * u[i]) : ((a == 2.0) ? 1.0 : 0.0);
             p[i] = 0.5 * ram2[i] * r[i] * sg[i];               // d phi / d d_i
@@ -326,7 +329,7 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 #pragma unroll
                 for (int l = 0; l < 6; ++l) Ht[k][l] = 0.0;
             double Hd[3][3];
-            const double ip = 1.0 / phi;
+            const double ip = (phi > 0.0) ? 1.0 / phi : 0.0;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll

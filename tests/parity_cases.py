@@ -283,3 +283,48 @@ def check_j2_radial_line(backend, B=4096, rot=False):
         it_d = (status.astype(np.uint32) & 0xFFFF).astype(np.int32)
         assert np.mean(it_d == it_o) > 0.99, np.bincount(np.abs(it_d - it_o))
     check_vjp(backend, sc)
+
+
+def check_edge_cases(backend):
+    """Zero strain (sigma = 0: the reference's normal is NaN there and masked by the branch select), iteration cap
+    reached without convergence (the reference returns the last iterate silently; status reports it), and a
+    very large strain increment."""
+    from cmad_amd.models.device import NewtonSettings, build_desc
+
+    class S:
+        pass
+    values = ol.j2_voce_values()
+    # --- zero / tiny strain
+    sc = S(); sc.mat = ol.Material(values); sc.desc, sc.info = build_desc(values)
+    B = 130
+    g = np.zeros((9, B)); g[0, 1::2] = 1e-300
+    xp = np.zeros((7, B))
+    xi, sig, status = backend.update(sc, g, xp)
+    assert np.isfinite(xi).all() and np.isfinite(sig).all() and not xi.any()
+    assert ((status.astype(np.uint32) & 0xFFFF) == 0).all() and ((status.astype(np.uint32) >> 16) & 1).all()
+    sb = np.ones((6, B))
+    gk, xb, ub = backend.vjp(sc, g, xp, xi, sb)
+    assert np.isfinite(gk).all() and np.isfinite(xb).all() and np.isfinite(ub).all()
+    # --- iteration cap: 1 and 2 iterations only
+    from cmad_amd.synthetic import gauss_point_batch
+    g = gauss_point_batch(512, seed=9, dev_scale=8.0)
+    xp = np.zeros((7, 512))
+    for cap in (1, 2):
+        sc = S(); sc.mat = ol.Material(values)
+        sc.desc, sc.info = build_desc(values, newton=NewtonSettings(max_iters=cap))
+        xi_o, sig_o, it_o, cv_o = sc.mat.update_batch(ol.newton_settings(max_iters=cap), g, xp)
+        xi_d, sig_d, status = backend.update(sc, g, xp)
+        status = status.astype(np.uint32)
+        np.testing.assert_allclose(xi_d, xi_o, rtol=1e-10, atol=1e-13)          # same (unconverged) iterate
+        assert ((status & 0xFFFF) == it_o).all() and (it_o.max() == cap)
+        assert (((status >> 16) & 1) == cv_o).all() and (cv_o == 0).any()
+    # --- 20 x yield strain in one step, Hill with line search
+    hv = ol.j2_voce_values(yield_kind="hill", hill=HILL)
+    st_o, st_d = settings_pair(True)
+    sc = S(); sc.mat = ol.Material(hv); sc.desc, sc.info = build_desc(hv, newton=st_d)
+    g = gauss_point_batch(512, seed=10, dev_scale=20.0)
+    xi_o, sig_o, it_o, cv_o = sc.mat.update_batch(st_o, g, xp)
+    xi_d, sig_d, status = backend.update(sc, g, xp)
+    ok = cv_o.astype(bool) & ((status.astype(np.uint32) >> 16) & 1).astype(bool)
+    assert ok.mean() > 0.99
+    np.testing.assert_allclose(xi_d[:, ok], xi_o[:, ok], rtol=1e-10, atol=1e-11)

@@ -132,3 +132,7 @@ def test_j2_radial_line_newton_matches_general_path(backend, rot):
     np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(b[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-10, atol=1e-8)
     np.testing.assert_allclose(b[2].cpu().numpy(), a[2].cpu().numpy(), rtol=1e-9, atol=1e-9 * a[2].abs().max().item())
+
+
+def test_edge_cases(backend):
+    pc.check_edge_cases(backend)

@@ -204,3 +204,7 @@ def test_j2_radial_line_newton_matches_general_path(rot, solver_variant):
     if solver_variant == "dense":
         pytest.skip("specialisation of the structured path")
     pc.check_j2_radial_line(BACKEND, B=2048, rot=rot)
+
+
+def test_edge_cases():
+    pc.check_edge_cases(BACKEND)
