@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "cm_structured.hpp"
+#include "cm_hessian.hpp"
 
 // The library can be built from this one file in four independent pieces (hipcc -DCM_PART=0..3, see
 // cmad_amd/build.py) so the template instantiations compile in parallel; without CM_PART everything is one TU.
@@ -397,6 +398,36 @@ __global__ __launch_bounds__(64) void k_evaluate_rate(cm_model_desc m, int64_t B
     }
 }
 
+// ---- cm_hessians: one thread per (point, pair of differentiation variables) -----------------------------------
+template <int DEF, int YK, bool ROT>
+__global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi,
+        double* __restrict__ d2C, double* __restrict__ d2S, double* __restrict__ dC, double* __restrict__ dS) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS, NPAIR = NQ * (NQ + 1) / 2;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * NPAIR) return;
+    const int64_t pt = tid / NPAIR;
+    int rem = (int)(tid % NPAIR), a = 0;
+    while (rem >= NQ - a) { rem -= NQ - a; ++a; }         // pairs (a, b >= a) in row-major order
+    const int b = a + rem;
+    double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6];
+    for (int k = 0; k < NU; ++k) G[k] = gradu[(int64_t)k * B + pt];
+    for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + pt]; x[k] = xi[(int64_t)k * B + pt]; }
+    hessian_pair<DEF, YK, ROT>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
+    if (d2C) for (int k = 0; k < NX; ++k) {
+        d2C[((pt * NX + k) * NQ + a) * NQ + b] = oC[k];
+        d2C[((pt * NX + k) * NQ + b) * NQ + a] = oC[k];
+    }
+    if (d2S) for (int k = 0; k < 6; ++k) {
+        d2S[((pt * 6 + k) * NQ + a) * NQ + b] = oS[k];
+        d2S[((pt * 6 + k) * NQ + b) * NQ + a] = oS[k];
+    }
+    if (a == b) {
+        if (dC) for (int k = 0; k < NX; ++k) dC[(pt * NX + k) * NQ + a] = oCa[k];
+        if (dS) for (int k = 0; k < 6; ++k) dS[(pt * 6 + k) * NQ + a] = oSa[k];
+    }
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 
@@ -635,6 +666,28 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
     const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
         hipLaunchKernelGGL((k_evaluate_rate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, gradu_prev, xi_prev, xi,
                            C, jac, sigma, dsigma);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+#endif
+
+#if CM_HAS_PART(1)
+int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                double* d2C, double* d2S, double* dC, double* dS, void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m) || m->yield_kind == CM_YIELD_HYBRID_HILL_NN) return CM_ERR_UNSUPPORTED;
+    if (B == 0) return CM_OK;
+    if (!gradu || !xi_prev || !xi) return CM_ERR_BAD_ARG;
+    const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
+    const int64_t nthreads = B * (int64_t)(nq * (nq + 1) / 2);
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (Y != CM_YIELD_HYBRID_HILL_NN)
+            hipLaunchKernelGGL((k_hessians<D, Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, d2C, d2S, dC, dS);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();

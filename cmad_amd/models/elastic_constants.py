@@ -119,3 +119,46 @@ def lame_jacobian(elastic: dict):
     ec = ElasticConstants.from_params(seeded)
     lm, mu = _D2._c(ec.lmbda), _D2._c(ec.mu)
     return names, lm.v, mu.v, np.array([lm.d, mu.d])
+
+
+class _HD:
+    """Minimal hyper-dual (value, d/da, d/db, d2/dadb) for the second-order chain rule of the elastic pair."""
+    __slots__ = ("v", "a", "b", "ab")
+
+    def __init__(self, v, a=0., b=0., ab=0.):
+        self.v, self.a, self.b, self.ab = float(v), float(a), float(b), float(ab)
+
+    @staticmethod
+    def _c(o):
+        return o if isinstance(o, _HD) else _HD(o)
+
+    def __add__(self, o): o = self._c(o); return _HD(self.v + o.v, self.a + o.a, self.b + o.b, self.ab + o.ab)
+    __radd__ = __add__
+    def __neg__(self): return _HD(-self.v, -self.a, -self.b, -self.ab)
+    def __sub__(self, o): return self + (-self._c(o))
+    def __rsub__(self, o): return self._c(o) - self
+    def __mul__(self, o):
+        o = self._c(o)
+        return _HD(self.v * o.v, self.a * o.v + self.v * o.a, self.b * o.v + self.v * o.b,
+                   self.ab * o.v + self.a * o.b + self.b * o.a + self.v * o.ab)
+    __rmul__ = __mul__
+    def _chain(self, g0, g1, g2): return _HD(g0, g1 * self.a, g1 * self.b, g1 * self.ab + g2 * self.a * self.b)
+    def __truediv__(self, o): o = self._c(o); i = 1. / o.v; return self * o._chain(i, -i * i, 2. * i ** 3)
+    def __rtruediv__(self, o): return self._c(o) / self
+    def __pow__(self, n): return self._chain(self.v ** n, n * self.v ** (n - 1), n * (n - 1) * self.v ** (n - 2))
+    def sqrt(self): r = np.sqrt(self.v); return self._chain(r, 0.5 / r, -0.25 / (r * self.v))
+
+
+def lame_second_derivs(elastic: dict):
+    """H[i, j, k] = d2 (lmbda, mu)[i] / d elastic[names[j]] d elastic[names[k]]  (names as in lame_jacobian)."""
+    names = tuple(n for n in _CONSTANT_NAMES if n in elastic)
+    H = np.zeros((2, 2, 2))
+    for j in range(2):
+        for k in range(j, 2):
+            seeded = {n: _HD(elastic[n]) for n in names}
+            seeded[names[j]].a = 1.0
+            seeded[names[k]].b = 1.0
+            ec = ElasticConstants.from_params(seeded)
+            for i, val in enumerate((_HD._c(ec.lmbda), _HD._c(ec.mu))):
+                H[i, j, k] = H[i, k, j] = val.ab
+    return names, H

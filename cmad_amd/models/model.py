@@ -109,7 +109,8 @@ class Model(ABC):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if self._model_kind == 1:
             Gp = np.zeros_like(G) if U_prev is None else np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
-            rc = L.cm_evaluate_rate(C.byref(desc), 1, int(which), _ptr(g), _ptr(t(Gp)), _ptr(x0), _ptr(x1), _ptr(Cd),
+            gp = t(Gp)                                    # named: must outlive the launch
+            rc = L.cm_evaluate_rate(C.byref(desc), 1, int(which), _ptr(g), _ptr(gp), _ptr(x0), _ptr(x1), _ptr(Cd),
                                     _ptr(J), _ptr(s), _ptr(S), stream)
             _lib.check(rc, "cm_evaluate_rate")
         else:
@@ -146,8 +147,64 @@ class Model(ABC):
             _, J, _, _, _ = self._point_evaluate(mode, xi, xi_prev, params, U, U_prev=U_prev)
             self._Jac = J
 
+    # ------------------------------------------------------------------ reference :245-270
+    def _param_chain(self, info):
+        """First- and second-order maps from the kernel's KP parameters to the active parameters:
+        T1[kp, i] = d kp / d p_i ; T2[kp, i, j] = d2 kp / d p_i d p_j (non-zero only for lambda, mu)."""
+        from .elastic_constants import lame_second_derivs
+        from .device import HILL_NAMES
+        paths = self.parameters.active_paths()
+        P = len(paths)
+        T1 = np.zeros((_lib.CM_NUM_PARAMS, P)); T2 = np.zeros((_lib.CM_NUM_PARAMS, P, P))
+        names, H = lame_second_derivs(self.parameters.values["elastic"])
+        el_pos = {}
+        for i, path in enumerate(paths):
+            unit = np.zeros(_lib.CM_NUM_PARAMS)
+            for kp in range(_lib.CM_NUM_PARAMS):
+                unit[:] = 0.0; unit[kp] = 1.0
+                T1[kp, i] = kp_to_leaf_grad(path[:-1] if isinstance(path[-1], int) else path, unit, info)
+            if path[0] == "elastic":
+                el_pos[i] = info["elastic_names"].index(path[-1])
+        for i, ji in el_pos.items():
+            for k, jk in el_pos.items():
+                T2[_lib.P_LAMBDA, i, k] = H[0, ji, jk]
+                T2[_lib.P_MU, i, k] = H[1, ji, jk]
+        return T1, T2
+
+    def _second_derivative_pass(self):
+        """cm_hessians for the gathered state -> raw arrays w.r.t. q = [xi, xi_prev, p(KP)]."""
+        import torch
+        if self._model_kind != 0 or self._hybrid is not None:
+            raise NotImplementedError("second derivatives are built for the total-form model with J2 / Hill / Hosford")
+        xi, xi_prev, params, U, U_prev = self.variables()
+        desc, info = self._desc(params)
+        L = _lib.lib()
+        nx, nu = L.cm_num_xi(C.byref(desc)), L.cm_num_gradu(C.byref(desc))
+        nq = 2 * nx + _lib.CM_NUM_PARAMS
+        dev = torch.device("cuda")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).to(dev)
+        G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        d2C, d2S, dC, dS = e(nx, nq, nq), e(6, nq, nq), e(nx, nq), e(6, nq)
+        g, x0, x1 = t(G), t(self._flat(xi_prev)), t(self._flat(xi))       # keep the inputs alive across the launch
+        rc = L.cm_hessians(C.byref(desc), 1, _ptr(g), _ptr(x0), _ptr(x1),
+                           _ptr(d2C), _ptr(d2S), _ptr(dC), _ptr(dS), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "cm_hessians")
+        return d2C.cpu().numpy(), d2S.cpu().numpy(), dC.cpu().numpy(), dS.cpu().numpy(), info, nx
+
     def evaluate_hessians(self) -> None:
-        raise NotImplementedError("second derivatives of the residual are a SURVEY section 8(f) 'next' row")
+        """Evaluate the Hessians of the residual (reference :245-270): d2C_dxi2, d2C_dxi_dxi_prev, d2C_dxi_prev2
+        (n, n_xi, n_xi), d2C_dxi_dparams, d2C_dxi_prev_dparams (n, n_xi, P), d2C_dparams2 (n, P, P)."""
+        d2C, d2S, dC, dS, info, nx = self._second_derivative_pass()
+        T1, T2 = self._param_chain(info)
+        a, b, c = slice(0, nx), slice(nx, 2 * nx), slice(2 * nx, None)
+        self.d2C_dxi2 = d2C[:, a, a]
+        self.d2C_dxi_dxi_prev = d2C[:, a, b]
+        self.d2C_dxi_prev2 = d2C[:, b, b]
+        self.d2C_dxi_dparams = np.einsum("qkp,pi->qki", d2C[:, a, c], T1)
+        self.d2C_dxi_prev_dparams = np.einsum("qkp,pi->qki", d2C[:, b, c], T1)
+        self.d2C_dparams2 = np.einsum("qpr,pi,rj->qij", d2C[:, c, c], T1, T1) + np.einsum("qp,pij->qij", dC[:, c], T2)
+        self._hessian_cache = (d2S, dS, T1, T2, nx)
 
     # ------------------------------------------------------------------ reference :273-293
     def evaluate_cauchy(self) -> None:

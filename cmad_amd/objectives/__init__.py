@@ -1,2 +1,2 @@
 from .batched import BatchedCalibrationObjective, shard_bounds  # noqa: F401
-from .mp_objective import MPAdjointObjective, MPDirectObjective, MPObjective  # noqa: F401
+from .mp_objective import MPAdjointObjective, MPDirectAdjointObjective, MPDirectObjective, MPObjective  # noqa: F401

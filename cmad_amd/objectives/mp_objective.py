@@ -120,8 +120,68 @@ class MPDirectObjective(MPObjective):
 
 
 class MPDirectAdjointObjective(MPObjective):
-    """Gradient + Hessian (reference :218-345): needs second derivatives of the residual -- a SURVEY
-    section 8(f) 'next' row."""
+    """Gradient + Hessian via the direct-adjoint method (reference :218-345, arXiv:2501.04584): adjoint pass
+    storing phi per step, then a forward sensitivity pass contracting the second derivatives of the residual
+    (`model.evaluate_hessians()`, cm_hessians) and of the QoI with dxi/dp -- the reference's 13 einsum terms."""
 
     def _evaluate(self):
-        raise NotImplementedError("Hessian objective not built yet (SURVEY section 8(f))")
+        from ..typing import HessianResult
+        qoi, model, F = self._qoi, self._model, self._global_state
+        xi_at_step, num_steps = self._xi_at_step, self._num_steps
+        J = self._forward_pass_with_storage()
+        nap = model.parameters.num_active_params
+        grad = np.zeros((1, nap))
+        num_dofs = model.num_dofs
+        history_vec = np.zeros((num_dofs, 1))
+        phi_at_step = [np.zeros(num_dofs)] * (num_steps + 1)
+        for step in range(num_steps, 0, -1):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            model.gather_xi(xi_at_step[step], xi_at_step[step - 1])
+            model.seed_xi(); model.evaluate()
+            dC_dxi = model.Jac()
+            qoi.evaluate(step)
+            phi = np.linalg.solve(dC_dxi.T, -qoi.dJ().T + history_vec)
+            phi_at_step[step] = phi.squeeze()
+            model.seed_xi_prev(); model.evaluate()
+            history_vec = -model.Jac().T @ phi
+            model.seed_params(); model.evaluate()
+            dC_dp = model.Jac()
+            qoi.evaluate(step)
+            grad += phi.T @ dC_dp + qoi.dJ()
+        grad = grad.squeeze()
+        untransformed_grad = grad.copy()
+        model.parameters.transform_grad(grad)
+
+        hessian = np.zeros((nap, nap))
+        dxi_dp_prev = np.zeros((num_dofs, nap))
+        for step in range(1, num_steps + 1):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            model.gather_xi(xi_at_step[step], xi_at_step[step - 1])
+            model.seed_xi(); model.evaluate(); dC_dxi = model.Jac()
+            model.seed_xi_prev(); model.evaluate(); dC_dxi_prev = model.Jac()
+            model.seed_params(); model.evaluate(); dC_dp = model.Jac()
+            dxi_dp = np.linalg.solve(dC_dxi, -dC_dp - dC_dxi_prev @ dxi_dp_prev)
+            model.evaluate_hessians()
+            d2C_dxi2, d2C_dxi_dxi_prev, d2C_dxi_prev2 = model.d2C_dxi2, model.d2C_dxi_dxi_prev, model.d2C_dxi_prev2
+            d2C_dp2 = model.d2C_dparams2
+            d2C_dp_dxi = model.d2C_dxi_dparams.transpose((0, 2, 1))
+            d2C_dp_dxi_prev = model.d2C_dxi_prev_dparams.transpose((0, 2, 1))
+            qoi.evaluate_hessians(step)
+            d2J_dxi2, d2J_dp2, d2J_dp_dxi = qoi.d2J_dxi2, qoi.d2J_dparams2, qoi.d2J_dxi_dparams.T
+            phi = phi_at_step[step]
+            hessian += d2J_dp2 \
+                + np.einsum("q,qij->ij", phi, d2C_dp2) \
+                + np.einsum("ik,kj->ij", d2J_dp_dxi, dxi_dp) \
+                + np.einsum("q,qik,kj->ij", phi, d2C_dp_dxi, dxi_dp) \
+                + np.einsum("jk,ki->ij", d2J_dp_dxi, dxi_dp) \
+                + np.einsum("q,qjk,ki->ij", phi, d2C_dp_dxi, dxi_dp) \
+                + np.einsum("km,ki,mj->ij", d2J_dxi2, dxi_dp, dxi_dp) \
+                + np.einsum("q,qkm,ki,mj->ij", phi, d2C_dxi2, dxi_dp, dxi_dp) \
+                + np.einsum("q,qik,kj->ij", phi, d2C_dp_dxi_prev, dxi_dp_prev) \
+                + np.einsum("q,qkm,ki,mj->ij", phi, d2C_dxi_dxi_prev, dxi_dp, dxi_dp_prev) \
+                + np.einsum("q,qmk,ki,mj->ij", phi, d2C_dxi_dxi_prev, dxi_dp_prev, dxi_dp) \
+                + np.einsum("q,qkm,ki,mj->ij", phi, d2C_dxi_prev2, dxi_dp_prev, dxi_dp_prev) \
+                + np.einsum("q,qjk,ki->ij", phi, d2C_dp_dxi_prev, dxi_dp_prev)
+            dxi_dp_prev = dxi_dp
+        model.parameters.transform_hessian(hessian, untransformed_grad)
+        return HessianResult(J=J, grad=grad, hessian=hessian)

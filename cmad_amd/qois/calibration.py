@@ -53,3 +53,24 @@ class Calibration(QoI):
                 ds = ds.reshape(3, 3, -1)                      # (9, P) -> (3, 3, P)
             self._dJ = np.atleast_2d(np.einsum("ij,ijk->k", w * mismatch, ds))
         model._deriv_mode = saved[0]
+
+    def evaluate_hessians(self, step) -> None:
+        """d2J_dxi2 (n_xi, n_xi), d2J_dxi_dparams (n_xi, P), d2J_dparams2 (P, P) of qoi.py:160-188.
+        The mixed block is the true d2J/dxi dparams; the reference builds it from jacfwd(..., DXI_PREV)
+        (qoi.py:51-53), which is identically zero -- the two agree whenever the stress does not depend on the
+        active parameters (flow-stress calibration, every reference test)."""
+        from ..models.device import fold_weight_and_data
+        model = self._model
+        d2C, d2S, dC, dS, info, nx = model._second_derivative_pass()
+        T1, T2 = model._param_chain(info)
+        wsq6, data6, _ = fold_weight_and_data(self.weight_at_step(step), self.data_at_step(step)[:, :, None])
+        model.seed_none(); model.evaluate_cauchy()
+        S = model.Sigma()
+        s6 = np.array([S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]])
+        r = wsq6 * (s6 - data6[:, 0])
+        Hq = np.einsum("r,ra,rb->ab", wsq6, dS, dS) + np.einsum("r,rab->ab", r, d2S)
+        gq = r @ dS
+        a, c = slice(0, nx), slice(2 * nx, None)
+        self.d2J_dxi2 = Hq[a, a]
+        self.d2J_dxi_dparams = Hq[a, c] @ T1
+        self.d2J_dparams2 = T1.T @ Hq[c, c] @ T1 + np.einsum("p,pij->ij", gq[c], T2)

@@ -212,6 +212,19 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which,
                      const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                      double* C, double* jac, double* sigma, double* dsigma, void* stream);
 
+/*
+ * cm_hessians: second derivatives of the residual and of the global stress at given states w.r.t.
+ * q = [xi (n_xi), xi_prev (n_xi), p (CM_NUM_PARAMS, KP order, native lambda/mu)], n_q = 2 n_xi + CM_NUM_PARAMS.
+ * Replaces Model.evaluate_hessians() (cmad/models/model.py:133-147, 245-270: jax.hessian / jacrev(jacfwd) of
+ * the residual) and the stress part of QoI.evaluate_hessians() (cmad/qois/qoi.py:160-188), total-form model,
+ * J2 / Hill / Hosford.  Outputs are point-major (array of structures; B is small for this call), row-major:
+ *   d2C[B][n_xi][n_q][n_q], d2S[B][6][n_q][n_q], dC[B][n_xi][n_q], dS[B][6][n_q]      (any may be NULL)
+ * dC / dS are the first derivatives produced by the same pass (for cross-checks against cm_evaluate).
+ */
+int cm_hessians(const cm_model_desc* m, int64_t B,
+                const double* gradu, const double* xi_prev, const double* xi,
+                double* d2C, double* d2S, double* dC, double* dS, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,39 @@
+"""TEST INFRASTRUCTURE: the cmad_amd facade classes with their three device entry points re-routed to the host
+build of the same kernel arithmetic (tests/native).  Lets CPU CI exercise the Python-side logic of
+Model / QoI / objectives (block slicing, parameter chain rules, the 13-term Hessian contraction) without a GPU.
+Never imported by the product."""
+import numpy as np
+
+import host_harness_lib as hh
+from cmad_amd import _lib
+from cmad_amd.models import SmallElasticPlastic
+from cmad_amd.models.deriv_types import DerivType
+from cmad_amd.models.device import NewtonSettings
+
+
+class HostSmallElasticPlastic(SmallElasticPlastic):
+    def _point_evaluate(self, which, xi, xi_prev, params, U, want_jac=True, U_prev=None):
+        desc, info = self._desc(params)
+        nx = self.num_dofs
+        G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
+        C, J, s, S = hh.evaluate(desc, int(which), G, self._flat(xi_prev).reshape(-1, 1), self._flat(xi).reshape(-1, 1), nx)
+        if which == DerivType.DNONE or not want_jac:
+            return C[:, 0], None, s[:, 0], None, info
+        return C[:, 0], J[:, :, 0], s[:, 0], S[:, :, 0], info
+
+    def device_newton(self, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search=None):
+        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0})
+        desc, info = self._desc(newton=st)
+        G = np.asarray(self._U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
+        xi, sig, status = hh.update(desc, G, self._flat(self._xi_prev).reshape(-1, 1), self.num_dofs)
+        self._xi = [b.astype(self.dtype) for b in self._split(xi[:, 0])]
+        s = int(status[0])
+        return s & _lib.STATUS_ITERS_MASK, bool(s & _lib.STATUS_CONVERGED)
+
+    def _second_derivative_pass(self):
+        xi, xi_prev, params, U, U_prev = self.variables()
+        desc, info = self._desc(params)
+        nx = self.num_dofs
+        G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
+        d2C, d2S, dC, dS = hh.hessians(desc, G, self._flat(xi_prev).reshape(-1, 1), self._flat(xi).reshape(-1, 1), nx)
+        return d2C[0], d2S[0], dC[0], dS[0], info, nx

@@ -6,6 +6,7 @@
 #include <cstring>
 #define CM_HOST_BUILD 1
 #include "../../cmad_amd/csrc/cm_structured.hpp"
+#include "../../cmad_amd/csrc/cm_hessian.hpp"
 
 using namespace cm;
 
@@ -130,6 +131,28 @@ static void run_evaluate_rate(const cm_model_desc& m, int64_t B, int which, cons
     }
 }
 
+template <int DEF, int YK, bool ROT>
+static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                         double* d2C, double* d2S, double* dC, double* dS) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
+    if constexpr (YK != CM_YIELD_HYBRID_HILL_NN) {
+        for (int64_t pt = 0; pt < B; ++pt) {
+            double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6];
+            for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt];
+            for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + pt]; x[k] = xi[k * B + pt]; }
+            for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
+                hessian_pair<DEF, YK, ROT>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
+                for (int k = 0; k < NX; ++k) { d2C[((pt * NX + k) * NQ + a) * NQ + b] = oC[k]; d2C[((pt * NX + k) * NQ + b) * NQ + a] = oC[k]; }
+                for (int k = 0; k < 6; ++k) { d2S[((pt * 6 + k) * NQ + a) * NQ + b] = oS[k]; d2S[((pt * 6 + k) * NQ + b) * NQ + a] = oS[k]; }
+                if (a == b) {
+                    for (int k = 0; k < NX; ++k) dC[(pt * NX + k) * NQ + a] = oCa[k];
+                    for (int k = 0; k < 6; ++k) dS[(pt * 6 + k) * NQ + a] = oSa[k];
+                }
+            }
+        }
+    }
+}
+
 template <bool UNI = false, class F>
 static int dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity;
@@ -168,6 +191,10 @@ int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
 int hh_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                      const double* xi_prev, const double* xi, double* C, double* J, double* s, double* S) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_evaluate_rate<D, Y, R>(*m, B, which, gradu, gradu_prev, xi_prev, xi, C, J, s, S); });
+}
+int hh_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                double* d2C, double* d2S, double* dC, double* dS) {
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_hessians<D, Y, R>(*m, B, gradu, xi_prev, xi, d2C, d2S, dC, dS); });
 }
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {

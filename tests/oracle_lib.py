@@ -77,6 +77,7 @@ def lib():
         L.orc_newton.argtypes = [C.POINTER(Desc), C.POINTER(Newton)] + [dp] * 6 + [C.POINTER(C.c_int)]
         L.orc_newton.restype = C.c_int
         L.orc_solve.argtypes = [C.c_int, dp, dp, C.c_int]
+        L.orc_second_derivs.argtypes = [C.POINTER(Desc), dp, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp]
         L.orc_update_batch.argtypes = [C.POINTER(Desc), C.POINTER(Newton), dp, C.c_int64,
                                        dp, dp, dp, dp, dp, ip, ip, C.c_int]
         L.orc_tangent_batch.argtypes = [C.POINTER(Desc), dp, C.c_int64, dp, dp, dp, dp, dp, dp, C.c_int]
@@ -210,6 +211,20 @@ class Material:
         out = np.zeros((9, self.ncols(which)))
         lib().orc_dcauchy(C.byref(self.desc), which, _p(f64(xi)), _p(f64(xi_prev)), _p(self.p), _p(U), _p(Up), _p(out))
         return out
+
+    def second_derivs(self, xi, xi_prev, U, Up=None):
+        """d2C (nx, nq, nq) and d2S (9, nq, nq) w.r.t. q = [xi, xi_prev, p (oracle order, NP)]."""
+        U, Up = self._uu(U, Up)
+        nq = 2 * self.nx + NP
+        d2C = np.zeros((self.nx, nq, nq)); d2S = np.zeros((9, nq, nq))
+        c, s9 = np.zeros(self.nx), np.zeros(9)
+        xi, xi_prev = f64(xi), f64(xi_prev)
+        for a in range(nq):
+            for b in range(a, nq):
+                lib().orc_second_derivs(C.byref(self.desc), _p(xi), _p(xi_prev), _p(self.p), _p(U), _p(Up), a, b, _p(c), _p(s9))
+                d2C[:, a, b] = c; d2C[:, b, a] = c
+                d2S[:, a, b] = s9; d2S[:, b, a] = s9
+        return d2C, d2S
 
     def yield_state(self, xi, U):
         U, _ = self._uu(U, None)

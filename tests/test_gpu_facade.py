@@ -344,3 +344,80 @@ def test_rate_model_calibration_recovers_truth():
     opt, fval, info = fmin_l_bfgs_b(lambda x: tuple(obj.evaluate(x)), x0, bounds=model.parameters.opt_bounds, factr=10)
     model.parameters.set_active_values_from_flat(opt)
     assert np.linalg.norm(model.parameters.flat_active_values() - true_params) < 1e-6
+
+
+def _hessian_problem(active_elastic=False, K=10):
+    from cmad_amd.models import DefType, SmallElasticPlastic
+    from cmad_amd.qois import Calibration
+    params = params_J2_voce()
+    if active_elastic:
+        import copy
+        from cmad_amd.parameters import Parameters
+        from cmad_amd.parameters.parameters import tree_map
+        values = params.values
+        flags = tree_map(lambda a: False, copy.deepcopy(values))
+        flags["elastic"] = {"E": True, "nu": True}
+        flags["plastic"]["flow stress"] = tree_map(lambda x: True, flags["plastic"]["flow stress"])
+        tr = tree_map(lambda a: None, copy.deepcopy(values))
+        tr["elastic"]["E"] = np.array([200e3])                 # log transform
+        tr["plastic"]["flow stress"]["initial yield"]["Y"] = np.array([200.])
+        tr["plastic"]["flow stress"]["hardening"]["voce"]["S"] = np.array([100., 300.])
+        tr["plastic"]["flow stress"]["hardening"]["voce"]["D"] = np.array([10., 30.])
+        params = Parameters(values, flags, tr)
+    F = plane_stress_F(0.02, K // 2)
+    model = SmallElasticPlastic(params, DefType.PLANE_STRESS)
+    cauchy = _compute_cauchy(model, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    rng = np.random.default_rng(22)
+    data = cauchy + rng.normal(0., 2., cauchy.shape)
+    qoi = Calibration(model, data, weight)
+    model.parameters.set_active_values_from_flat(1.1 * model.parameters.flat_active_values(False), False)
+    return model, qoi, F
+
+
+@pytest.mark.parametrize("active_elastic", [False, True])
+def test_direct_adjoint_hessian(active_elastic):
+    """tests/objectives/test_J2_fd_checks.py:66-98, 366-372: the Hessian of MPDirectAdjointObjective is
+    symmetric, matches central differences of the adjoint gradient, and its directional second derivative's FD
+    error drops by decades.  With E, nu active it also exercises the second-order elastic-constant chain."""
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectAdjointObjective
+    model, qoi, F = _hessian_problem(active_elastic)
+    x = model.parameters.flat_active_values(True)
+    J, grad, H = MPDirectAdjointObjective(qoi, F).evaluate(x)
+    Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
+    assert abs(J - Ja) <= 1e-12 * abs(J)
+    np.testing.assert_allclose(grad, ga, rtol=1e-10, atol=1e-12 * np.abs(ga).max())
+    np.testing.assert_allclose(H, H.T, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+    n = x.size
+    H_fd = np.zeros((n, n))
+    h = 1e-5
+    for k in range(n):
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        H_fd[:, k] = (MPAdjointObjective(qoi, F).evaluate(xp_).grad - MPAdjointObjective(qoi, F).evaluate(xm_).grad) / (2 * h)
+    np.testing.assert_allclose(H, H_fd, rtol=5e-5, atol=5e-6 * np.abs(H).max())
+    rng = np.random.default_rng(22)
+    d = rng.uniform(-1., 1., size=n)
+    ref = d @ H @ d
+    errs = []
+    for hh_ in np.logspace(-1, -4, 4):
+        Jp = MPAdjointObjective(qoi, F).evaluate(x + hh_ * d).J
+        Jm = MPAdjointObjective(qoi, F).evaluate(x - hh_ * d).J
+        errs.append(abs((Jp + Jm - 2. * J) / hh_ ** 2 - ref))
+    assert np.log10(max(errs) / min(errs)) > 3.0
+
+
+def test_evaluate_hessians_shapes_and_errors():
+    from cmad_amd.models import DefType, SmallElasticPlastic, SmallRateElasticPlastic, mp_U_from_F, newton_solve
+    m = SmallElasticPlastic(params_J2_voce(), DefType.FULL_3D)
+    G = np.diag([0.004, -0.001, -0.001])
+    m.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
+    newton_solve(m)
+    m.evaluate_hessians()
+    assert m.d2C_dxi2.shape == (7, 7, 7) and m.d2C_dxi_dxi_prev.shape == (7, 7, 7) and m.d2C_dxi_prev2.shape == (7, 7, 7)
+    assert m.d2C_dparams2.shape == (7, 3, 3) and m.d2C_dxi_dparams.shape == (7, 7, 3) and m.d2C_dxi_prev_dparams.shape == (7, 7, 3)
+    assert np.abs(m.d2C_dxi2).max() > 0
+    r = SmallRateElasticPlastic(params_J2_voce(), DefType.FULL_3D)
+    r.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
+    with pytest.raises(NotImplementedError):
+        r.evaluate_hessians()

@@ -1,0 +1,78 @@
+"""CPU coverage of the facade's Python logic (Model block slicing, parameter chain rules, QoI derivatives, the
+adjoint / direct / direct-adjoint objectives) with the device entry points re-routed to the host build of the
+kernel arithmetic (tests/host_facade.py).  The same scenarios run on the GPU in tests/test_gpu_facade.py."""
+import copy
+
+import numpy as np
+import pytest
+
+from host_facade import HostSmallElasticPlastic
+from problems import params_J2_voce, plane_stress_F
+
+
+def _cauchy_history(model, F):
+    from cmad_amd.models import mp_U_from_F, newton_solve
+    n = F.shape[2] - 1
+    cauchy = np.zeros((3, 3, n + 1))
+    model.set_xi_to_init_vals()
+    for step in range(1, n + 1):
+        model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+        newton_solve(model)
+        model.evaluate_cauchy()
+        cauchy[:, :, step] = model.Sigma().copy()
+        model.advance_xi()
+    return cauchy
+
+
+def _problem(active_elastic, K=8):
+    from cmad_amd.models import DefType
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.parameters.parameters import tree_map
+    from cmad_amd.qois import Calibration
+    params = params_J2_voce()
+    if active_elastic:
+        values = params.values
+        flags = tree_map(lambda a: False, copy.deepcopy(values))
+        flags["elastic"] = {"E": True, "nu": True}
+        flags["plastic"]["flow stress"] = tree_map(lambda x: True, flags["plastic"]["flow stress"])
+        tr = tree_map(lambda a: None, copy.deepcopy(values))
+        tr["elastic"]["E"] = np.array([200e3])
+        tr["plastic"]["flow stress"]["initial yield"]["Y"] = np.array([200.])
+        tr["plastic"]["flow stress"]["hardening"]["voce"]["S"] = np.array([100., 300.])
+        tr["plastic"]["flow stress"]["hardening"]["voce"]["D"] = np.array([10., 30.])
+        params = Parameters(values, flags, tr)
+    F = plane_stress_F(0.02, K // 2)
+    model = HostSmallElasticPlastic(params, DefType.PLANE_STRESS)
+    cauchy = _cauchy_history(model, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    data = cauchy + np.random.default_rng(22).normal(0., 2., cauchy.shape)
+    qoi = Calibration(model, data, weight)
+    model.parameters.set_active_values_from_flat(1.1 * model.parameters.flat_active_values(False), False)
+    return model, qoi, F
+
+
+@pytest.mark.parametrize("active_elastic", [False, True])
+def test_gradients_and_hessian(active_elastic):
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectAdjointObjective, MPDirectObjective
+    model, qoi, F = _problem(active_elastic)
+    x = model.parameters.flat_active_values(True)
+    J, grad, H = MPDirectAdjointObjective(qoi, F).evaluate(x)
+    Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
+    Jd, gd = MPDirectObjective(qoi, F).evaluate(x)
+    assert abs(J - Ja) <= 1e-12 * abs(J) and abs(J - Jd) <= 1e-12 * abs(J)
+    np.testing.assert_allclose(ga, gd, rtol=1e-9, atol=1e-11 * np.abs(ga).max())
+    np.testing.assert_allclose(grad, ga, rtol=1e-10, atol=1e-12 * np.abs(ga).max())
+    np.testing.assert_allclose(H, H.T, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+    n, h = x.size, 1e-5
+    H_fd = np.zeros((n, n))
+    for k in range(n):
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        H_fd[:, k] = (MPAdjointObjective(qoi, F).evaluate(xp_).grad - MPAdjointObjective(qoi, F).evaluate(xm_).grad) / (2 * h)
+    np.testing.assert_allclose(H, H_fd, rtol=5e-5, atol=5e-6 * np.abs(H).max())
+    g_fd = np.zeros(n)
+    for k in range(n):
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        g_fd[k] = (MPAdjointObjective(qoi, F).evaluate(xp_).J - MPAdjointObjective(qoi, F).evaluate(xm_).J) / (2 * h)
+    np.testing.assert_allclose(ga, g_fd, rtol=1e-5, atol=1e-7 * np.abs(ga).max())

@@ -208,3 +208,55 @@ def test_j2_radial_line_newton_matches_general_path(rot, solver_variant):
 
 def test_edge_cases():
     pc.check_edge_cases(BACKEND)
+
+
+@pytest.mark.parametrize("plastic", [True, False])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_variant):
+    """cm_hessians (hyper-dual evaluation of the residual in the product code) vs the oracle's nested duals:
+    every block of d2C and d2 sigma w.r.t. (xi, xi_prev, params), and the first derivatives of the same pass vs
+    the hand-derived cm_evaluate blocks."""
+    import numpy as np
+    import host_harness_lib as hh
+    from cmad_amd.models.device import build_desc
+    from test_oracle_vs_torch_ad import _state
+    if solver_variant == "dense":
+        pytest.skip("not solver dependent")
+    rng = np.random.default_rng(12)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng), **kw)
+    E, nu = values["elastic"]["E"], values["elastic"]["nu"]
+    values["elastic"] = {"lambda": E * nu / ((1 + nu) * (1 - 2 * nu)), "mu": E / (2 * (1 + nu))}   # KP == native
+    mat = ol.Material(values, def_type=def_type, uniaxial_idx=1)
+    desc, info = build_desc(values, def_type=def_type, uniaxial_stress_idx=1)
+    for _ in range(50):
+        xi, xp, U = _state(rng, mat, plastic)
+        if (mat.yield_state(xi, U)[1] > 0) == plastic:
+            break
+    nx = mat.nx
+    d2C, d2S, dC, dS = hh.hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    oC, oS = mat.second_derivs(xi, xp, U)
+    # KP index -> oracle p index (elastic stored as (mu, lambda) in the oracle's pair order)
+    kp2o = [ol.P_EL1, ol.P_EL0, ol.P_Y, ol.P_VOCE_S, ol.P_VOCE_D, ol.P_LIN_K] + [ol.P_YC + j for j in range(6)]
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in kp2o]
+    V6 = [0, 1, 2, 4, 5, 8]
+    refC = oC[:, qmap][:, :, qmap]
+    refS = oS[V6][:, qmap][:, :, qmap]
+    if yield_kind != "hill":                 # yc slots are unused for J2; Hosford's exponent is compared too
+        keep = list(range(2 * nx + 6)) + ([2 * nx + 6] if yield_kind == "hosford" else [])
+    else:
+        keep = list(range(2 * nx + 12))
+    sel = np.ix_(range(nx), keep, keep)
+    scale = max(1.0, np.abs(refC[sel]).max())
+    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * scale)
+    sel6 = np.ix_(range(6), keep, keep)
+    np.testing.assert_allclose(d2S[0][sel6], refS[sel6], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refS[sel6]).max()))
+    # first derivatives of the same pass == hand-derived blocks
+    for which, lo in ((0, 0), (1, nx)):
+        C_, J, s_, S = hh.evaluate(desc, which, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+        np.testing.assert_allclose(dS[0][:, lo:lo + nx], S[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(S).max()))
+    C_, J, s_, S = hh.evaluate(desc, 2, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    npar = 12 if yield_kind == "hill" else 6
+    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], J[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+    np.testing.assert_allclose(dS[0][:, 2 * nx:2 * nx + npar], S[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(S).max()))
