@@ -83,4 +83,5 @@ def make_newton_solve(residual, max_iters: int = 10, abs_tol: float = 1e-14, rel
         xi, _, _ = ev.update(t(np.asarray(U.grad_fields["u"])), t(model._flat(xi_prev)), want_sigma=False, want_status=False)
         return model._split(xi.cpu().numpy()[:, 0])
 
+    solve.model, solve.settings = model, settings          # read by MPJVPObjective
     return solve

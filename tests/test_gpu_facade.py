@@ -421,3 +421,25 @@ def test_evaluate_hessians_shapes_and_errors():
     r.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
     with pytest.raises(NotImplementedError):
         r.evaluate_hessians()
+
+
+def test_jvp_objective_agrees_with_direct_adjoint():
+    """tests/objectives/test_jvp_vs_original.py:31-97: J rtol 1e-12, grad 1e-9, Hessian 1e-8 between
+    MPDirectAdjointObjective (per-point evaluate blocks) and MPJVPObjective (batched update / adjoint kernels)."""
+    from cmad_amd.models import DefType, SmallElasticPlastic, make_newton_solve
+    from cmad_amd.objectives import MPDirectAdjointObjective, MPJVPObjective
+    from cmad_amd.qois import Calibration
+    F = plane_stress_F(0.02, 6)
+    truth = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+    cauchy = _compute_cauchy(truth, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    x0 = 0.1 * np.ones(3)
+    m1 = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+    J1, g1, H1 = MPDirectAdjointObjective(Calibration(m1, cauchy, weight), F).evaluate(x0)
+    m2 = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+    obj = MPJVPObjective(Calibration(m2, cauchy, weight), F, make_newton_solve(m2._residual))
+    J2, g2 = obj.evaluate_objective_and_grad(x0)
+    H2 = obj.evaluate_hessian(x0)
+    np.testing.assert_allclose(J1, J2, rtol=1e-10)
+    np.testing.assert_allclose(g1, g2, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(H1, H2, rtol=1e-8, atol=1e-8)
