@@ -443,3 +443,31 @@ def test_jvp_objective_agrees_with_direct_adjoint():
     np.testing.assert_allclose(J1, J2, rtol=1e-10)
     np.testing.assert_allclose(g1, g2, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(H1, H2, rtol=1e-8, atol=1e-8)
+
+
+# ---- `cmad` command line on the device (reference tests/cli/test_*_roundtrip.py) -------------------------------
+
+@pytest.mark.gpu
+def test_cli_primal_and_objective(tmp_path):
+    import cli_cases
+    from cmad_amd.cli.main import main
+    (tmp_path / "p").mkdir(); (tmp_path / "o").mkdir()
+    cli_cases.check_primal(main, tmp_path / "p")
+    cli_cases.check_objective(main, tmp_path / "o")
+
+
+@pytest.mark.gpu
+def test_cli_gradient_and_hessian_strategies(tmp_path):
+    import cli_cases
+    from cmad_amd.cli.main import main
+    (tmp_path / "g").mkdir(); (tmp_path / "h").mkdir()
+    cli_cases.check_gradient(main, tmp_path / "g", ["adjoint", "direct", "direct_adjoint", "jvp"])
+    cli_cases.check_hessian(main, tmp_path / "h", ["direct_adjoint", "jvp"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["adjoint", "jvp"])
+def test_cli_calibrate(tmp_path, kind):
+    import cli_cases
+    from cmad_amd.cli.main import main
+    cli_cases.check_calibrate(main, tmp_path, num_pts=50 if kind == "jvp" else 20, kind=kind)
