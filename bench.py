@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--j2-radial-line", action="store_true",
                     help="opt into CM_SOLVER_J2_RADIAL_LINE (same Newton iterates restricted to the radial line); "
                          "side measurement, never the default")
+    ap.add_argument("--ls-evals", type=int, default=0,
+                    help="J2 workloads: line-search evaluations per Newton iteration (0 = newton_solve defaults, "
+                         "4 = make_newton_solve defaults)")
     ap.add_argument("--workload", default="j2_update_vjp",
                     choices=["j2_update_vjp", "j2_update", "j2_objective_grad", "hosford_update", "hybrid_update"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
@@ -111,15 +114,16 @@ def main():
     wl = args.workload
     values = j2_voce_values()
     newton = NewtonSettings(j2_radial_line=args.j2_radial_line)   # newton_solve defaults: 10 iters, 1e-14, no line search
+    if args.ls_evals > 0:                          # make_newton_solve: same tolerances + Armijo line search
+        newton = NewtonSettings.traced(line_search_settings={"max evals": args.ls_evals})
     eps_y, hybrid, bytes_per_update = 1e-3, None, BYTES_PER_UPDATE
     if wl == "hosford_update":                     # configs[2]: notch_hosford.yaml material + solver settings
         from cmad_amd.synthetic import hosford_values
         values, eps_y = hosford_values(), 2e-3
         newton = NewtonSettings.traced(max_iters=500, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 100})
     elif wl == "hybrid_update":                    # configs[3]: hybrid Hill + ICNN [6,16,1]
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from parity_cases import al7079_hybrid_setup
         from cmad_amd.models.device import HybridHillEffectiveStress
+        from cmad_amd.synthetic import al7079_hybrid_setup
         icnn, values = al7079_hybrid_setup()
         hybrid, eps_y = HybridHillEffectiveStress(icnn), 525.0 / 70.2e3
         newton = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})

@@ -215,10 +215,19 @@ CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, do
 // ---- local Newton, structured (same control flow as cm::newton) -----------------------------------------
 // `ev` is left holding the evaluation at the returned x (the one that passed the convergence test), so the
 // reverse sweep of the fused kernels does not have to redo it.
-// LS: the line-search branch is a compile-time variant (it roughly doubles the live registers of the loop).
+// LS: the line search is a compile-time variant.  While trial points are evaluated the base iterate and the
+// Newton direction are parked in the lane's LDS column (`stage`, 2*NX doubles); they are read back only when a
+// trial is rejected.
+struct LaneStage {
+    double* p;        // this lane's first slot
+    int stride;       // distance between consecutive slots of one lane (block size on the device, 1 on the host)
+    // volatile: without it the compiler forwards the stored values to the loads and keeps them in registers
+    CM_D volatile double& at(int k) const { return const_cast<volatile double*>(p)[k * stride]; }
+};
+
 template <int YK, bool LS>
 CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
-                       EvalS<YK>& ev) {
+                       EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
     constexpr int NX = 7;
     double C[NX];
 #pragma unroll
@@ -229,68 +238,92 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
     int it = 0;
     bool running = lane_valid;
     uint32_t flags = 0;
-    for (;;) {
-        const double nsq = dot<NX>(C, C);
-        const bool conv = (nsq < rel2) || (nsq < abs2);
-        if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
-        if (running && it >= m.max_iters) running = false;
-        if (!__any(running)) break;
-        if (running) {
-            double delta[NX];
-            PlasticOp op;
-            op_build<YK>(m, ev, op);               // ev is the evaluation at the current x (carried)
-            if (!op.ok) flags |= CM_STATUS_SINGULAR;
-            op_solve<false>(op, ev.y, C, delta);
-            if constexpr (!LS) {
+    if constexpr (!LS) {
+        for (;;) {
+            const double nsq = dot<NX>(C, C);
+            const bool conv = (nsq < rel2) || (nsq < abs2);
+            if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
+            if (running && it >= m.max_iters) running = false;
+            if (!__any(running)) break;
+            if (running) {
+                double delta[NX];
+                PlasticOp op;
+                op_build<YK>(m, ev, op);               // ev is the evaluation at the current x (carried)
+                if (!op.ok) flags |= CM_STATUS_SINGULAR;
+                op_solve<false>(op, ev.y, C, delta);
 #pragma unroll
                 for (int k = 0; k < NX; ++k) x[k] -= delta[k];
-                residual_s<YK>(m, eg, x, xp, ev, C);
-            } else {
-                const double cc = dot<NX>(C, C);
-                const double phi0 = 0.5 * cc, dphi0 = -cc, armijo = m.ls_c1 * dphi0;
-                int n = 0;
-                double alpha = 1.0, best_alpha = 1.0, best_phi = INFINITY;
-                bool accepted = false, have_best = false;
-                double xt[NX];
-                bool ls = true;
-                // trials are evaluated straight into (ev, C): on acceptance they already are the carried state
-                while (__any(ls)) {
-                    if (ls) {
+                ++it;
+            }
+            // evaluated by every lane: a lane that has stopped re-evaluates its unchanged x (same ev, C), which
+            // costs nothing in lockstep and spares the register copies a predicated redefinition would need
+            residual_s<YK>(m, eg, x, xp, ev, C);
+        }
+        return flags | (uint32_t)it;
+    } else {
+        // Newton iterations and line-search trials share ONE residual evaluation per pass of the loop (at the
+        // bottom); everything above it is bookkeeping on the evaluation that just arrived.  Trials are evaluated
+        // straight into (x, ev, C), so an accepted trial already is the carried state.
+        // phase: 0 at an accepted iterate | 1 a trial arrived | 2 the lowest-merit step re-evaluated (commit)
+        //        3, 4: every trial was non-finite -> full step with the base residual carried (line_search.py:181-183)
+        int phase = 0, n = 0;
+        double alpha = 1.0, best_alpha = 1.0, best_phi = INFINITY, cc = 0.0;
+        for (;;) {
+            if (running && phase != 0) {
+                bool commit = (phase == 2);
+                if (phase == 1) {
+                    const double phi = 0.5 * dot<NX>(C, C);            // merit; phi(0) = cc / 2, phi'(0) = -cc
+                    const bool finite = isfinite(phi);
+                    if (finite && phi < best_phi) { best_alpha = alpha; best_phi = phi; }
+                    const bool accepted = finite && (phi <= 0.5 * cc + alpha * (m.ls_c1 * -cc));
+                    ++n;
+                    if (accepted) commit = true;
+                    else if (n < m.ls_max_evals) {
+                        const double am = quad_min(0.5 * cc, -cc, alpha, phi);
+                        alpha = finite ? fmin(fmax(am, m.ls_lo * alpha), m.ls_hi * alpha) : 0.5 * alpha;
 #pragma unroll
-                        for (int k = 0; k < NX; ++k) xt[k] = x[k] - alpha * delta[k];
-                        residual_s<YK>(m, eg, xt, xp, ev, C);
-                        const double phi = 0.5 * dot<NX>(C, C);
-                        const bool finite = isfinite(phi);
-                        if (finite && phi < best_phi) { best_alpha = alpha; best_phi = phi; have_best = true; }
-                        accepted = finite && (phi <= phi0 + alpha * armijo);
-                        const double am = quad_min(phi0, dphi0, alpha, phi);
-                        const double ac = fmin(fmax(am, m.ls_lo * alpha), m.ls_hi * alpha);
-                        if (!accepted) alpha = finite ? ac : 0.5 * alpha;
-                        ++n;
-                        ls = (n < m.ls_max_evals) && !accepted;
+                        for (int k = 0; k < NX; ++k) x[k] = stage.at(k) - alpha * stage.at(NX + k);
+                    } else if (best_phi < INFINITY) {                  // no trial accepted: lowest-merit step tried
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) x[k] = stage.at(k) - best_alpha * stage.at(NX + k);
+                        phase = 2;
+                    } else {                                           // base point again, to recover its residual
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) x[k] = stage.at(k);
+                        phase = 3;
                     }
+                } else if (phase == 3) {                               // C is the base residual: park it, full step
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) { x[k] -= stage.at(NX + k); stage.at(k) = C[k]; }
+                    phase = 4;
+                } else if (phase == 4) {                               // ev is at the full step; carry the base residual
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) C[k] = stage.at(k);
+                    commit = true;
                 }
-                if (accepted) {
+                if (commit) { phase = 0; ++it; }
+            }
+            if (running && phase == 0) {
+                const double nsq = dot<NX>(C, C);
+                const bool conv = (nsq < rel2) || (nsq < abs2);
+                if (conv) { running = false; flags |= CM_STATUS_CONVERGED; }
+                else if (it >= m.max_iters) running = false;
+                else {
+                    double delta[NX];
+                    PlasticOp op;
+                    op_build<YK>(m, ev, op);
+                    if (!op.ok) flags |= CM_STATUS_SINGULAR;
+                    op_solve<false>(op, ev.y, C, delta);
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) x[k] -= alpha * delta[k];
-                } else if (have_best) {             // no trial accepted: lowest-merit step tried (line_search.py:181-183)
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) x[k] -= best_alpha * delta[k];
-                    residual_s<YK>(m, eg, x, xp, ev, C);
-                } else {                            // every trial non-finite: full step, base residual carried
-                    double Cb[NX], Cd[NX];
-                    residual_s<YK>(m, eg, x, xp, ev, Cb);
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) x[k] -= delta[k];
-                    residual_s<YK>(m, eg, x, xp, ev, Cd);
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) C[k] = Cb[k];
+                    for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
+                    cc = nsq; alpha = 1.0; best_alpha = 1.0; best_phi = INFINITY; n = 0; phase = 1;
                 }
             }
-            ++it;
+            if (!__any(running)) break;
+            residual_s<YK>(m, eg, x, xp, ev, C);       // every lane (see above)
         }
+        return flags | (uint32_t)it;
     }
-    return flags | (uint32_t)it;
 }
 
 // ---- J2, FULL_3D, plain Newton: the same iteration restricted to its invariant subspace ---------------------
@@ -455,13 +488,14 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
 
 // ---- front doors: structured for FULL_3D, dense otherwise (STRUCT = false forces the dense path) ------------
 template <int DEF, int YK, bool LS, bool STRUCT = true>
-CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid) {
+CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid,
+                         LaneStage stage = LaneStage{nullptr, 0}) {
     if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) {
         EvalS<YK> ev;
         if constexpr (YK == CM_YIELD_J2 && !LS) {
             if (m.solver_flags & CM_SOLVER_J2_RADIAL_LINE) return newton_j2_line(m, eg, xp, x, valid, ev);
         }
-        return newton_s<YK, LS>(m, eg, xp, x, valid, ev);
+        return newton_s<YK, LS>(m, eg, xp, x, valid, ev, stage);
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, valid);
 }

@@ -45,9 +45,33 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
     for (int k = 0; k < N; ++k) (p + (int64_t)k * B)[t] = v[k];
 }
 
+// minimum waves per SIMD requested from the register allocator (512 VGPRs per lane-slot / waves, in steps of 8:
+// 4 waves <= 128, 3 waves <= 168, 2 waves <= 256).  Experiment knobs: -DCM_OCC_<name>=<waves>.
+#ifndef CM_OCC_UPD_J2
+#define CM_OCC_UPD_J2 1
+#endif
+#ifndef CM_OCC_UPD_J2_LS
+#define CM_OCC_UPD_J2_LS 1
+#endif
+#ifndef CM_OCC_UPD_HOSFORD
+#define CM_OCC_UPD_HOSFORD 1
+#endif
+#ifndef CM_OCC_REV_J2_LS
+#define CM_OCC_REV_J2_LS 1
+#endif
+constexpr int kLsSlots = 2 * 7;         // line search: parked iterate and direction per lane (cm_structured.hpp)
+
+template <int DEF, int YK, bool LS, bool TANGENT>
+constexpr int min_waves_update() {
+    if (DEF != CM_FULL_3D) return 1;
+    if (YK == CM_YIELD_J2) return LS ? CM_OCC_UPD_J2_LS : CM_OCC_UPD_J2;
+    if (YK == CM_YIELD_HOSFORD && !LS) return CM_OCC_UPD_HOSFORD;
+    return 1;
+}
+
 // ---- cm_update / cm_update_tangent ----------------------------------------------------------------
 template <int DEF, int YK, bool ROT, bool LS, bool TANGENT>
-__global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
+__global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>())) void k_update(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
@@ -63,7 +87,8 @@ __global__ __launch_bounds__(kBlock) void k_update(cm_model_desc m, int64_t B,
     load_soa<NX>(xi_prev, B, b, xp);
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
-    uint32_t st = newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
+    __shared__ double ls_stage[LS ? kLsSlots * kBlock : 1];     // line search: parked iterate + direction (structured path)
+    uint32_t st = newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
     Eval<DEF> ev;
     strain_stress<DEF>(m, eg, z, x, ev);
     if (status) {
@@ -240,7 +265,10 @@ struct Wsq { double w[6]; };
 // minimum waves per SIMD requested from the register allocator: the J2 FULL_3D plain-Newton variants sit at
 // ~130 VGPRs, two above the 4-wave limit (128); every other variant is left unconstrained.
 template <int DEF, int YK, bool LS, int MODE>
-constexpr int min_waves() { return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1; }
+constexpr int min_waves() {
+    if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && LS) return CM_OCC_REV_J2_LS;
+    return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1;
+}
 
 template <int DEF, int YK, bool ROT, bool LS, int MODE>
 __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_reverse(cm_model_desc m, int64_t B,
@@ -268,13 +296,14 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
     constexpr bool SFAST = (DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN && (MODE == 1 || MODE == 3));
     EvalS<SFAST ? YK : CM_YIELD_J2> evs;
+    __shared__ double ls_stage[(SFAST && LS) ? kLsSlots * kBlock : 1];
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
             bool done = false;
             if constexpr (YK == CM_YIELD_J2 && !LS) {
                 if (m.solver_flags & CM_SOLVER_J2_RADIAL_LINE) { newton_j2_line(m, eg, xp, x, valid, evs); done = true; }
             }
-            if (!done) newton_s<YK, LS>(m, eg, xp, x, valid, evs);
+            if (!done) newton_s<YK, LS>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop

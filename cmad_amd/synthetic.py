@@ -25,6 +25,29 @@ def hosford_values(a=100., E=1000., nu=0.25, Y=2., S=10., D=2.):
     return v
 
 
+AL7079_HILL = (0.1477, 0.6805, 0.5345, 1.7977, 1.7148, 2.1675)    # F, G, H, L, M, N (calibrations/al7079/support.py:76-78)
+
+
+def al7079_hybrid_setup():
+    """BASELINE.json configs[3]: hybrid Hill + symmetric ICNN [6, 16, 1] yield surface with the Al7079 elastic
+    constants and Hill coefficients (cmad/calibrations/al7079/support.py:76-78,
+    nn_hill_uniaxial_stress_forward.py:84), weights from the seeded initialiser (seed 22), input scaler on
+    (0, 1) with zero offset and output scaler on the +/- sigma_c range as in
+    fit_hybrid_icnn_effective_stress.py:46-63,258-263.  The trained pickle is not in the reference repo.
+    Returns (icnn, parameter values)."""
+    from .neural_networks import AffineScaler, InputConvexNeuralNetwork
+    sig_c = np.array([525., 512., 515., 505., 493., 511., 530., 510., 544., 523., 486., 485.])
+    feats = np.abs(np.random.default_rng(22).normal(size=(24, 6))) * 300.0 + 50.0      # stand-in deviator samples
+    in_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.vstack([feats, np.zeros((1, 6))]))
+    in_sc.min_ = in_sc.min_ * 0.0
+    out_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.r_[-sig_c, sig_c].reshape(-1, 1))
+    icnn = InputConvexNeuralNetwork([6, 16, 1], in_sc, out_sc, seed=22)
+    values = j2_voce_values(E=70.22857142857143e3, nu=0.33396551724137924, Y=525.0, S=200., D=20.)
+    values["plastic"]["effective stress"] = {"hill": dict(zip("FGHLMN", AL7079_HILL)),
+                                             "neural network": icnn.params}
+    return icnn, values
+
+
 def gauss_point_batch(B, eps_y=1e-3, seed=SEED, skew=False, dev_scale=4.0, chunk=1 << 20, ndims=3):
     """Returns gradu (ndims^2, B) float64 SoA (numpy).  Chunked so 1e7 points need < 1 GB transient."""
     rng = np.random.default_rng(seed)

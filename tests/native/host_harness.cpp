@@ -23,8 +23,10 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         strain_from_gradu<DEF, ROT>(m, G, eg);
         strain_z<DEF, ROT>(m, z);
         const bool ls = m.ls_max_evals > 0;
-        uint32_t st = g_dense ? (ls ? newton_any<DEF, YK, true, false>(m, eg, z, xp, x, true) : newton_any<DEF, YK, false, false>(m, eg, z, xp, x, true))
-                              : (ls ? newton_any<DEF, YK, true, true>(m, eg, z, xp, x, true) : newton_any<DEF, YK, false, true>(m, eg, z, xp, x, true));
+        double parked[2 * 9];                      // the kernels keep this in the lane's LDS column
+        const LaneStage stage{parked, 1};
+        uint32_t st = g_dense ? (ls ? newton_any<DEF, YK, true, false>(m, eg, z, xp, x, true, stage) : newton_any<DEF, YK, false, false>(m, eg, z, xp, x, true, stage))
+                              : (ls ? newton_any<DEF, YK, true, true>(m, eg, z, xp, x, true, stage) : newton_any<DEF, YK, false, true>(m, eg, z, xp, x, true, stage));
         Eval<DEF> ev;
         strain_stress<DEF>(m, eg, z, x, ev);
         double sg[6];

@@ -179,23 +179,7 @@ def check_hosford_a100(backend, B=2048):
         xp, g = xi_o, 1.3 * g
 
 
-def al7079_hybrid_setup():
-    """BASELINE.json configs[3]: hybrid Hill + symmetric ICNN [6, 16, 1] yield surface with the Al7079 elastic
-    constants and Hill coefficients (cmad/calibrations/al7079/support.py:76-78,
-    nn_hill_uniaxial_stress_forward.py:84), weights from the seeded initialiser (seed 22), input scaler on
-    (0, 1) with zero offset and output scaler on the +/- sigma_c range as in
-    fit_hybrid_icnn_effective_stress.py:46-63,258-263.  The trained pickle is not in the reference repo."""
-    from cmad_amd.neural_networks import AffineScaler, InputConvexNeuralNetwork
-    sig_c = np.array([525., 512., 515., 505., 493., 511., 530., 510., 544., 523., 486., 485.])
-    feats = np.abs(np.random.default_rng(22).normal(size=(24, 6))) * 300.0 + 50.0      # stand-in deviator samples
-    in_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.vstack([feats, np.zeros((1, 6))]))
-    in_sc.min_ = in_sc.min_ * 0.0
-    out_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.r_[-sig_c, sig_c].reshape(-1, 1))
-    icnn = InputConvexNeuralNetwork([6, 16, 1], in_sc, out_sc, seed=22)
-    values = ol.j2_voce_values(E=70.22857142857143e3, nu=0.33396551724137924, Y=525.0, S=200., D=20.,
-                               yield_kind="hill", hill=HILL)
-    values["plastic"]["effective stress"]["neural network"] = icnn.params
-    return icnn, values
+from cmad_amd.synthetic import al7079_hybrid_setup  # noqa: E402  (shared with bench.py)
 
 
 def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False):
