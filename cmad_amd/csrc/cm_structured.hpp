@@ -197,6 +197,28 @@ CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, do
         for (int k = 0; k < 7; ++k) x[k] = b[k];
         return;
     }
+    if constexpr (YK == CM_YIELD_J2) {
+        // B^-1 v = (v + c tr(v) d) / a (op_build), so the two block solves collapse to four scalars:
+        //   tb = tr(b_v), tg = tr(gt), gb = row . b_v, gn = row . col = sum gt_k^2 / w_k   (either orientation)
+        //   rp = (gb + c tb tg) / a ,  rq = (gn + c tg tg) / a
+        //   x_v = (b_v + col tau + c d (tb + tg tau)) / a
+        const double ia = op.inv3[0], c = op.inv3[1];
+        const double tb = b[0] + b[3] + b[5], tg = y.gt[0] + y.gt[3] + y.gt[5];
+        double gb = 0.0, gn = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            gb += (TRANSPOSED ? kIW[k] : 1.0) * y.gt[k] * b[k];
+            gn += kIW[k] * y.gt[k] * y.gt[k];
+        }
+        const double rp = (gb + c * tb * tg) * ia, rq = (gn + c * tg * tg) * ia;
+        const double tau = (b[6] + op.k * rp) * rcp(op.j66 - op.k * rq);
+        const double cd = c * (tb + tg * tau);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            x[k] = ia * (b[k] + (TRANSPOSED ? 1.0 : kIW[k]) * y.gt[k] * tau + (kDiag[k] ? cd : 0.0));
+        x[6] = tau - op.eta * (rp + rq * tau);
+        return;
+    }
     double n[6], p[6], q[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) n[k] = y.gt[k] * kIW[k];
@@ -487,15 +509,18 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
 }
 
 // ---- front doors: structured for FULL_3D, dense otherwise (STRUCT = false forces the dense path) ------------
-template <int DEF, int YK, bool LS, bool STRUCT = true>
+// RL: the opt-in J2 radial-line iteration (cm_model_desc.solver_flags & CM_SOLVER_J2_RADIAL_LINE); a compile-time
+// variant chosen by the launcher so that the default kernels do not carry its code and registers.
+template <int DEF, int YK, bool LS, bool STRUCT = true, bool RL = false>
 CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid,
                          LaneStage stage = LaneStage{nullptr, 0}) {
     if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) {
         EvalS<YK> ev;
-        if constexpr (YK == CM_YIELD_J2 && !LS) {
-            if (m.solver_flags & CM_SOLVER_J2_RADIAL_LINE) return newton_j2_line(m, eg, xp, x, valid, ev);
+        if constexpr (RL) {
+            static_assert(YK == CM_YIELD_J2 && !LS, "radial line: J2, FULL_3D, plain Newton only");
+            return newton_j2_line(m, eg, xp, x, valid, ev);
         }
-        return newton_s<YK, LS>(m, eg, xp, x, valid, ev, stage);
+        else return newton_s<YK, LS>(m, eg, xp, x, valid, ev, stage);
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, valid);
 }

@@ -57,7 +57,7 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #define CM_OCC_UPD_HOSFORD 1
 #endif
 #ifndef CM_OCC_REV_J2_LS
-#define CM_OCC_REV_J2_LS 1
+#define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
 constexpr int kLsSlots = 2 * 7;         // line search: parked iterate and direction per lane (cm_structured.hpp)
 
@@ -70,7 +70,7 @@ constexpr int min_waves_update() {
 }
 
 // ---- cm_update / cm_update_tangent ----------------------------------------------------------------
-template <int DEF, int YK, bool ROT, bool LS, bool TANGENT>
+template <int DEF, int YK, bool ROT, bool LS, bool TANGENT, bool RL = false>
 __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>())) void k_update(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>()))
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
     __shared__ double ls_stage[LS ? kLsSlots * kBlock : 1];     // line search: parked iterate + direction (structured path)
-    uint32_t st = newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
+    uint32_t st = newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
     Eval<DEF> ev;
     strain_stress<DEF>(m, eg, z, x, ev);
     if (status) {
@@ -270,7 +270,7 @@ constexpr int min_waves() {
     return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1;
 }
 
-template <int DEF, int YK, bool ROT, bool LS, int MODE>
+template <int DEF, int YK, bool ROT, bool LS, int MODE, bool RL = false>
 __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_reverse(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi_in,
         const double* __restrict__ sbar_or_data, Wsq wsq, const double* __restrict__ hist_in,
@@ -299,11 +299,8 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     __shared__ double ls_stage[(SFAST && LS) ? kLsSlots * kBlock : 1];
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
-            bool done = false;
-            if constexpr (YK == CM_YIELD_J2 && !LS) {
-                if (m.solver_flags & CM_SOLVER_J2_RADIAL_LINE) { newton_j2_line(m, eg, xp, x, valid, evs); done = true; }
-            }
-            if (!done) newton_s<YK, LS>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
+            if constexpr (RL) newton_j2_line(m, eg, xp, x, valid, evs);
+            else newton_s<YK, LS>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
@@ -517,6 +514,12 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
     const bool found = dispatch<!TANGENT>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && !LS) {
+            if (m->solver_flags & CM_SOLVER_J2_RADIAL_LINE) {
+                hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -545,6 +548,13 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         // CM_DEBUG_DYN_LDS=<bytes>: occupancy experiments only (extra dynamic LDS per block limits blocks per CU)
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
         const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) {
+                if (m->solver_flags & CM_SOLVER_J2_RADIAL_LINE) {
+                    hipLaunchKernelGGL((k_reverse<D, Y, R, false, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
+                                       hist_in, xi_out, sigma_out, xpbar, gbar, partials);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((k_reverse<D, Y, R, (MODE == 1 || MODE == 3) ? LS : false, MODE>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                hist_in, xi_out, sigma_out, xpbar, gbar, partials);
         });
