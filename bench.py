@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--ls-evals", type=int, default=0,
                     help="J2 workloads: line-search evaluations per Newton iteration (0 = newton_solve defaults, "
                          "4 = make_newton_solve defaults)")
+    ap.add_argument("--def-type", default="full_3d", choices=["full_3d", "plane_stress"],
+                    help="J2 workloads: plane_stress is a side measurement (the reference's material-point tests' type)")
     ap.add_argument("--workload", default="j2_update_vjp",
                     choices=["j2_update_vjp", "j2_update", "j2_objective_grad", "hosford_update", "hybrid_update"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
@@ -131,15 +133,25 @@ def main():
         bytes_per_update = 232                     # read gradu 72 + xi_prev 56, write xi 56 + sigma 48
     elif wl == "j2_objective_grad":
         bytes_per_update = 176                     # read gradu 72 + xi_prev 56 + data 48, no per-point writes
-    desc, info = build_desc(values, newton=newton, hybrid=hybrid)
+    ps = args.def_type == "plane_stress"
+    if ps:
+        assert wl.startswith("j2_"), "--def-type plane_stress applies to the J2 workloads"
+        bytes_per_update += 8 * (-5 - 5 + 1 + 1)   # grad u 9 -> 4 doubles, xi / xi_prev 7 -> 8 doubles
+        if wl == "j2_objective_grad":
+            bytes_per_update -= 8                  # no xi written
+    from cmad_amd.models.deformation_types import DefType
+    desc, info = build_desc(values, def_type=DefType.PLANE_STRESS if ps else DefType.FULL_3D, newton=newton, hybrid=hybrid)
     ev = DeviceEvaluator(desc, info)
+    nxi = 8 if ps else 7
 
     # resident inputs (disjoint shard per rank: seed + rank)
-    gradu = torch.from_numpy(gauss_point_batch(B, seed=22 + rank, eps_y=eps_y)).to(dev)
-    xi_prev = torch.zeros((7, B), dtype=torch.float64, device=dev)
+    gradu = torch.from_numpy(gauss_point_batch(B, seed=22 + rank, eps_y=eps_y, ndims=2 if ps else 3)).to(dev)
+    xi_prev = torch.zeros((nxi, B), dtype=torch.float64, device=dev)
+    if ps:
+        xi_prev[7] = 1.0                           # F33 starts at 1 (small_elastic_plastic.py:161-169)
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
     sigma_bar = torch.randn((6, B), dtype=torch.float64, device=dev, generator=gen)
-    out = {"xi": torch.empty((7, B), dtype=torch.float64, device=dev),
+    out = {"xi": torch.empty((nxi, B), dtype=torch.float64, device=dev),
            "sigma": torch.empty((6, B), dtype=torch.float64, device=dev),
            "grad": torch.empty(12, dtype=torch.float64, device=dev)}
 
@@ -221,7 +233,7 @@ def main():
                              "j2_objective_grad": "fused J2 calibration objective + gradient, single step (configs[4] per GPU)",
                              "hosford_update": "Hosford a=100 stress update, notch_hosford.yaml material (configs[2])",
                              "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])"}[wl],
-                "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
+                "def_type": args.def_type, "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
                 "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
                            "line_search_max_evals": newton.line_search["max evals"],
                            "solver": "J2 radial-line restriction of the 7-dof Newton (opt-in)" if args.j2_radial_line

@@ -102,10 +102,17 @@ struct EvalS {
     YieldS<YK> y;
 };
 
-template <int YK>
-CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, EvalS<YK>& ev, double* C) {
+// DEF = PLANE_STRESS: x[7] = F33 enters the strain through z = V(q3 q3^T) and adds the row C[7] = sigma_33 / 2mu
+// (cm::strain_stress, cm::residual); `z` is not read for FULL_3D.
+template <int YK, int DEF = CM_FULL_3D>
+CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* z, const double* x, const double* xp,
+                     EvalS<YK>& ev, double* C) {
+    static_assert(DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS, "structured path: FULL_3D and PLANE_STRESS");
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ev.e[k] = eg[k] - x[k];
+    for (int k = 0; k < 6; ++k) {
+        ev.e[k] = eg[k] - x[k];
+        if constexpr (DEF == CM_PLANE_STRESS) ev.e[k] += (x[7] - 1.0) * z[k];
+    }
     ev.tr = ev.e[0] + ev.e[3] + ev.e[5];
     const double twomu = 2.0 * m.mu, lt = m.lambda * ev.tr;
 #pragma unroll
@@ -128,6 +135,16 @@ CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x
         }
     }
     C[6] = ev.plastic ? ev.f : ev.dgam;
+    if constexpr (DEF == CM_PLANE_STRESS) {
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r += kW[k] * z[k] * ev.s[k];
+        C[7] = r * i2mu;
+    }
+}
+template <int YK>
+CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, EvalS<YK>& ev, double* C) {
+    residual_s<YK, CM_FULL_3D>(m, eg, nullptr, x, xp, ev, C);
 }
 
 // A = dC/dx in structured form at an evaluated state
@@ -234,6 +251,65 @@ CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, do
     x[6] = tau - op.eta * s;
 }
 
+// ---- PLANE_STRESS: the 8x8 system is the structured 7x7 block bordered by the F33 column and the sigma_33 row ---
+//   A8 = [ A7   u ]    u = dC[0:7]/dF33 = [ -beta W^-1 Ht z ; gt . z ]   (plastic; 0 elastic -- Ht d = gt . d = 0
+//        [ r^T  d ]                                                        removes the lambda terms of Cel z)
+//                      r = dC7/dx[0:7] = -[ w o z + (lambda / 2mu) tr(z) d ; 0 ],   d = (w o z) . z + (lambda / 2mu) tr(z)^2
+//   A8 y = b:    p = A7^-1 b[0:7], q = A7^-1 u, tau = (b7 - r.p) / (d - r.q), y = [p - tau q ; tau]
+//   A8^T y = b:  p = A7^-T b[0:7], q = A7^-T r, tau = (b7 - u.p) / (d - u.q), y = [p - tau q ; tau]
+struct Border {
+    double u[7], r[6], d;
+};
+template <int YK>
+CM_D void border_build(const cm_model_desc& m, const PlasticOp& op, const EvalS<YK>& ev, const double z[6], Border& bd) {
+    const double l2m = m.lambda * 0.5 / m.mu, zt = z[0] + z[3] + z[5];
+    double dd = l2m * zt * zt;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        bd.r[k] = -(kW[k] * z[k] + (kDiag[k] ? l2m * zt : 0.0));
+        dd += kW[k] * z[k] * z[k];
+    }
+    bd.d = dd;
+    double hz[6];
+    hess_apply<YK>(m, ev.y, z, hz);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bd.u[k] = ev.plastic ? -op.beta * kIW[k] * hz[k] : 0.0;
+    bd.u[6] = ev.plastic ? dot<6>(ev.y.gt, z) : 0.0;
+}
+
+// y = A^-1 b (TRANSPOSED: A^-T b) for DEF's full system; b and y may alias.  Returns false on a zero pivot.
+template <int DEF, bool TRANSPOSED, int YK>
+CM_D bool solve_s(const cm_model_desc& m, const PlasticOp& op, const EvalS<YK>& ev, const double* z, const double* b, double* y) {
+    if constexpr (DEF == CM_FULL_3D) {
+        op_solve<TRANSPOSED>(op, ev.y, b, y);
+        return true;
+    } else {
+        Border bd;
+        border_build<YK>(m, op, ev, z, bd);
+        double p[7], q[7];
+        const double b7 = b[7];
+        op_solve<TRANSPOSED>(op, ev.y, b, p);
+        double rp, rq;
+        if constexpr (!TRANSPOSED) {
+            op_solve<false>(op, ev.y, bd.u, q);
+            rp = dot<6>(bd.r, p); rq = dot<6>(bd.r, q);
+        } else {
+            double r7[7];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r7[k] = bd.r[k];
+            r7[6] = 0.0;
+            op_solve<true>(op, ev.y, r7, q);
+            rp = dot<7>(bd.u, p); rq = dot<7>(bd.u, q);
+        }
+        const double den = bd.d - rq;
+        const double tau = (b7 - rp) * rcp(den);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) y[k] = p[k] - tau * q[k];
+        y[7] = tau;
+        return fabs(den) > 1e-300;
+    }
+}
+
 // ---- local Newton, structured (same control flow as cm::newton) -----------------------------------------
 // `ev` is left holding the evaluation at the returned x (the one that passed the convergence test), so the
 // reverse sweep of the fused kernels does not have to redo it.
@@ -247,14 +323,14 @@ struct LaneStage {
     CM_D volatile double& at(int k) const { return const_cast<volatile double*>(p)[k * stride]; }
 };
 
-template <int YK, bool LS>
+template <int YK, bool LS, int DEF = CM_FULL_3D>
 CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
-                       EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
-    constexpr int NX = 7;
+                       EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}, const double* z = nullptr) {
+    constexpr int NX = Dims<DEF>::NX;
     double C[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) x[k] = xp[k];
-    residual_s<YK>(m, eg, x, xp, ev, C);
+    residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);
     const double n0sq = dot<NX>(C, C);             // squared-norm form of nonlinear_solver.py:140-150, see cm::newton
     const double rel2 = m.rel_tol * m.rel_tol * n0sq, abs2 = m.abs_tol * m.abs_tol;
     int it = 0;
@@ -272,14 +348,14 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
                 PlasticOp op;
                 op_build<YK>(m, ev, op);               // ev is the evaluation at the current x (carried)
                 if (!op.ok) flags |= CM_STATUS_SINGULAR;
-                op_solve<false>(op, ev.y, C, delta);
+                if (!solve_s<DEF, false>(m, op, ev, z, C, delta)) flags |= CM_STATUS_SINGULAR;
 #pragma unroll
                 for (int k = 0; k < NX; ++k) x[k] -= delta[k];
                 ++it;
             }
             // evaluated by every lane: a lane that has stopped re-evaluates its unchanged x (same ev, C), which
             // costs nothing in lockstep and spares the register copies a predicated redefinition would need
-            residual_s<YK>(m, eg, x, xp, ev, C);
+            residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);
         }
         return flags | (uint32_t)it;
     } else {
@@ -335,14 +411,14 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
                     PlasticOp op;
                     op_build<YK>(m, ev, op);
                     if (!op.ok) flags |= CM_STATUS_SINGULAR;
-                    op_solve<false>(op, ev.y, C, delta);
+                    if (!solve_s<DEF, false>(m, op, ev, z, C, delta)) flags |= CM_STATUS_SINGULAR;
 #pragma unroll
                     for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
                     cc = nsq; alpha = 1.0; best_alpha = 1.0; best_phi = INFINITY; n = 0; phase = 1;
                 }
             }
             if (!__any(running)) break;
-            residual_s<YK>(m, eg, x, xp, ev, C);       // every lane (see above)
+            residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);       // every lane (see above)
         }
         return flags | (uint32_t)it;
     }
@@ -396,20 +472,25 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
     return st;
 }
 
-// ---- reverse sweep, structured (same contract as cm::reverse_point, DEF = FULL_3D) ---------------------------
-template <int YK, bool HAVE_EV = false>
+// ---- reverse sweep, structured (same contract as cm::reverse_point; FULL_3D and PLANE_STRESS) ---------------
+template <int YK, bool HAVE_EV = false, int DEF = CM_FULL_3D>
 CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp,
                           const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar,
-                          EvalS<YK>* evp = nullptr) {
+                          EvalS<YK>* evp = nullptr, const double* z = nullptr) {
+    constexpr int NX = Dims<DEF>::NX;
+    constexpr bool PS = (DEF == CM_PLANE_STRESS);
     EvalS<YK> evl;
-    double C[7], lam[7];
-    if constexpr (!HAVE_EV) residual_s<YK>(m, eg, x, xp, evl, C);
+    double C[NX], lam[NX];
+    if constexpr (!HAVE_EV) residual_s<YK, DEF>(m, eg, z, x, xp, evl, C);
     const EvalS<YK>& ev = HAVE_EV ? *evp : evl;
     // strain and stress are rebuilt from (eg, x) here rather than read from `ev`: 6 subtractions instead of
     // 12-24 registers carried across the Newton loop of the fused kernels
     double ee[6], ss[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ee[k] = eg[k] - x[k];
+    for (int k = 0; k < 6; ++k) {
+        ee[k] = eg[k] - x[k];
+        if constexpr (PS) ee[k] += (x[7] - 1.0) * z[k];
+    }
     const double etr = ee[0] + ee[3] + ee[5];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ss[k] = 2.0 * m.mu * ee[k] + (kDiag[k] ? m.lambda * etr : 0.0);
@@ -420,11 +501,12 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
 #pragma unroll
     for (int k = 0; k < 6; ++k) lam[k] = -csb[k];
     lam[6] = 0.0;
+    if constexpr (PS) lam[7] = dot<6>(z, csb);                   // d s / d F33 = Cel z
     if (xin) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) lam[k] += xin[k];
+        for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
-    op_solve<true>(op, ev.y, lam, lam);
+    const bool ok = solve_s<DEF, true>(m, op, ev, z, lam, lam);
     const double i2mu = 0.5 / m.mu;
     const YieldS<YK>& y = ev.y;
     double u[6], hu[6];
@@ -435,9 +517,18 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
     if (pbar) {
         const double ge = dot<6>(y.gt, ee), hue = dot<6>(hu, ee);
         const double sbd = sbm[0] + sbm[3] + sbm[5], sbe = dot<6>(sbm, ee);
-        // lam . dC/dlambda = 0 for a pressure-independent surface (Ht d = 0, gt . d = 0)
-        pbar[CM_P_LAMBDA] = sbd * etr;
-        pbar[CM_P_MU] = 2.0 * sbe - (2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f / m.mu));
+        // lam[0:7] . dC/dlambda = 0 for a pressure-independent surface (Ht d = 0, gt . d = 0)
+        double cl = 0.0, cm_ = 2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f / m.mu);
+        if constexpr (PS) {
+            const double zt = z[0] + z[3] + z[5];
+            double zwe = 0.0, zws = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { zwe += kW[k] * z[k] * ee[k]; zws += kW[k] * z[k] * ss[k]; }
+            cl = lam[7] * zt * etr * i2mu;
+            cm_ += lam[7] * (2.0 * zwe * i2mu - zws * i2mu / m.mu);      // C7 = (w o z) . s / 2mu
+        }
+        pbar[CM_P_LAMBDA] = sbd * etr - cl;
+        pbar[CM_P_MU] = 2.0 * sbe - cm_;
         pbar[CM_P_Y] = lam6 * i2mu;
         pbar[CM_P_VOCE_S] = m.has_voce ? lam6 * (1.0 - ev.hd.expo) * i2mu : 0.0;
         pbar[CM_P_VOCE_D] = m.has_voce ? lam6 * m.voce_S * x[6] * ev.hd.expo * i2mu : 0.0;
@@ -466,30 +557,38 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
 #pragma unroll
         for (int k = 0; k < 6; ++k) s += y.gt[k] * kIW[k] * lam[k];
         xpbar[6] = ev.plastic ? -s : lam[6];
+        if constexpr (PS) xpbar[7] = 0.0;
     }
     if (egbar) {
         double t[6], ct[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) t[k] = hu[k] + lam6 * y.gt[k] * i2mu;
+        for (int k = 0; k < 6; ++k) {
+            t[k] = hu[k] + lam6 * y.gt[k] * i2mu;
+            if constexpr (PS) t[k] += lam[7] * kW[k] * z[k] * i2mu;
+        }
         apply_cel(m, t, ct);
 #pragma unroll
         for (int k = 0; k < 6; ++k) egbar[k] = csb[k] - ct[k];
     }
-    return op.ok;
+    return op.ok && ok;
 }
 
-// ---- forward tangent, structured (same contract as cm::tangent_point, DEF = FULL_3D) ------------------------
-template <int YK>
-CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, double (&T)[6][6]) {
+// ---- forward tangent, structured (same contract as cm::tangent_point; FULL_3D and PLANE_STRESS) -------------
+template <int YK, int DEF = CM_FULL_3D>
+CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp, double (&T)[6][6],
+                          const double* z = nullptr) {
+    constexpr int NX = Dims<DEF>::NX;
+    constexpr bool PS = (DEF == CM_PLANE_STRESS);
     EvalS<YK> ev;
-    double C[7];
-    residual_s<YK>(m, eg, x, xp, ev, C);
+    double C[NX];
+    residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);
     PlasticOp op;
     op_build<YK>(m, ev, op);
     const YieldS<YK>& y = ev.y;
+    bool ok = op.ok;
 #pragma unroll
     for (int l = 0; l < 6; ++l) {
-        double b[7], unit[6], hcol[6];
+        double b[NX], unit[6], hcol[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) unit[k] = (k == l) ? 1.0 : 0.0;
         hess_apply<YK>(m, y, unit, hcol);                             // column l of Ht
@@ -497,43 +596,56 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
 #pragma unroll
         for (int k = 0; k < 6; ++k) b[k] = ev.plastic ? op.beta * kIW[k] * hcol[k] : 0.0;
         b[6] = ev.plastic ? -y.gt[l] : 0.0;
-        op_solve<false>(op, y, b, b);
+        if constexpr (PS) {                                           // -dC7/deg_l = -(Cel (w o z))_l / 2mu
+            const double zt = z[0] + z[3] + z[5];
+            b[7] = -(kW[l] * z[l] + (kDiag[l] ? m.lambda * 0.5 / m.mu * zt : 0.0));
+        }
+        ok = solve_s<DEF, false>(m, op, ev, z, b, b) && ok;
         double de[6], ds[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) de[k] = ((k == l) ? 1.0 : 0.0) - b[k];
+        for (int k = 0; k < 6; ++k) {
+            de[k] = ((k == l) ? 1.0 : 0.0) - b[k];
+            if constexpr (PS) de[k] += z[k] * b[7];
+        }
         apply_cel(m, de, ds);
 #pragma unroll
         for (int r = 0; r < 6; ++r) T[r][l] = ds[r];
     }
-    return op.ok;
+    return ok;
 }
 
-// ---- front doors: structured for FULL_3D, dense otherwise (STRUCT = false forces the dense path) ------------
+// ---- front doors: structured for FULL_3D / PLANE_STRESS with J2, Hill, Hosford; dense otherwise
+// (STRUCT = false forces the dense path) -------------------------------------------------------------------
+template <int DEF, int YK>
+constexpr bool has_structured() {
+    return (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS) && YK != CM_YIELD_HYBRID_HILL_NN;
+}
 // RL: the opt-in J2 radial-line iteration (cm_model_desc.solver_flags & CM_SOLVER_J2_RADIAL_LINE); a compile-time
 // variant chosen by the launcher so that the default kernels do not carry its code and registers.
 template <int DEF, int YK, bool LS, bool STRUCT = true, bool RL = false>
 CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid,
                          LaneStage stage = LaneStage{nullptr, 0}) {
-    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) {
+    if constexpr (STRUCT && has_structured<DEF, YK>()) {
         EvalS<YK> ev;
         if constexpr (RL) {
-            static_assert(YK == CM_YIELD_J2 && !LS, "radial line: J2, FULL_3D, plain Newton only");
+            static_assert(DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS, "radial line: J2, FULL_3D, plain Newton only");
             return newton_j2_line(m, eg, xp, x, valid, ev);
         }
-        else return newton_s<YK, LS>(m, eg, xp, x, valid, ev, stage);
+        else return newton_s<YK, LS, DEF>(m, eg, xp, x, valid, ev, stage, z);
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, valid);
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
                       const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar) {
-    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) return reverse_point_s<YK>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar);
+    if constexpr (STRUCT && has_structured<DEF, YK>())
+        return reverse_point_s<YK, false, DEF>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar, nullptr, z);
     else return reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, egbar);
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
                       double (&T)[6][6]) {
-    if constexpr (STRUCT && DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN) return tangent_point_s<YK>(m, eg, x, xp, T);
+    if constexpr (STRUCT && has_structured<DEF, YK>()) return tangent_point_s<YK, DEF>(m, eg, x, xp, T, z);
     else return tangent_point<DEF, YK>(m, eg, z, x, xp, T);
 }
 

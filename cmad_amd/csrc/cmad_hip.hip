@@ -59,7 +59,7 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_REV_J2_LS
 #define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
-constexpr int kLsSlots = 2 * 7;         // line search: parked iterate and direction per lane (cm_structured.hpp)
+constexpr int kLsSlots = 2 * 8;         // line search: parked iterate and direction per lane, 2 * max NX (cm_structured.hpp)
 
 template <int DEF, int YK, bool LS, bool TANGENT>
 constexpr int min_waves_update() {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>()))
     load_soa<NX>(xi_prev, B, b, xp);
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
-    __shared__ double ls_stage[LS ? kLsSlots * kBlock : 1];     // line search: parked iterate + direction (structured path)
+    __shared__ double ls_stage[(LS && has_structured<DEF, YK>()) ? kLsSlots * kBlock : 1];   // parked iterate + direction
     uint32_t st = newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
     Eval<DEF> ev;
     strain_stress<DEF>(m, eg, z, x, ev);
@@ -294,13 +294,13 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
     // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
-    constexpr bool SFAST = (DEF == CM_FULL_3D && YK != CM_YIELD_HYBRID_HILL_NN && (MODE == 1 || MODE == 3));
+    constexpr bool SFAST = (has_structured<DEF, YK>() && (MODE == 1 || MODE == 3));
     EvalS<SFAST ? YK : CM_YIELD_J2> evs;
     __shared__ double ls_stage[(SFAST && LS) ? kLsSlots * kBlock : 1];
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
             if constexpr (RL) newton_j2_line(m, eg, xp, x, valid, evs);
-            else newton_s<YK, LS>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
+            else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     // arrays are always passed (never a run-time null): a nullable local array would be forced into scratch
     // (MODE 1 / 3 have no per-point cotangent outputs at all: compile-time nulls let the compiler drop that work)
     constexpr bool BARS = (MODE == 0 || MODE == 2);
-    if constexpr (SFAST) reverse_point_s<YK, true>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs);
+    if constexpr (SFAST) reverse_point_s<YK, true, DEF>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs, z);
     else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
                               BARS ? egbar : nullptr);
     if (BARS && xpbar_out && valid) {

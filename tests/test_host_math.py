@@ -11,8 +11,8 @@ BACKEND = pc.HostBackend()
 
 @pytest.fixture(params=["structured", "dense"], autouse=True)
 def solver_variant(request):
-    """FULL_3D runs twice: the structured block solve the kernels use and the dense 7x7 LU (PLANE_STRESS is
-    always dense)."""
+    """FULL_3D and PLANE_STRESS run twice: the structured (bordered) block solve the kernels use and the dense
+    LU of the same system."""
     import host_harness_lib as hh
     hh.set_dense(request.param == "dense")
     yield request.param
