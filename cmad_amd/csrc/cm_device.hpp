@@ -157,14 +157,26 @@ CM_D QuadForm quad_form(const cm_model_desc& m) {
 // ---- symmetric input-convex network [6, H, 1] (one hidden layer) --------------------------------------
 // cmad/neural_networks/input_convex_neural_network.py:36-69.  Packed weights (device memory, uniform
 // addresses -> scalar loads): W0[6][H], b0[H], Wx1[6], b1, Wz[H], in_scale[6], in_min[6], out_scale, out_min, f(0).
-// f(x) = softplus(x W0 + b0) . Wz + x . Wx1 + b1 ;  value/gradient/Hessian w.r.t. the SCALED input xs.
+// f(x) = softplus(x W0 + b0) . Wz + x . Wx1 + b1.  The yield term only needs the symmetrised network
+// 1/2 (f(x) + f(-x)), so both signs share one pass over the hidden units (one dot product, one rank-1 Hessian
+// update per unit; the pass-through x . Wx1 cancels):
+//   F = f(x) + f(-x),  G = grad f(x) - grad f(-x) = d F / d x,  Hx = d2 F / d x2      (w.r.t. the SCALED input xs)
+struct SoftUnit { double sp, sg; };
+CM_D SoftUnit soft_unit(double a) {
+    const double e = exp(-fabs(a));
+    const double inv = 1.0 / (1.0 + e);
+    SoftUnit u;
+    u.sp = fmax(a, 0.0) + log1p(e);                             // jax.nn.softplus = logaddexp(a, 0)
+    u.sg = (a >= 0.0) ? inv : e * inv;                          // sigmoid(a)
+    return u;
+}
 template <bool HESS>
-CM_D void icnn_forward(const double* __restrict__ w, int H, const double xs[6], double& f, double g[6], double Hx[6][6]) {
+CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6], double& F, double G[6], double Hx[6][6]) {
     const double* W0 = w; const double* b0 = w + 6 * H; const double* Wx1 = b0 + H; const double* b1 = Wx1 + 6;
     const double* Wz = b1 + 1;
-    f = b1[0];
+    F = 2.0 * b1[0];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { f += xs[i] * Wx1[i]; g[i] = Wx1[i]; }
+    for (int i = 0; i < 6; ++i) G[i] = 0.0;
     if constexpr (HESS) {
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -172,25 +184,24 @@ CM_D void icnn_forward(const double* __restrict__ w, int H, const double xs[6], 
             for (int j = 0; j < 6; ++j) Hx[i][j] = 0.0;
     }
     for (int o = 0; o < H; ++o) {
-        double a = b0[o];
+        double t = 0.0;
         double wc[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { wc[i] = W0[i * H + o]; a += xs[i] * wc[i]; }
-        const double e = exp(-fabs(a));
-        const double inv = 1.0 / (1.0 + e);
-        const double sp = fmax(a, 0.0) + log1p(e);              // jax.nn.softplus = logaddexp(a, 0)
-        const double sg = (a >= 0.0) ? inv : e * inv;           // sigmoid(a)
+        for (int i = 0; i < 6; ++i) { wc[i] = W0[i * H + o]; t += xs[i] * wc[i]; }
+        const SoftUnit up = soft_unit(b0[o] + t), un = soft_unit(b0[o] - t);
         const double wz = Wz[o];
-        f += sp * wz;
-        const double c1 = sg * wz;
+        F += (up.sp + un.sp) * wz;
+        const double c1 = (up.sg - un.sg) * wz;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g[i] += c1 * wc[i];
+        for (int i = 0; i < 6; ++i) G[i] += c1 * wc[i];
         if constexpr (HESS) {
-            const double c2 = sg * (1.0 - sg) * wz;
+            const double c2 = (up.sg * (1.0 - up.sg) + un.sg * (1.0 - un.sg)) * wz;
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 6; ++i) {
+                const double ci = c2 * wc[i];
 #pragma unroll
-                for (int j = i; j < 6; ++j) Hx[i][j] += c2 * wc[i] * wc[j];
+                for (int j = i; j < 6; ++j) Hx[i][j] += ci * wc[j];
+            }
         }
     }
     if constexpr (HESS) {
@@ -210,17 +221,17 @@ CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val
     const double* sc = w + 6 * H + H + 6 + 1 + H;             // in_scale[6], in_min[6], out_scale, out_min, f0
     const double h = (s[0] + s[3] + s[5]) * (1.0 / 3.0);
     const double x[6] = {s[0] - h, s[3] - h, s[5] - h, s[1], s[2], s[4]};
-    double xp[6], xn[6];
+    // scaled input; the reference evaluates g(xs) and g(-xs) (input_convex_neural_network.py:59-69)
+    double xs[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { xp[i] = sc[i] * x[i] + sc[6 + i]; xn[i] = -xp[i]; }
-    double fp, fn, gp[6], gn[6], Hp[6][6], Hn[6][6];
-    icnn_forward<HESS>(w, H, xp, fp, gp, Hp);
-    icnn_forward<HESS>(w, H, xn, fn, gn, Hn);
+    for (int i = 0; i < 6; ++i) xs[i] = sc[i] * x[i] + sc[6 + i];
+    double F, G[6], Hs[6][6];
+    icnn_symmetric<HESS>(w, H, xs, F, G, Hs);
     const double ios = 1.0 / sc[12];
-    val = (0.5 * (fp + fn) - sc[14] - sc[13]) * ios;           // (1/2 (f(x)+f(-x)) - f(0) - out_min) / out_scale
+    val = (0.5 * F - sc[14] - sc[13]) * ios;                   // (1/2 (f(x)+f(-x)) - f(0) - out_min) / out_scale
     double gx[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) gx[i] = 0.5 * (gp[i] - gn[i]) * sc[i] * ios;
+    for (int i = 0; i < 6; ++i) gx[i] = 0.5 * G[i] * sc[i] * ios;
     // chain through x(s6): normal slots k -> x index (0,1,2) minus the mean; shear slots 1,2,4 -> x index 3,4,5
     constexpr int XI[6] = {0, 3, 4, 1, 5, 2};
     const double gm = (gx[0] + gx[1] + gx[2]) * (1.0 / 3.0);
@@ -231,7 +242,7 @@ CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) Hx[i][j] = 0.5 * (Hp[i][j] + Hn[i][j]) * sc[i] * sc[j] * ios;
+            for (int j = 0; j < 6; ++j) Hx[i][j] = 0.5 * Hs[i][j] * sc[i] * sc[j] * ios;
         // J = d x / d s6: H6 = J^T Hx J with J_ik = delta(i, XI[k]) - (i < 3 && diag k) / 3
         double tot = 0.0;
 #pragma unroll
@@ -304,10 +315,22 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
         const double mx = fmax(t0, fmax(t1, t2));
         const double imx = (mx > 0.0) ? 1.0 / mx : 0.0;             // equal normal stresses: phi = 0, normal := 0
         const double u[3] = {t0 * imx, t1 * imx, t2 * imx};
-        // u_i^a = exp(a log u_i) (u_i in [0,1]); (|d_i|/phi)^(a-2) = u_i^a Sr^2 / (u_i^2 S) -- no further pow
+        // u_i^a (u_i in [0,1]); (|d_i|/phi)^(a-2) = u_i^a Sr^2 / (u_i^2 S) -- no further pow.
+        // Integer exponents (the usual case: 6, 8, 100) by repeated squaring, ~log2(a) multiplications per term
+        // and a few ulp; anything else as exp(a log u).  `a` is a kernel argument, so the branch is uniform.
         double ua[3];
+        const int ai = (int)a;
+        if (a == (double)ai && ai >= 2 && ai <= 65536) {
+            double base[3] = {u[0], u[1], u[2]};
+            ua[0] = ua[1] = ua[2] = 1.0;
+            for (int e = ai; e != 0; e >>= 1) {
+                if (e & 1) { ua[0] *= base[0]; ua[1] *= base[1]; ua[2] *= base[2]; }
+                base[0] *= base[0]; base[1] *= base[1]; base[2] *= base[2];
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ua[i] = (u[i] > 0.0) ? exp(a * log(u[i])) : 0.0;
+            for (int i = 0; i < 3; ++i) ua[i] = (u[i] > 0.0) ? exp(a * log(u[i])) : 0.0;
+        }
         const double S = 0.5 * (ua[0] + ua[1] + ua[2]);
         const double Sr = (S > 0.0) ? exp(log(S) / a) : 0.0;
         phi = mx * Sr;

@@ -56,6 +56,12 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_UPD_HOSFORD
 #define CM_OCC_UPD_HOSFORD 1
 #endif
+#ifndef CM_OCC_UPD_HOSFORD_LS
+#define CM_OCC_UPD_HOSFORD_LS 1
+#endif
+#ifndef CM_OCC_UPD_HYBRID
+#define CM_OCC_UPD_HYBRID 2         // 268-276 -> 256 VGPRs: two waves per SIMD for the exp/log-bound network kernels
+#endif
 #ifndef CM_OCC_REV_J2_LS
 #define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
@@ -65,7 +71,8 @@ template <int DEF, int YK, bool LS, bool TANGENT>
 constexpr int min_waves_update() {
     if (DEF != CM_FULL_3D) return 1;
     if (YK == CM_YIELD_J2) return LS ? CM_OCC_UPD_J2_LS : CM_OCC_UPD_J2;
-    if (YK == CM_YIELD_HOSFORD && !LS) return CM_OCC_UPD_HOSFORD;
+    if (YK == CM_YIELD_HOSFORD) return LS ? CM_OCC_UPD_HOSFORD_LS : CM_OCC_UPD_HOSFORD;
+    if (YK == CM_YIELD_HYBRID_HILL_NN) return CM_OCC_UPD_HYBRID;
     return 1;
 }
 

@@ -9,7 +9,7 @@ import oracle_lib as ol
 
 XI_ATOL = 1e-13
 HILL = [0.1477, 0.6805, 0.5345, 1.7977, 1.7148, 2.1675]
-YIELDS = [("J2", {}), ("hill", {"hill": HILL}), ("hosford", {"a": 4.}), ("hosford", {"a": 8.})]
+YIELDS = [("J2", {}), ("hill", {"hill": HILL}), ("hosford", {"a": 4.}), ("hosford", {"a": 8.5})]      # 8.5: the non-integer exp/log branch of the Hosford powers
 
 
 def rand_rot(rng):
