@@ -28,6 +28,8 @@ class ModelDesc(C.Structure):
         ("abs_tol", C.c_double), ("rel_tol", C.c_double),
         ("ls_c1", C.c_double), ("ls_lo", C.c_double), ("ls_hi", C.c_double),
         ("nn_weights", C.c_void_p), ("nn_nlayers", C.c_int32), ("nn_widths", C.c_int32 * 7),
+        ("beta_equivalent_stress", C.c_double), ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double),
+        ("beta_max_iters", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

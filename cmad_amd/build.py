@@ -24,11 +24,11 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-NPARTS = 4          # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
+NPARTS = 7          # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
 
 
 def build(force=False, verbose=False, jobs=None):
-    """hipcc --offload-arch=gfx950: the four parts of cmad_hip.hip are compiled concurrently, then linked."""
+    """hipcc --offload-arch=gfx950: the parts of cmad_hip.hip are compiled concurrently, then linked."""
     if not force and not is_stale():
         return LIB
     hipcc = hipcc_path()

@@ -263,9 +263,125 @@ CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val
     }
 }
 
+CM_D double quad_min(double phi0, double dphi0, double a, double phi);
+
+// the network-backed surfaces (dense Hessian, no structured solve, no second-derivative kernel)
+constexpr bool is_nn_yield(int yk) { return yk == CM_YIELD_HYBRID_HILL_NN || yk == CM_YIELD_SCALED_HYBRID_HILL_NN; }
+
+template <int YK, bool HESS>
+CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]);
+
+// scaled_effective_stress around the hybrid surface (cmad/models/effective_stress.py:97-108, 130-146):
+//   phi(s) = phi_h(beta s) / beta,  beta: phi_h(beta s) = Yeq  (scalar make_newton_solve started at Y / phi_J2(s),
+//   default line search), phi = phi_J2 when phi_J2 is within 1e-14 of zero.
+// With tau = beta s, g = grad phi_h(tau), H = hess phi_h(tau), c = g . tau, and the implicit-function derivative
+// d beta = -beta (g . ds) / (g . s) of nonlinear_solver.py:158-171:
+//   grad phi  = phi_h g / c
+//   hess phi  = beta M (I - tau g^T / c),   M = g g^T / c + phi_h H / c - phi_h g (H tau + g)^T / c^2
+template <bool HESS>
+CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
+    double pj;
+    {
+        double gj[6];
+        yield_eval<CM_YIELD_J2, false>(m, s, pj, gj, Ht);
+    }
+    if (!(fabs(pj) > 1e-14)) {                                  // jnp.isclose(phi_J2, 0., tol, tol): J2 value, normal := 0
+        phi = pj;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gt[k] = 0.0;
+        if constexpr (HESS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int l = 0; l < 6; ++l) Ht[k][l] = 0.0;
+        }
+        return;
+    }
+    const double iy = 1.0 / m.beta_equivalent_stress;
+    // r(beta) = phi_h(beta s) / Yeq - 1 and r'(beta) = grad phi_h(beta s) . s / Yeq
+    auto r_dr = [&](double b, double& r, double& dr) {
+        double t[6], ph, g[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = b * s[k];
+        yield_eval<CM_YIELD_HYBRID_HILL_NN, false>(m, t, ph, g, Ht);
+        double gs = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gs += g[k] * s[k];
+        r = ph * iy - 1.0; dr = gs * iy;
+    };
+    double beta = m.Y / pj;
+    {
+        constexpr int kMaxEvals = 4;                            // DEFAULT_LINE_SEARCH_SETTINGS, line_search.py:40-46
+        double C, dC;
+        r_dr(beta, C, dC);
+        const double n0 = fabs(C);
+        for (int it = 0; it < m.beta_max_iters; ++it) {
+            const double nrm = fabs(C);
+            if (nrm / n0 < m.beta_rel_tol || nrm < m.beta_abs_tol) break;
+            const double delta = C / dC;
+            const double phi0 = 0.5 * C * C, dphi0 = -C * C, armijo = m.ls_c1 * dphi0;
+            int n = 0;
+            double alpha = 1.0, best_alpha = 1.0, best_phi = INFINITY, best_C = C, best_dC = dC, Ct = C, dCt = dC;
+            bool accepted = false, have_best = false;
+            while (n < kMaxEvals && !accepted) {
+                r_dr(beta - alpha * delta, Ct, dCt);
+                const double ph = 0.5 * Ct * Ct;
+                const bool finite = isfinite(ph);
+                if (finite && ph < best_phi) { best_alpha = alpha; best_phi = ph; best_C = Ct; best_dC = dCt; have_best = true; }
+                accepted = finite && (ph <= phi0 + alpha * armijo);
+                const double am = quad_min(phi0, dphi0, alpha, ph);
+                const double ac = fmin(fmax(am, m.ls_lo * alpha), m.ls_hi * alpha);
+                if (!accepted) alpha = finite ? ac : 0.5 * alpha;
+                ++n;
+            }
+            if (accepted) { beta -= alpha * delta; C = Ct; dC = dCt; }
+            else if (have_best) { beta -= best_alpha * delta; C = best_C; dC = best_dC; }
+            else {                                              // every trial non-finite: full step, base residual carried
+                beta -= delta;
+                double Cn;
+                r_dr(beta, Cn, dC);
+            }
+        }
+    }
+    double tau[6], ph, g[6], H[6][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tau[k] = beta * s[k];
+    yield_eval<CM_YIELD_HYBRID_HILL_NN, HESS>(m, tau, ph, g, H);
+    double c = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c += g[k] * tau[k];
+    const double ic = 1.0 / c;
+    phi = ph / beta;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gt[k] = ph * g[k] * ic;
+    if constexpr (HESS) {
+        double Ht_au[6], tHt = 0.0;                              // H tau, tau . H tau
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) a += H[k][l] * tau[l];
+            Ht_au[k] = a; tHt += tau[k] * a;
+        }
+        // M tau = g + phi_h H tau / c - phi_h g (tau . H tau + c) / c^2
+        double Mt[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Mt[k] = g[k] + ph * ic * Ht_au[k] - ph * g[k] * (tHt + c) * ic * ic;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int l = 0; l < 6; ++l) {
+                const double Mkl = g[k] * g[l] * ic + ph * ic * H[k][l] - ph * g[k] * (Ht_au[l] + g[l]) * ic * ic;
+                Ht[k][l] = beta * (Mkl - Mt[k] * g[l] * ic);
+            }
+    }
+}
+
 template <int YK, bool HESS>
 CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
-    if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
+    if constexpr (YK == CM_YIELD_SCALED_HYBRID_HILL_NN) {
+        scaled_hybrid_eval<HESS>(m, s, phi, gt, Ht);
+    } else if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
         yield_eval<CM_YIELD_HILL, HESS>(m, s, phi, gt, Ht);
         double v, g6[6], H6[6][6];
         icnn_yield_term<HESS>(m, s, v, g6, H6);

@@ -6,10 +6,10 @@
 #include "cm_structured.hpp"
 #include "cm_hessian.hpp"
 
-// The library can be built from this one file in four independent pieces (hipcc -DCM_PART=0..3, see
+// The library can be built from this one file in seven independent pieces (hipcc -DCM_PART=0..6, see
 // cmad_amd/build.py) so the template instantiations compile in parallel; without CM_PART everything is one TU.
-//   0: cm_update, cm_update_tangent            2: cm_update_vjp, cm_adjoint_step
-//   1: cm_update_rate, cm_evaluate, info calls 3: cm_update_and_vjp, cm_objective_grad
+//   0: cm_update            2: cm_update_vjp, cm_adjoint_step   4: cm_update_tangent          6: cm_objective_grad,
+//   1: cm_update_rate, info 3: cm_update_and_vjp                5: cm_evaluate(_rate)            cm_hessians
 #ifndef CM_PART
 #define CM_PART (-1)
 #endif
@@ -72,7 +72,7 @@ constexpr int min_waves_update() {
     if (DEF != CM_FULL_3D) return 1;
     if (YK == CM_YIELD_J2) return LS ? CM_OCC_UPD_J2_LS : CM_OCC_UPD_J2;
     if (YK == CM_YIELD_HOSFORD) return LS ? CM_OCC_UPD_HOSFORD_LS : CM_OCC_UPD_HOSFORD;
-    if (YK == CM_YIELD_HYBRID_HILL_NN) return CM_OCC_UPD_HYBRID;
+    if (is_nn_yield(YK)) return CM_OCC_UPD_HYBRID;
     return 1;
 }
 
@@ -468,7 +468,8 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     if (m->model_kind != model_kind) return false;
     if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS && m->def_type != CM_UNIAXIAL_STRESS) return false;
     if (m->def_type == CM_UNIAXIAL_STRESS && (m->uniaxial_idx < 0 || m->uniaxial_idx > 2)) return false;
-    if (m->yield_kind == CM_YIELD_HYBRID_HILL_NN)      // one hidden layer [6, H, 1], weights resident on the device
+    if (m->yield_kind == CM_YIELD_SCALED_HYBRID_HILL_NN && !(m->beta_equivalent_stress > 0.0 && m->beta_max_iters >= 0)) return false;
+    if (is_nn_yield(m->yield_kind))                    // one hidden layer [6, H, 1], weights resident on the device
         return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
                m->nn_widths[1] >= 1 && m->nn_widths[1] <= 256;
     if (m->yield_kind != CM_YIELD_J2 && m->yield_kind != CM_YIELD_HILL && m->yield_kind != CM_YIELD_HOSFORD) return false;
@@ -494,10 +495,14 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
     CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
+    CM_CASE(CM_FULL_3D, CM_YIELD_SCALED_HYBRID_HILL_NN)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
     if constexpr (UNI) {
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_J2)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HYBRID_HILL_NN)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
     }
 #undef CM_CASE
     return false;
@@ -580,7 +585,7 @@ extern "C" {
 
 
 #if CM_HAS_PART(1)
-int cm_abi_version(void) { return 1; }
+int cm_abi_version(void) { return 2; }
 #endif
 
 #if CM_HAS_PART(1)
@@ -641,7 +646,7 @@ int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
 }
 #endif
 
-#if CM_HAS_PART(0)
+#if CM_HAS_PART(4)
 int cm_update_tangent(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream) {
     return launch_update<true>(m, B, gradu, xi_prev, xi, sigma, dsigma_dgradu, status, stream);
@@ -674,7 +679,7 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
 int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(5)
 int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* jac, double* sigma, double* dsigma, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
@@ -695,7 +700,7 @@ int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
 }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(5)
 int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                      const double* xi_prev, const double* xi, double* C, double* jac, double* sigma, double* dsigma,
                      void* stream) {
@@ -718,11 +723,11 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
 }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(6)
 int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m) || m->yield_kind == CM_YIELD_HYBRID_HILL_NN) return CM_ERR_UNSUPPORTED;
+    if (!supported(m) || is_nn_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi) return CM_ERR_BAD_ARG;
     const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
@@ -732,7 +737,7 @@ int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const do
     const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (Y != CM_YIELD_HYBRID_HILL_NN)
+        if constexpr (!is_nn_yield(Y))
             hipLaunchKernelGGL((k_hessians<D, Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, d2C, d2S, dC, dS);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -740,7 +745,7 @@ int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const do
 }
 #endif
 
-#if CM_HAS_PART(3)
+#if CM_HAS_PART(6)
 int cm_objective_grad(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       const double* data, const double* wsq6, double* out, double* xi,
                       void* workspace, int64_t workspace_bytes, void* stream) {

@@ -56,8 +56,9 @@ class HybridHillEffectiveStress:
     `SmallElasticPlastic(..., effective_stress_fun=HybridHillEffectiveStress(icnn))` where the reference passes
     `partial(hybrid_hill_effective_stress, nn_fun=icnn.evaluate)`; the network weights are read from
     params["plastic"]["effective stress"]["neural network"] like the reference does.
-    The HIP kernel supports one hidden layer ([6, H, 1]); the beta-rescaled variant
-    (`scaled_effective_stress`, :130-146) is not built."""
+    The HIP kernel supports one hidden layer ([6, H, 1]); `ScaledHybridHillEffectiveStress` is the beta-rescaled
+    variant (`scaled_effective_stress`, :130-146)."""
+    yield_kind = 3
 
     def __init__(self, icnn):
         if len(icnn.layer_widths) != 3 or icnn.layer_widths[0] != 6 or icnn.layer_widths[-1] != 1:
@@ -71,6 +72,21 @@ class HybridHillEffectiveStress:
         widths, w = self.icnn.pack_for_device(nn_params)
         f0 = float(np.asarray(forward(np.zeros(widths[0]), nn_params)).ravel()[0])
         return widths, np.concatenate([w, [f0]])
+
+
+class ScaledHybridHillEffectiveStress(HybridHillEffectiveStress):
+    """`scaled_effective_stress(cauchy, params, effective_stress_fun=hybrid, update_fun=beta_make_newton_solve(hybrid,
+    equivalent_stress, max_iters, abs_tol, rel_tol))` (cmad/models/effective_stress.py:97-108, 130-146):
+    phi(sigma) = phi_h(beta sigma) / beta with beta such that phi_h(beta sigma) = equivalent_stress, so the network
+    is always queried on the level set it was fitted on.  Same argument defaults as `beta_make_newton_solve`."""
+    yield_kind = 4
+
+    def __init__(self, icnn, equivalent_stress, max_iters=10, abs_tol=1e-14, rel_tol=1e-14):
+        super().__init__(icnn)
+        if not equivalent_stress > 0.0:
+            raise ValueError("equivalent_stress must be positive")
+        self.equivalent_stress = float(equivalent_stress)
+        self.max_iters, self.abs_tol, self.rel_tol = int(max_iters), float(abs_tol), float(rel_tol)
 
 
 def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, uniaxial_stress_idx=0,
@@ -89,7 +105,11 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
         ytype = "hill"
     if ytype not in YIELD_KINDS:
         raise NotImplementedError(f"effective stress '{ytype}' has no HIP kernel")
-    d.yield_kind = 3 if hybrid is not None else YIELD_KINDS[ytype]
+    d.yield_kind = hybrid.yield_kind if hybrid is not None else YIELD_KINDS[ytype]
+    if hybrid is not None and hybrid.yield_kind == 4:
+        d.beta_equivalent_stress = hybrid.equivalent_stress
+        d.beta_max_iters = hybrid.max_iters
+        d.beta_abs_tol, d.beta_rel_tol = hybrid.abs_tol, hybrid.rel_tol
     Q = np.asarray(values.get("rotation matrix", np.eye(3)), dtype=np.float64).reshape(3, 3)
     for i in range(9):
         d.Q[i] = float(Q.reshape(9)[i])

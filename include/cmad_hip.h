@@ -40,8 +40,9 @@ enum cm_status {
 enum cm_def_type { CM_FULL_3D = 0, CM_PLANE_STRAIN = 1, CM_PLANE_STRESS = 2, CM_UNIAXIAL_STRESS = 3 };
 /* registry names cmad/models/small_elastic_plastic.py:95, small_rate_elastic_plastic.py */
 enum cm_model_kind { CM_SMALL_ELASTIC_PLASTIC = 0, CM_SMALL_RATE_ELASTIC_PLASTIC = 1 };
-/* cmad/models/effective_stress.py:15-27 (+ hybrid_hill :149-163) */
-enum cm_yield_kind { CM_YIELD_J2 = 0, CM_YIELD_HILL = 1, CM_YIELD_HOSFORD = 2, CM_YIELD_HYBRID_HILL_NN = 3 };
+/* cmad/models/effective_stress.py:15-27 (+ hybrid_hill :149-163, scaled_effective_stress around it :130-146) */
+enum cm_yield_kind { CM_YIELD_J2 = 0, CM_YIELD_HILL = 1, CM_YIELD_HOSFORD = 2, CM_YIELD_HYBRID_HILL_NN = 3,
+                     CM_YIELD_SCALED_HYBRID_HILL_NN = 4 };
 
 /* Kernel-level parameter order used by every sensitivity output ("KP order").
  * The Python facade maps it onto cmad.parameters' sorted-pytree flat order and applies the
@@ -91,10 +92,18 @@ typedef struct cm_model_desc {
     const double* nn_weights;
     int32_t nn_nlayers;
     int32_t nn_widths[7];
+    /* CM_YIELD_SCALED_HYBRID_HILL_NN: phi(s) = phi_h(beta s) / beta with beta from the scalar Newton
+     * phi_h(beta s) / beta_equivalent_stress = 1 started at Y / phi_J2(s)
+     * (beta_make_newton_solve(effective_stress_fun, equivalent_stress, max_iters, abs_tol, rel_tol),
+     *  models/effective_stress.py:97-108; its line search uses ls_c1 / ls_lo / ls_hi above with 4 evaluations) */
+    double  beta_equivalent_stress;
+    double  beta_abs_tol, beta_rel_tol;     /* default 1e-14 / 1e-14 */
+    int32_t beta_max_iters;                 /* default 10 */
+    int32_t reserved0;
 } cm_model_desc;
 
 /* library / build info */
-int  cm_abi_version(void);
+int  cm_abi_version(void);                       /* 2: cm_model_desc grew the beta_* fields */
 const char* cm_last_hip_error(void);             /* name of the last HIP error behind a CM_ERR_LAUNCH */
 int  cm_sizeof_model_desc(void);                 /* sizeof(cm_model_desc) as compiled, for binding checks */
 int  cm_num_xi(const cm_model_desc* m);          /* local dofs per point, <0 if unsupported */

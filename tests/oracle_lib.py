@@ -15,7 +15,7 @@ _SO = os.path.join(_ORACLE_DIR, "libcmad_oracle.so")
 
 FULL_3D, PLANE_STRAIN, PLANE_STRESS, UNIAXIAL_STRESS = 0, 1, 2, 3
 SMALL_EP, SMALL_RATE_EP = 0, 1
-Y_J2, Y_HILL, Y_HOSFORD, Y_HYBRID = 0, 1, 2, 3
+Y_J2, Y_HILL, Y_HOSFORD, Y_HYBRID, Y_SCALED_HYBRID = 0, 1, 2, 3, 4
 LS_NONE, LS_TRACED, LS_LEGACY = 0, 1, 2
 W_XI, W_XI_PREV, W_PARAMS, W_U, W_U_PREV = 0, 1, 2, 3, 4
 
@@ -34,7 +34,9 @@ class Desc(C.Structure):
     _fields_ = [("model_kind", C.c_int), ("def_type", C.c_int), ("yield_kind", C.c_int),
                 ("elastic_pair", C.c_int), ("has_voce", C.c_int), ("has_linear", C.c_int),
                 ("uniaxial_idx", C.c_int), ("hardening_order", C.c_int), ("yield_tol", C.c_double),
-                ("nn_nlayers", C.c_int), ("nn_widths", C.c_int * 8), ("nn_w", C.POINTER(C.c_double))]
+                ("nn_nlayers", C.c_int), ("nn_widths", C.c_int * 8), ("nn_w", C.POINTER(C.c_double)),
+                ("beta_equivalent_stress", C.c_double), ("beta_max_iters", C.c_int),
+                ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double)]
 
 
 class Newton(C.Structure):
@@ -114,7 +116,9 @@ class Material:
     """
 
     def __init__(self, values, def_type=FULL_3D, model_kind=SMALL_EP, yield_tol=1e-14, uniaxial_idx=0,
-                 nn=None):
+                 nn=None, scaled=None):
+        """nn = (layer_widths, packed weights) selects the hybrid Hill + ICNN surface; scaled = (equivalent_stress,
+        max_iters, abs_tol, rel_tol) wraps it in `scaled_effective_stress` (effective_stress.py:97-146)."""
         self.values = values
         p = np.zeros(NP)
         p[P_Q:P_Q + 9] = np.asarray(values.get("rotation matrix", np.eye(3)), dtype=float).reshape(9)
@@ -126,10 +130,10 @@ class Material:
         pl = values["plastic"]
         ykey = next(iter(pl["effective stress"]))
         if nn is not None:
-            yk = Y_HYBRID
+            yk = Y_SCALED_HYBRID if scaled is not None else Y_HYBRID
         else:
             yk = {"J2": Y_J2, "hill": Y_HILL, "hosford": Y_HOSFORD}[ykey]
-        if yk in (Y_HILL, Y_HYBRID):
+        if yk in (Y_HILL, Y_HYBRID, Y_SCALED_HYBRID):
             h = pl["effective stress"]["hill"]
             p[P_YC:P_YC + 6] = [float(h[k]) for k in HILL_NAMES]
         elif yk == Y_HOSFORD:
@@ -157,6 +161,10 @@ class Material:
             for i, w in enumerate(widths):
                 self.desc.nn_widths[i] = int(w)
             self.desc.nn_w = _p(packed)
+        if scaled is not None:
+            self.desc.beta_equivalent_stress = float(scaled[0])
+            self.desc.beta_max_iters = int(scaled[1])
+            self.desc.beta_abs_tol, self.desc.beta_rel_tol = float(scaled[2]), float(scaled[3])
         self.nx = lib().orc_nxi(C.byref(self.desc))
         self.nu = lib().orc_nu(C.byref(self.desc))
 

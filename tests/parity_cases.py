@@ -182,8 +182,11 @@ def check_hosford_a100(backend, B=2048):
 from cmad_amd.synthetic import al7079_hybrid_setup  # noqa: E402  (shared with bench.py)
 
 
-def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False):
-    from cmad_amd.models.device import HybridHillEffectiveStress, NewtonSettings, build_desc
+def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False, scaled=False):
+    """scaled: the beta-rescaled surface `scaled_effective_stress` (effective_stress.py:130-146) with the al7079
+    script's equivalent stress (nn_hill_uniaxial_stress_forward.py:74-78)."""
+    from cmad_amd.models.device import (HybridHillEffectiveStress, NewtonSettings, ScaledHybridHillEffectiveStress,
+                                        build_desc)
     from cmad_amd.synthetic import gauss_point_batch
 
     class S:
@@ -193,10 +196,11 @@ def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False):
     if rot:
         values["rotation matrix"] = rand_rot(np.random.default_rng(4))
     widths, packed = icnn.pack_for_device()
-    sc.mat = ol.Material(values, def_type=def_type, nn=(widths, packed))
+    sc.mat = ol.Material(values, def_type=def_type, nn=(widths, packed),
+                         scaled=(525.0, 10, 1e-14, 1e-14) if scaled else None)
     st_o = ol.newton_settings(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=10)
     st_d = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})
-    hyb = HybridHillEffectiveStress(icnn)
+    hyb = ScaledHybridHillEffectiveStress(icnn, 525.0) if scaled else HybridHillEffectiveStress(icnn)
     sc.desc, sc.info = build_desc(values, def_type=def_type, newton=st_d, hybrid=hyb)
     sc._keep = sc.info["nn_packed"]
     nd = 3 if def_type == ol.FULL_3D else 2

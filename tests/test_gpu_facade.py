@@ -471,3 +471,40 @@ def test_cli_calibrate(tmp_path, kind):
     import cli_cases
     from cmad_amd.cli.main import main
     cli_cases.check_calibrate(main, tmp_path, num_pts=50 if kind == "jvp" else 20, kind=kind)
+
+
+@pytest.mark.gpu
+def test_scaled_hybrid_uniaxial_stress_forward():
+    """Mirror of the reference's calibrations/al7079/nn_hill_uniaxial_stress_forward.py:84-151: UNIAXIAL_STRESS along
+    axis 1 with the beta-rescaled hybrid Hill + ICNN surface, rotated material frames, imperative newton_solve with
+    the legacy back-tracking (max_ls_evals=5); the script's own check is that the stress stays uniaxial."""
+    from cmad_amd.models import (DefType, ScaledHybridHillEffectiveStress, SmallElasticPlastic, mp_U_from_F,
+                                 newton_solve)
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.synthetic import al7079_hybrid_setup
+    icnn, values = al7079_hybrid_setup()
+    params = Parameters(values)
+    model = SmallElasticPlastic(params, DefType.UNIAXIAL_STRESS, uniaxial_stress_idx=1,
+                                effective_stress_fun=ScaledHybridHillEffectiveStress(icnn, 525.0))
+    num_steps = 40
+    F = np.repeat(np.eye(1)[:, :, None], num_steps + 1, axis=2)
+    F[0, 0, :] += np.linspace(0.0, 0.03, num_steps + 1)
+    rng = np.random.default_rng(3)
+    peak = []
+    for _ in range(2):
+        q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        params.set_rotation_matrix(q * np.sign(np.linalg.det(q)))
+        model.set_xi_to_init_vals()
+        cauchy = np.zeros((3, 3, num_steps + 1))
+        for step in range(1, num_steps + 1):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            iters, res = newton_solve(model, abs_tol=1e-13, rel_tol=1e-13, max_ls_evals=5)
+            assert res < 1e-11, (step, iters, res)
+            model.seed_none()
+            model.evaluate_cauchy()
+            cauchy[:, :, step] = model.Sigma().copy()
+            model.advance_xi()
+        assert abs(np.linalg.norm(cauchy) - np.linalg.norm(cauchy[1, 1, :])) < 1e-11
+        assert model.xi()[1][0] > 1e-3                          # the point did yield
+        peak.append(cauchy[1, 1, -1])
+    assert 400.0 < min(peak) and max(peak) < 2000.0 and abs(peak[0] - peak[1]) > 1e-3   # anisotropic response

@@ -84,6 +84,12 @@ def test_hybrid_hill_icnn(backend, def_type):
     pc.check_hybrid_nn(backend, def_type, B=2048, rot=(def_type == ol.FULL_3D))
 
 
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_scaled_hybrid_hill_icnn(backend, def_type):
+    """beta-rescaled network surface (`scaled_effective_stress`, effective_stress.py:130-146)."""
+    pc.check_hybrid_nn(backend, def_type, B=1024, rot=(def_type == ol.FULL_3D), scaled=True)
+
+
 def test_hybrid_through_the_facade():
     import torch
     from cmad_amd.models import DefType, HybridHillEffectiveStress, SmallElasticPlastic

@@ -95,6 +95,13 @@ def test_hybrid_hill_icnn(def_type, rot):
     pc.check_hybrid_nn(BACKEND, def_type, B=192, rot=rot)
 
 
+@pytest.mark.parametrize("def_type,rot", [(ol.FULL_3D, True), (ol.PLANE_STRESS, False)])
+def test_scaled_hybrid_hill_icnn(def_type, rot):
+    """`scaled_effective_stress`: inner scalar Newton for beta, closed-form normal and Hessian through the
+    implicit-function rule, against the oracle's dual-number differentiation of the same construction."""
+    pc.check_hybrid_nn(BACKEND, def_type, B=96, rot=rot, scaled=True)
+
+
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
