@@ -247,6 +247,26 @@ def main():
                                     "j2_objective_grad": "k_reverse<FULL_3D,J2,noROT,fused objective+grad>"}.get(wl, "k_update"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_update": bytes_per_update},
         }
+        if n == 1 and wl == "j2_update_vjp" and not ps and args.ls_evals == 0 and not args.j2_radial_line:
+            # the same workload with make_newton_solve's default line search (4 evaluations): same iterates for J2
+            # (every full step passes the Armijo test), the acceptance bookkeeping is the only extra work.
+            # Reported beside the headline, never as `value`.
+            nls = NewtonSettings.traced()
+            d2, i2 = build_desc(values, newton=nls)
+            ev2 = DeviceEvaluator(d2, i2)
+            for _ in range(2):
+                ev2.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(3, min(args.steps, 10))
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                ev2.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            res["with_line_search"] = {"max_evals": 4, "kernel_ms": ms, "value": B / (ms * 1e-3), "unit": "updates/s",
+                                       "roofline_frac": bytes_per_update * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if n == 1 and not args.no_cpu_baseline and wl == "j2_update_vjp":
             res["cpu_baseline"] = cpu_baseline(values)
         print(json.dumps(res))
