@@ -23,7 +23,7 @@ class ModelDesc(C.Structure):
         ("rotation_is_identity", C.c_int32), ("solver_flags", C.c_int32),
         ("yield_tol", C.c_double), ("Q", C.c_double * 9), ("lmbda", C.c_double), ("mu", C.c_double),
         ("Y", C.c_double), ("voce_S", C.c_double), ("voce_D", C.c_double), ("lin_K", C.c_double),
-        ("yc", C.c_double * 6),
+        ("yc", C.c_double * 19),
         ("max_iters", C.c_int32), ("ls_max_evals", C.c_int32),
         ("abs_tol", C.c_double), ("rel_tol", C.c_double),
         ("ls_c1", C.c_double), ("ls_lo", C.c_double), ("ls_hi", C.c_double),

@@ -267,6 +267,181 @@ CM_D double quad_min(double phi0, double dphi0, double a, double phi);
 
 // the network-backed surfaces (dense Hessian, no structured solve, no second-derivative kernel)
 constexpr bool is_nn_yield(int yk) { return yk == CM_YIELD_HYBRID_HILL_NN || yk == CM_YIELD_SCALED_HYBRID_HILL_NN; }
+// surfaces whose Hessian is a dense 6x6 (dense LU path only)
+constexpr bool is_dense_yield(int yk) { return is_nn_yield(yk) || yk == CM_YIELD_BARLAT; }
+
+// ---- Barlat Yld2004-18p (cmad/verification/functions.py:71-154, cmad/models/effective_stress.py:55-84) ----------
+// S' = L' s, S'' = L'' s (two linear maps of the stress), phi = (1/4 sum_ij |l'_i - l''_j|^a)^(1/a) over the
+// eigenvalues of S' and S''.  The reference differentiates through jnp.linalg.eigh; here the value, gradient and
+// Hessian come from the spectral representation of an isotropic function of two symmetric tensors:
+//   d l_i = v_i^T dS v_i ,   d2 l_i = 2 sum_{j != i} (v_i^T dS v_j)^2 / (l_i - l_j)
+//   with r_ij = |l'_i - l''_j| / phi, q_ij = sign r_ij^(a-1), D_ij = l'_i - l''_j:
+//   d phi = 1/4 sum q_ij dD_ij ,   d2 phi = (a-1)/phi [ 1/4 sum r_ij^(a-2) dD_ij^2 - d phi^2 ] + sum_x phi_x d2 l_x
+// Equal eigenvalues: (phi_i - phi_j)/(l_i - l_j) -> phi_ii - phi_ij (phi is symmetric in each triple), so nothing
+// is singular there -- unlike the eigh derivative rule, which divides by zero.
+// cyclic Jacobi, symmetric 3x3 given as [xx,xy,xz,yy,yz,zz]; V columns = eigenvectors
+CM_D void eig_sym3(const double s[6], double lam[3], double V[3][3]) {
+    double a00 = s[0], a01 = s[1], a02 = s[2], a11 = s[3], a12 = s[4], a22 = s[5];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    // one rotation in the (p, q) plane; app, aqq, apq the 2x2 block, apr / aqr the couplings to the third index
+#define CM_JACOBI(app, aqq, apq, apr, aqr, P, Q)                                                   \
+    if (apq != 0.0) {                                                                              \
+        const double theta = (aqq - app) / (2.0 * apq);                                            \
+        const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;                                      \
+        app -= t * apq; aqq += t * apq; apq = 0.0;                                                 \
+        const double xr = apr, yr = aqr;                                                           \
+        apr = c * xr - sn * yr; aqr = sn * xr + c * yr;                                            \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                            \
+            const double vp = V[k][P], vq = V[k][Q];                                               \
+            V[k][P] = c * vp - sn * vq; V[k][Q] = sn * vp + c * vq;                                \
+        }                                                                                          \
+    }
+    for (int sweep = 0; sweep < 6; ++sweep) {              // quadratic convergence: 4-5 sweeps reach round-off
+        CM_JACOBI(a00, a11, a01, a02, a12, 0, 1)
+        CM_JACOBI(a00, a22, a02, a01, a12, 0, 2)
+        CM_JACOBI(a11, a22, a12, a01, a02, 1, 2)
+    }
+#undef CM_JACOBI
+    lam[0] = a00; lam[1] = a11; lam[2] = a22;
+}
+
+// a_x = L^T (w o V(v v^T)) resp. L^T (w o V(sym(v_i v_j^T))): gradient of v_i^T S v_j w.r.t. the stress 6-vector
+CM_D void barlat_pull(const double UL[3][3], double c44, double c55, double c66,
+                      const double vi[3], const double vj[3], double out[6]) {
+    const double mxx = vi[0] * vj[0], myy = vi[1] * vj[1], mzz = vi[2] * vj[2];
+    out[0] = UL[0][0] * mxx + UL[1][0] * myy + UL[2][0] * mzz;
+    out[3] = UL[0][1] * mxx + UL[1][1] * myy + UL[2][1] * mzz;
+    out[5] = UL[0][2] * mxx + UL[1][2] * myy + UL[2][2] * mzz;
+    out[1] = c44 * (vi[0] * vj[1] + vi[1] * vj[0]);
+    out[2] = c66 * (vi[0] * vj[2] + vi[2] * vj[0]);
+    out[4] = c55 * (vi[1] * vj[2] + vi[2] * vj[1]);
+}
+
+template <bool HESS>
+CM_D void barlat_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
+    const double a = m.yc[18];
+    double lam[2][3], V[2][3][3], UL[2][3][3], csh[2][3];
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+        const double* q = m.yc + 9 * set;                      // c12, c13, c21, c23, c31, c32, c44, c55, c66
+        const double t3 = 1.0 / 3.0;
+        UL[set][0][0] = (q[0] + q[1]) * t3; UL[set][0][1] = (-2.0 * q[0] + q[1]) * t3; UL[set][0][2] = (q[0] - 2.0 * q[1]) * t3;
+        UL[set][1][0] = (-2.0 * q[2] + q[3]) * t3; UL[set][1][1] = (q[2] + q[3]) * t3; UL[set][1][2] = (q[2] - 2.0 * q[3]) * t3;
+        UL[set][2][0] = (-2.0 * q[4] + q[5]) * t3; UL[set][2][1] = (q[4] - 2.0 * q[5]) * t3; UL[set][2][2] = (q[4] + q[5]) * t3;
+        csh[set][0] = q[6]; csh[set][1] = q[7]; csh[set][2] = q[8];
+        double S6[6];
+        S6[0] = UL[set][0][0] * s[0] + UL[set][0][1] * s[3] + UL[set][0][2] * s[5];
+        S6[3] = UL[set][1][0] * s[0] + UL[set][1][1] * s[3] + UL[set][1][2] * s[5];
+        S6[5] = UL[set][2][0] * s[0] + UL[set][2][1] * s[3] + UL[set][2][2] * s[5];
+        S6[1] = q[6] * s[1]; S6[4] = q[7] * s[4]; S6[2] = q[8] * s[2];     // xy: c44, yz: c55, zx: c66
+        eig_sym3(S6, lam[set], V[set]);
+    }
+    double Dm[3][3], mx = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Dm[i][j] = lam[0][i] - lam[1][j]; mx = fmax(mx, fabs(Dm[i][j])); }
+    const double imx = (mx > 0.0) ? 1.0 / mx : 0.0;
+    double u[3][3], ua[3][3], Ssum = 0.0;
+    const int ai = (int)a;
+    const bool int_a = (a == (double)ai) && ai >= 2 && ai <= 65536;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            u[i][j] = fabs(Dm[i][j]) * imx;
+            double p;
+            if (int_a) {
+                p = 1.0;
+                double base = u[i][j];
+                for (int e = ai; e != 0; e >>= 1) { if (e & 1) p *= base; base *= base; }
+            } else p = (u[i][j] > 0.0) ? exp(a * log(u[i][j])) : 0.0;
+            ua[i][j] = p; Ssum += p;
+        }
+    Ssum *= 0.25;
+    const double Sr = (Ssum > 0.0) ? exp(log(Ssum) / a) : 0.0;
+    phi = mx * Sr;
+    const double c2 = (Ssum > 0.0) ? Sr * Sr / Ssum : 0.0;
+    // q_ij = sign r^(a-1), e_ij = r^(a-2) with r = |D| / phi = u / Sr
+    double qm[3][3], em[3][3], f1[3] = {0.0, 0.0, 0.0}, f2[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double uu = u[i][j];
+            em[i][j] = (uu > 0.0) ? ua[i][j] * c2 / (uu * uu) : ((a == 2.0) ? 1.0 : 0.0);
+            const double r = (Ssum > 0.0) ? uu / Sr : 0.0;
+            qm[i][j] = ((Dm[i][j] > 0.0) ? 1.0 : ((Dm[i][j] < 0.0) ? -1.0 : 0.0)) * em[i][j] * r;
+            f1[i] += 0.25 * qm[i][j]; f2[j] -= 0.25 * qm[i][j];       // d phi / d l'_i , d phi / d l''_j
+        }
+    double ax[2][3][6];                                        // gradients of the eigenvalues w.r.t. the stress
+#pragma unroll
+    for (int set = 0; set < 2; ++set)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double vi[3] = {V[set][0][i], V[set][1][i], V[set][2][i]};
+            barlat_pull(UL[set], csh[set][0], csh[set][1], csh[set][2], vi, vi, ax[set][i]);
+        }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double g = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g += f1[i] * ax[0][i][k] + f2[i] * ax[1][i][k];
+        gt[k] = g;
+    }
+    if constexpr (HESS) {
+        const double ip = (phi > 0.0) ? 1.0 / phi : 0.0, am1 = (a - 1.0) * ip;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int l = 0; l < 6; ++l) Ht[k][l] = -am1 * gt[k] * gt[l];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double cf = 0.25 * am1 * em[i][j];
+                double dv[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dv[k] = ax[0][i][k] - ax[1][j][k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+#pragma unroll
+                    for (int l = 0; l < 6; ++l) Ht[k][l] += cf * dv[k] * dv[l];
+            }
+        // eigenvector rotation terms: 2 theta_ij b_ij b_ij^T, theta_ij = (phi_i - phi_j) / (l_i - l_j)
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+            const double* fx = set ? f2 : f1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i + 1; j < 3; ++j) {
+                    const double dl = lam[set][i] - lam[set][j];
+                    const double scale = fabs(lam[set][i]) + fabs(lam[set][j]) + mx;
+                    double theta;
+                    if (fabs(dl) > 1e-7 * scale) theta = (fx[i] - fx[j]) / dl;
+                    else {                                     // limit: phi_ii - phi_ij in eigenvalue space
+                        double hii = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) hii += 0.25 * am1 * (set ? em[k][i] : em[i][k]);
+                        theta = hii - am1 * fx[i] * fx[i] + am1 * fx[i] * fx[j];
+                    }
+                    const double vi[3] = {V[set][0][i], V[set][1][i], V[set][2][i]};
+                    const double vj[3] = {V[set][0][j], V[set][1][j], V[set][2][j]};
+                    double b[6];
+                    barlat_pull(UL[set], csh[set][0], csh[set][1], csh[set][2], vi, vj, b);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+#pragma unroll
+                        for (int l = 0; l < 6; ++l) Ht[k][l] += 2.0 * theta * b[k] * b[l];
+                }
+        }
+    }
+}
 
 template <int YK, bool HESS>
 CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]);
@@ -379,7 +554,9 @@ CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& 
 
 template <int YK, bool HESS>
 CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
-    if constexpr (YK == CM_YIELD_SCALED_HYBRID_HILL_NN) {
+    if constexpr (YK == CM_YIELD_BARLAT) {
+        barlat_eval<HESS>(m, s, phi, gt, Ht);
+    } else if constexpr (YK == CM_YIELD_SCALED_HYBRID_HILL_NN) {
         scaled_hybrid_eval<HESS>(m, s, phi, gt, Ht);
     } else if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
         yield_eval<CM_YIELD_HILL, HESS>(m, s, phi, gt, Ht);

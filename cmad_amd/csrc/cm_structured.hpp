@@ -618,7 +618,7 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
 // (STRUCT = false forces the dense path) -------------------------------------------------------------------
 template <int DEF, int YK>
 constexpr bool has_structured() {
-    return (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS) && !is_nn_yield(YK);
+    return (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS) && !is_dense_yield(YK);
 }
 // RL: the opt-in J2 radial-line iteration (cm_model_desc.solver_flags & CM_SOLVER_J2_RADIAL_LINE); a compile-time
 // variant chosen by the launcher so that the default kernels do not carry its code and registers.

@@ -62,6 +62,9 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_UPD_HYBRID
 #define CM_OCC_UPD_HYBRID 2         // 268-276 -> 256 VGPRs: two waves per SIMD for the exp/log-bound network kernels
 #endif
+#ifndef CM_OCC_UPD_BARLAT
+#define CM_OCC_UPD_BARLAT 1
+#endif
 #ifndef CM_OCC_REV_J2_LS
 #define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
@@ -73,6 +76,7 @@ constexpr int min_waves_update() {
     if (YK == CM_YIELD_J2) return LS ? CM_OCC_UPD_J2_LS : CM_OCC_UPD_J2;
     if (YK == CM_YIELD_HOSFORD) return LS ? CM_OCC_UPD_HOSFORD_LS : CM_OCC_UPD_HOSFORD;
     if (is_nn_yield(YK)) return CM_OCC_UPD_HYBRID;
+    if (YK == CM_YIELD_BARLAT) return CM_OCC_UPD_BARLAT;
     return 1;
 }
 
@@ -472,6 +476,7 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     if (is_nn_yield(m->yield_kind))                    // one hidden layer [6, H, 1], weights resident on the device
         return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
                m->nn_widths[1] >= 1 && m->nn_widths[1] <= 256;
+    if (m->yield_kind == CM_YIELD_BARLAT) return m->yc[18] >= 1.0;
     if (m->yield_kind != CM_YIELD_J2 && m->yield_kind != CM_YIELD_HILL && m->yield_kind != CM_YIELD_HOSFORD) return false;
     return true;
 }
@@ -497,7 +502,10 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_FULL_3D, CM_YIELD_SCALED_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
+    CM_CASE(CM_FULL_3D, CM_YIELD_BARLAT)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_BARLAT)
     if constexpr (UNI) {
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_BARLAT)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_J2)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)
@@ -585,7 +593,7 @@ extern "C" {
 
 
 #if CM_HAS_PART(1)
-int cm_abi_version(void) { return 2; }
+int cm_abi_version(void) { return 3; }
 #endif
 
 #if CM_HAS_PART(1)
@@ -727,7 +735,7 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
 int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m) || is_nn_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi) return CM_ERR_BAD_ARG;
     const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
@@ -737,7 +745,7 @@ int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const do
     const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!is_nn_yield(Y))
+        if constexpr (!is_dense_yield(Y))
             hipLaunchKernelGGL((k_hessians<D, Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, d2C, d2S, dC, dS);
     });
     if (!found) return CM_ERR_UNSUPPORTED;

@@ -16,8 +16,11 @@ from .. import _lib
 from .deformation_types import DefType
 from .elastic_constants import lame_jacobian
 
-YIELD_KINDS = {"J2": 0, "hill": 1, "hosford": 2}
+YIELD_KINDS = {"J2": 0, "hill": 1, "hosford": 2, "barlat": 5}
 HILL_NAMES = ("F", "G", "H", "L", "M", "N")
+# flatten_barlat_params order, cmad/models/effective_stress.py:55-78
+BARLAT_NAMES = tuple(f"{pre}_{ij}" for pre in ("sp", "dp")
+                     for ij in ("12", "13", "21", "23", "31", "32", "44", "55", "66")) + ("a",)
 
 # cmad/util/line_search.py:40-46
 DEFAULT_LINE_SEARCH_SETTINGS = {
@@ -134,6 +137,10 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
             d.yc[i] = float(h[n])
     elif ytype == "hosford":
         d.yc[0] = float(plastic["effective stress"]["hosford"]["a"])
+    elif ytype == "barlat":
+        coeffs = plastic["effective stress"]["barlat"]
+        for i, n in enumerate(BARLAT_NAMES):
+            d.yc[i] = float(coeffs[n])
     d.uniaxial_idx = int(uniaxial_stress_idx)
     d.yield_tol = float(yield_tol)
     d.max_iters = int(newton.max_iters)
@@ -182,6 +189,8 @@ def kp_to_leaf_grad(path, g_kp, info):
         return g_kp[0] * 0.0
     if parent == "hosford":
         raise NotImplementedError("sensitivity w.r.t. the Hosford exponent is not available in the HIP path")
+    if parent == "barlat":
+        raise NotImplementedError("sensitivities w.r.t. the Barlat coefficients are not available in the HIP path")
     raise KeyError(path)
 
 

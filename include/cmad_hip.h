@@ -42,7 +42,7 @@ enum cm_def_type { CM_FULL_3D = 0, CM_PLANE_STRAIN = 1, CM_PLANE_STRESS = 2, CM_
 enum cm_model_kind { CM_SMALL_ELASTIC_PLASTIC = 0, CM_SMALL_RATE_ELASTIC_PLASTIC = 1 };
 /* cmad/models/effective_stress.py:15-27 (+ hybrid_hill :149-163, scaled_effective_stress around it :130-146) */
 enum cm_yield_kind { CM_YIELD_J2 = 0, CM_YIELD_HILL = 1, CM_YIELD_HOSFORD = 2, CM_YIELD_HYBRID_HILL_NN = 3,
-                     CM_YIELD_SCALED_HYBRID_HILL_NN = 4 };
+                     CM_YIELD_SCALED_HYBRID_HILL_NN = 4, CM_YIELD_BARLAT = 5 /* Yld2004-18p, verification/functions.py:71-154 */ };
 
 /* Kernel-level parameter order used by every sensitivity output ("KP order").
  * The Python facade maps it onto cmad.parameters' sorted-pytree flat order and applies the
@@ -81,7 +81,8 @@ typedef struct cm_model_desc {
     double  Y;                  /* initial yield */
     double  voce_S, voce_D;     /* Voce S(1 - exp(-D alpha)) */
     double  lin_K;              /* linear K alpha */
-    double  yc[6];              /* hill F,G,H,L,M,N | hosford a in yc[0] */
+    double  yc[19];             /* hill F,G,H,L,M,N | hosford a in yc[0] | barlat sp_12,sp_13,sp_21,sp_23,sp_31,sp_32,
+                                 * sp_44,sp_55,sp_66, dp_12 ... dp_66, a (effective_stress.py:55-78) */
     /* local Newton (models/nonlinear_solver.py:88-155) */
     int32_t max_iters;          /* default 10 (MP path) / 20 (FE binding) */
     int32_t ls_max_evals;       /* 0 = plain Newton (imperative newton_solve default); default 4 traced */
@@ -103,7 +104,7 @@ typedef struct cm_model_desc {
 } cm_model_desc;
 
 /* library / build info */
-int  cm_abi_version(void);                       /* 2: cm_model_desc grew the beta_* fields */
+int  cm_abi_version(void);                       /* 3: cm_model_desc.yc holds 19 entries (Barlat), beta_* fields */
 const char* cm_last_hip_error(void);             /* name of the last HIP error behind a CM_ERR_LAUNCH */
 int  cm_sizeof_model_desc(void);                 /* sizeof(cm_model_desc) as compiled, for binding checks */
 int  cm_num_xi(const cm_model_desc* m);          /* local dofs per point, <0 if unsupported */

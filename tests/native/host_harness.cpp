@@ -137,7 +137,7 @@ template <int DEF, int YK, bool ROT>
 static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                          double* d2C, double* d2S, double* dC, double* dS) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
-    if constexpr (!is_nn_yield(YK)) {
+    if constexpr (!is_dense_yield(YK)) {
         for (int64_t pt = 0; pt < B; ++pt) {
             double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6];
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt];
@@ -170,7 +170,10 @@ static int dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_FULL_3D, CM_YIELD_SCALED_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
+    CM_CASE(CM_FULL_3D, CM_YIELD_BARLAT)
+    CM_CASE(CM_PLANE_STRESS, CM_YIELD_BARLAT)
     if constexpr (UNI) {
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_BARLAT)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_J2)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)

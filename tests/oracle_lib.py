@@ -15,7 +15,8 @@ _SO = os.path.join(_ORACLE_DIR, "libcmad_oracle.so")
 
 FULL_3D, PLANE_STRAIN, PLANE_STRESS, UNIAXIAL_STRESS = 0, 1, 2, 3
 SMALL_EP, SMALL_RATE_EP = 0, 1
-Y_J2, Y_HILL, Y_HOSFORD, Y_HYBRID, Y_SCALED_HYBRID = 0, 1, 2, 3, 4
+Y_J2, Y_HILL, Y_HOSFORD, Y_HYBRID, Y_SCALED_HYBRID, Y_BARLAT = 0, 1, 2, 3, 4, 5
+BARLAT_NAMES = tuple(f"{pre}_{ij}" for pre in ("sp", "dp") for ij in ("12", "13", "21", "23", "31", "32", "44", "55", "66")) + ("a",)
 LS_NONE, LS_TRACED, LS_LEGACY = 0, 1, 2
 W_XI, W_XI_PREV, W_PARAMS, W_U, W_U_PREV = 0, 1, 2, 3, 4
 
@@ -36,7 +37,7 @@ class Desc(C.Structure):
                 ("uniaxial_idx", C.c_int), ("hardening_order", C.c_int), ("yield_tol", C.c_double),
                 ("nn_nlayers", C.c_int), ("nn_widths", C.c_int * 8), ("nn_w", C.POINTER(C.c_double)),
                 ("beta_equivalent_stress", C.c_double), ("beta_max_iters", C.c_int),
-                ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double)]
+                ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double), ("barlat", C.c_double * 19)]
 
 
 class Newton(C.Structure):
@@ -132,7 +133,7 @@ class Material:
         if nn is not None:
             yk = Y_SCALED_HYBRID if scaled is not None else Y_HYBRID
         else:
-            yk = {"J2": Y_J2, "hill": Y_HILL, "hosford": Y_HOSFORD}[ykey]
+            yk = {"J2": Y_J2, "hill": Y_HILL, "hosford": Y_HOSFORD, "barlat": Y_BARLAT}[ykey]
         if yk in (Y_HILL, Y_HYBRID, Y_SCALED_HYBRID):
             h = pl["effective stress"]["hill"]
             p[P_YC:P_YC + 6] = [float(h[k]) for k in HILL_NAMES]
@@ -161,6 +162,10 @@ class Material:
             for i, w in enumerate(widths):
                 self.desc.nn_widths[i] = int(w)
             self.desc.nn_w = _p(packed)
+        if yk == Y_BARLAT:
+            bc = pl["effective stress"]["barlat"]
+            for i, name in enumerate(BARLAT_NAMES):
+                self.desc.barlat[i] = float(bc[name])
         if scaled is not None:
             self.desc.beta_equivalent_stress = float(scaled[0])
             self.desc.beta_max_iters = int(scaled[1])
@@ -301,7 +306,7 @@ class Material:
         return g, xb, ub
 
 
-def j2_voce_values(E=200e3, nu=0.3, Y=200., S=200., D=20., Q=None, yield_kind="J2", hill=None, a=None):
+def j2_voce_values(E=200e3, nu=0.3, Y=200., S=200., D=20., Q=None, yield_kind="J2", hill=None, a=None, barlat=None):
     """Parameter tree of tests/support/test_problems.py:9-40 (J2 / J2-equivalent Hill / Hosford)."""
     if yield_kind == "J2":
         eff = {"J2": 0.}
@@ -310,6 +315,9 @@ def j2_voce_values(E=200e3, nu=0.3, Y=200., S=200., D=20., Q=None, yield_kind="J
         eff = {"hill": dict(zip(HILL_NAMES, [float(x) for x in h]))}
     elif yield_kind == "hosford":
         eff = {"hosford": {"a": 4. if a is None else float(a)}}
+    elif yield_kind == "barlat":
+        coeffs = np.r_[np.ones(18), 4. if a is None else float(a)] if barlat is None else np.asarray(barlat, dtype=float)
+        eff = {"barlat": dict(zip(BARLAT_NAMES, [float(x) for x in coeffs]))}
     else:
         raise ValueError(yield_kind)
     return {

@@ -9,7 +9,15 @@ import oracle_lib as ol
 
 XI_ATOL = 1e-13
 HILL = [0.1477, 0.6805, 0.5345, 1.7977, 1.7148, 2.1675]
-YIELDS = [("J2", {}), ("hill", {"hill": HILL}), ("hosford", {"a": 4.}), ("hosford", {"a": 8.5})]      # 8.5: the non-integer exp/log branch of the Hosford powers
+# Yld2004-18p coefficients of cmad/calibrations/al7079/support.py:80-88 (sp_12 ... dp_66, a = 18.2)
+AL7079_BARLAT = [0.4555, 1.0274, 0.7101, 1.3755, 0.5314, 0.8817, 1.0558, 1.1133, 0.9220,
+                 1.2431, 1.5438, 1.2204, 0.7632, 0.5327, 0.3015, 0.9722, 0.7399, 1.0760, 18.2]
+# generic scenarios use the exponent 8 (plain Newton converges everywhere); the calibrated 18.2 needs the line
+# search and has its own scenario, check_barlat_calibrated
+BARLAT = ("barlat", {"barlat": AL7079_BARLAT[:18] + [8.0]})
+# 8.5: the non-integer exp/log branch of the Hosford powers
+YIELDS = [("J2", {}), ("hill", {"hill": HILL}), ("hosford", {"a": 4.}), ("hosford", {"a": 8.5}), BARLAT]
+SENS_YIELDS = YIELDS[:3] + [BARLAT]              # tangent / vjp / objective scenarios
 
 
 def rand_rot(rng):
@@ -180,6 +188,14 @@ def check_hosford_a100(backend, B=2048):
 
 
 from cmad_amd.synthetic import al7079_hybrid_setup  # noqa: E402  (shared with bench.py)
+
+
+def check_barlat_calibrated(backend, def_type=ol.FULL_3D, B=512, rot=True):
+    """Yld2004-18p with the Al7079 coefficients and exponent 18.2 (calibrations/al7079/support.py:80-88) under the
+    traced Newton with its default line search: two load steps + the reverse sweep, device vs oracle."""
+    sc = Scenario(def_type, "barlat", {"barlat": AL7079_BARLAT}, rot, True, B=B)
+    check_update(backend, sc)
+    check_vjp(backend, sc)
 
 
 def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False, scaled=False):

@@ -7,7 +7,7 @@ import oracle_lib as ol
 import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
-CASES = pc.YIELDS[:3]
+CASES = pc.SENS_YIELDS
 IDX9 = [0, 1, 2, 1, 3, 4, 2, 4, 5]
 
 

@@ -85,6 +85,12 @@ def test_hybrid_hill_icnn(backend, def_type):
 
 
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_barlat_calibrated_coefficients(backend, def_type):
+    """Yld2004-18p, Al7079 coefficients, a = 18.2."""
+    pc.check_barlat_calibrated(backend, def_type, B=2048)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_scaled_hybrid_hill_icnn(backend, def_type):
     """beta-rescaled network surface (`scaled_effective_stress`, effective_stress.py:130-146)."""
     pc.check_hybrid_nn(backend, def_type, B=1024, rot=(def_type == ol.FULL_3D), scaled=True)

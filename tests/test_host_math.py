@@ -28,14 +28,14 @@ def test_update(def_type, yield_kind, kw, rot, ls):
 
 
 @pytest.mark.parametrize("rot", [False, True])
-@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("yield_kind,kw", pc.SENS_YIELDS)
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_tangent(def_type, yield_kind, kw, rot):
     pc.check_tangent(BACKEND, pc.Scenario(def_type, yield_kind, kw, rot, False, B=256))
 
 
 @pytest.mark.parametrize("rot", [False, True])
-@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("yield_kind,kw", pc.SENS_YIELDS)
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_vjp(def_type, yield_kind, kw, rot):
     pc.check_vjp(BACKEND, pc.Scenario(def_type, yield_kind, kw, rot, False, B=256))
@@ -43,7 +43,7 @@ def test_vjp(def_type, yield_kind, kw, rot):
 
 @pytest.mark.parametrize("plastic", [True, False])
 @pytest.mark.parametrize("rot", [False, True])
-@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("yield_kind,kw", pc.SENS_YIELDS)
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_explicit_blocks_at_arbitrary_states(def_type, yield_kind, kw, rot, plastic):
     """cm_evaluate's blocks (C, dC/dxi, dC/dxi_prev, dC/dparams, dC/dgradu, sigma and its derivatives) at
@@ -93,6 +93,11 @@ def test_hosford_a100_notch_material():
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_hybrid_hill_icnn(def_type, rot):
     pc.check_hybrid_nn(BACKEND, def_type, B=192, rot=rot)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_barlat_calibrated_coefficients(def_type):
+    pc.check_barlat_calibrated(BACKEND, def_type, B=256)
 
 
 @pytest.mark.parametrize("def_type,rot", [(ol.FULL_3D, True), (ol.PLANE_STRESS, False)])
