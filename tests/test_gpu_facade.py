@@ -508,3 +508,32 @@ def test_scaled_hybrid_uniaxial_stress_forward():
         assert model.xi()[1][0] > 1e-3                          # the point did yield
         peak.append(cauchy[1, 1, -1])
     assert 400.0 < min(peak) and max(peak) < 2000.0 and abs(peak[0] - peak[1]) > 1e-3   # anisotropic response
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("history", ["uniaxial", "biaxial"])
+def test_isotropic_barlat_reproduces_the_j2_analytical_fields(history):
+    """Yld2004-18p with unit coefficients and a = 4 is von Mises: the facade model with a `barlat` parameter block
+    must reproduce the reference's analytical J2 + Voce fields (tests/models/test_elastic_plastic_models.py:15-125,
+    tolerance 1e-6) -- including the uniaxial history, whose repeated eigenvalue is where differentiating through
+    eigh breaks down and the kernel's spectral form takes the limit instead."""
+    from cmad_amd.models import DefType, SmallElasticPlastic, mp_U_from_F, newton_solve
+    from cmad_amd.parameters import Parameters
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "j2_voce_analytical.npz"))
+    stress, strain, alpha = g[f"{history}_stress"], g[f"{history}_strain"], g[f"{history}_alpha"]
+    values = ol.j2_voce_values(yield_kind="barlat", a=4.0)
+    model = SmallElasticPlastic(Parameters(values), DefType.FULL_3D)
+    n = strain.shape[2]
+    F = np.repeat(np.eye(3)[:, :, None], n + 1, axis=2)
+    F[:, :, 1:] += strain
+    cauchy, alphas = np.zeros((3, 3, n + 1)), np.zeros(n)
+    model.set_xi_to_init_vals()
+    for step in range(1, n + 1):
+        model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+        newton_solve(model)
+        model.advance_xi()
+        model.evaluate_cauchy()
+        cauchy[:, :, step] = model.Sigma()
+        alphas[step - 1] = model.xi()[1][0]
+    assert np.linalg.norm(alphas - alpha) < 1e-6
+    assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6
