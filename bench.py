@@ -78,9 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000, help="Gauss points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--j2-radial-line", action="store_true",
-                    help="opt into CM_SOLVER_J2_RADIAL_LINE (same Newton iterates restricted to the radial line); "
-                         "side measurement, never the default")
+    ap.add_argument("--general-newton", action="store_true",
+                    help="CM_SOLVER_GENERAL_NEWTON: force the general 7-dof Newton where the J2 radial-line "
+                         "restriction (same iterates) would apply; side measurement")
     ap.add_argument("--ls-evals", type=int, default=0,
                     help="J2 workloads: line-search evaluations per Newton iteration (0 = newton_solve defaults, "
                          "4 = make_newton_solve defaults)")
@@ -115,7 +115,7 @@ def main():
     B = args.points
     wl = args.workload
     values = j2_voce_values()
-    newton = NewtonSettings(j2_radial_line=args.j2_radial_line)   # newton_solve defaults: 10 iters, 1e-14, no line search
+    newton = NewtonSettings(j2_radial_line=not args.general_newton)   # newton_solve defaults: 10 iters, 1e-14, no line search
     if args.ls_evals > 0:                          # make_newton_solve: same tolerances + Armijo line search
         newton = NewtonSettings.traced(line_search_settings={"max evals": args.ls_evals})
     eps_y, hybrid, bytes_per_update = 1e-3, None, BYTES_PER_UPDATE
@@ -236,37 +236,44 @@ def main():
                 "def_type": args.def_type, "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
                 "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
                            "line_search_max_evals": newton.line_search["max evals"],
-                           "solver": "J2 radial-line restriction of the 7-dof Newton (opt-in)" if args.j2_radial_line
-                                     else "general 7-dof Newton, structured block solve"},
+                           "solver": ("general 7-dof Newton, structured block solve"
+                                      if (args.general_newton or args.ls_evals > 0 or ps or not wl.startswith("j2_")) else
+                                      "7-dof Newton restricted to the J2 radial line it never leaves (identical iterates "
+                                      "and iteration counts; CM_SOLVER_GENERAL_NEWTON turns it off)")},
                 "parallelism": f"dp{n}: disjoint point shards; one RCCL all-reduce of the 12 fp64 gradient entries per "
                                "step, double-buffered so it overlaps the next step's kernel",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(B) if wl == "j2_update_vjp" else None,
-                         "kernel": {"j2_update_vjp": "k_reverse<FULL_3D,J2,noROT,fused update+vjp>",
+                         "kernel": {"j2_update_vjp": "k_reverse<FULL_3D,J2,noROT,noLS,fused update+vjp,radial-line>"
+                                    if not (args.general_newton or args.ls_evals > 0 or ps) else
+                                    "k_reverse<J2,noROT,fused update+vjp>",
                                     "j2_objective_grad": "k_reverse<FULL_3D,J2,noROT,fused objective+grad>"}.get(wl, "k_update"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_update": bytes_per_update},
         }
-        if n == 1 and wl == "j2_update_vjp" and not ps and args.ls_evals == 0 and not args.j2_radial_line:
-            # the same workload with make_newton_solve's default line search (4 evaluations): same iterates for J2
-            # (every full step passes the Armijo test), the acceptance bookkeeping is the only extra work.
+        if n == 1 and wl == "j2_update_vjp" and not ps and args.ls_evals == 0 and not args.general_newton:
+            # the same workload (i) on the general 7-dof Newton path (no J2 specialisation) and (ii) with
+            # make_newton_solve's default line search (4 evaluations; for J2 every full step passes the Armijo test,
+            # so the iterates are the same and the acceptance bookkeeping is the only extra work).
             # Reported beside the headline, never as `value`.
-            nls = NewtonSettings.traced()
-            d2, i2 = build_desc(values, newton=nls)
-            ev2 = DeviceEvaluator(d2, i2)
-            for _ in range(2):
-                ev2.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = max(3, min(args.steps, 10))
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                ev2.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            res["with_line_search"] = {"max_evals": 4, "kernel_ms": ms, "value": B / (ms * 1e-3), "unit": "updates/s",
-                                       "roofline_frac": bytes_per_update * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            def side(settings):
+                d2, i2 = build_desc(values, newton=settings)
+                ev2 = DeviceEvaluator(d2, i2)
+                for _ in range(2):
+                    ev2.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = max(3, min(args.steps, 10))
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    ev2.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                return {"kernel_ms": ms, "value": B / (ms * 1e-3), "unit": "updates/s",
+                        "roofline_frac": bytes_per_update * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            res["general_newton"] = side(NewtonSettings(j2_radial_line=False))
+            res["with_line_search"] = dict(side(NewtonSettings.traced()), max_evals=4)
         if n == 1 and not args.no_cpu_baseline and wl == "j2_update_vjp":
             res["cpu_baseline"] = cpu_baseline(values)
         print(json.dumps(res))

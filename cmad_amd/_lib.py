@@ -8,6 +8,7 @@ from .build import LIB
 CM_NUM_PARAMS = 12
 P_LAMBDA, P_MU, P_Y, P_VOCE_S, P_VOCE_D, P_LIN_K, P_YC0 = 0, 1, 2, 3, 4, 5, 6
 SOLVER_J2_RADIAL_LINE = 1
+SOLVER_GENERAL_NEWTON = 2
 STATUS_ITERS_MASK, STATUS_CONVERGED, STATUS_PLASTIC, STATUS_SINGULAR = 0xFFFF, 1 << 16, 1 << 17, 1 << 18
 CM_OK, CM_ERR_BAD_ARG, CM_ERR_UNSUPPORTED, CM_ERR_LAUNCH, CM_ERR_WORKSPACE = 0, -1, -2, -3, -4
 

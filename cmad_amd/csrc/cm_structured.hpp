@@ -465,10 +465,18 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
     for (int k = 0; k < 6; ++k) x[k] = xp[k] + dgam * ev.y.gt[k] * kIW[k];
     x[6] = alpha;
     uint32_t st = flags | (uint32_t)it;
+    // evaluation at the returned state: the reverse sweep needs it, and convergence is confirmed on the full
+    // residual there -- the scalar f of the line and the 7-dof residual differ by round-off, and a lane that stopped
+    // within that distance of the tolerance must behave exactly like the general path (e.g. re-applying the same
+    // strain to the returned state is a 0-iteration step).  Such a lane (about one in 10^6) takes the general path.
+    residual_s<CM_YIELD_J2>(m, eg, x, xp, ev, C);
+    if (flags & CM_STATUS_CONVERGED) {
+        const double nsq = dot<7>(C, C);
+        if (!((nsq < rel2) || (nsq < abs2))) fallback = true;
+    }
     if (__any(fallback)) {
         if (fallback) st = newton_s<CM_YIELD_J2, false>(m, eg, xp, x, lane_valid, ev);
     }
-    if (!fallback) residual_s<CM_YIELD_J2>(m, eg, x, xp, ev, C);   // evaluation at the returned state (reverse sweep)
     return st;
 }
 

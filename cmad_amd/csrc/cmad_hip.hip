@@ -535,7 +535,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
     const bool found = dispatch<!TANGENT>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && !LS) {
-            if (m->solver_flags & CM_SOLVER_J2_RADIAL_LINE) {
+            if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
                 return;
             }
@@ -569,7 +569,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
         const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) {
-                if (m->solver_flags & CM_SOLVER_J2_RADIAL_LINE) {
+                if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_reverse<D, Y, R, false, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                        hist_in, xi_out, sigma_out, xpbar, gbar, partials);
                     return;

@@ -40,9 +40,10 @@ class NewtonSettings:
     abs_tol: float = 1e-14
     rel_tol: float = 1e-14
     line_search: dict = field(default_factory=lambda: {**DEFAULT_LINE_SEARCH_SETTINGS, "max evals": 0})
-    # opt-in: J2 / FULL_3D / no line search runs the Newton iteration restricted to the radial line it never
-    # leaves (same iterates and counts; include/cmad_hip.h CM_SOLVER_J2_RADIAL_LINE).  Ignored elsewhere.
-    j2_radial_line: bool = False
+    # J2 / FULL_3D / no line search: the kernels run the Newton iteration restricted to the radial line it never
+    # leaves (same iterates and counts).  False forces the general 7-dof iteration
+    # (include/cmad_hip.h CM_SOLVER_GENERAL_NEWTON).  Ignored for every other configuration.
+    j2_radial_line: bool = True
 
     @classmethod
     def traced(cls, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search_settings=None):
@@ -150,7 +151,7 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     d.ls_c1 = float(ls.get("sufficient decrease", 1e-4))
     d.ls_lo = float(ls.get("min backtrack factor", 0.5))
     d.ls_hi = float(ls.get("max backtrack factor", 0.9))
-    d.solver_flags = _lib.SOLVER_J2_RADIAL_LINE if getattr(newton, "j2_radial_line", False) else 0
+    d.solver_flags = 0 if getattr(newton, "j2_radial_line", True) else _lib.SOLVER_GENERAL_NEWTON
     info = {"elastic_names": names, "lame_jac": J, "yield_type": ytype}
     if hybrid is not None:
         widths, packed = hybrid.packed(values)

@@ -53,9 +53,13 @@ enum cm_param_index {
     CM_NUM_PARAMS = 12
 };
 
-/* solver_flags: for J2 in FULL_3D without line search, run the Newton iteration restricted to the radial line
- * it never leaves (identical iterates and iteration counts, scalar linear algebra).  Off by default. */
+/* solver_flags.  For J2 in FULL_3D without line search the Newton iteration started at x_prev never leaves the
+ * radial line v = v_prev + dgam n_trial, so the kernels run the same iteration restricted to that line (identical
+ * iterates and iteration counts, scalar linear algebra; a lane whose iterate would cross to the elastic branch
+ * falls back to the general path).  CM_SOLVER_GENERAL_NEWTON switches every such specialisation off;
+ * CM_SOLVER_J2_RADIAL_LINE is accepted for compatibility (the restriction is the default). */
 #define CM_SOLVER_J2_RADIAL_LINE 1
+#define CM_SOLVER_GENERAL_NEWTON 2
 
 /* status word written per point by cm_update* (all optional outputs may be NULL) */
 #define CM_STATUS_ITERS_MASK 0xFFFFu
@@ -74,7 +78,7 @@ typedef struct cm_model_desc {
     int32_t has_linear;         /* hardening dict contains "linear" (models/hardening.py:16-19) */
     int32_t uniaxial_idx;       /* uniaxial_stress_idx, UNIAXIAL_STRESS only */
     int32_t rotation_is_identity; /* params["rotation matrix"] == eye(3) exactly -> skip Q products */
-    int32_t solver_flags;       /* 0 = general Newton; CM_SOLVER_* bits opt into specialisations */
+    int32_t solver_flags;       /* CM_SOLVER_* bits, 0 = defaults */
     double  yield_tol;          /* cond_residual tolerance, models/paths.py:26-27 (default 1e-14) */
     double  Q[9];               /* params["rotation matrix"], row-major */
     double  lambda, mu;         /* Lame pair, models/elastic_constants.py:53-104 */

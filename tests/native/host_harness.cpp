@@ -25,8 +25,17 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         const bool ls = m.ls_max_evals > 0;
         double parked[2 * 9];                      // the kernels keep this in the lane's LDS column
         const LaneStage stage{parked, 1};
-        uint32_t st = g_dense ? (ls ? newton_any<DEF, YK, true, false>(m, eg, z, xp, x, true, stage) : newton_any<DEF, YK, false, false>(m, eg, z, xp, x, true, stage))
-                              : (ls ? newton_any<DEF, YK, true, true>(m, eg, z, xp, x, true, stage) : newton_any<DEF, YK, false, true>(m, eg, z, xp, x, true, stage));
+        uint32_t st;
+        bool done = false;
+        if constexpr (DEF == CM_FULL_3D && YK == CM_YIELD_J2) {     // same choice as launch_update (cmad_hip.hip)
+            if (!g_dense && !ls && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                st = newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
+                done = true;
+            }
+        }
+        if (!done)
+            st = g_dense ? (ls ? newton_any<DEF, YK, true, false>(m, eg, z, xp, x, true, stage) : newton_any<DEF, YK, false, false>(m, eg, z, xp, x, true, stage))
+                         : (ls ? newton_any<DEF, YK, true, true>(m, eg, z, xp, x, true, stage) : newton_any<DEF, YK, false, true>(m, eg, z, xp, x, true, stage));
         Eval<DEF> ev;
         strain_stress<DEF>(m, eg, z, x, ev);
         double sg[6];

@@ -277,16 +277,18 @@ def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed
 
 
 def check_j2_radial_line(backend, B=4096, rot=False):
-    """Opt-in J2 radial-line Newton (CM_SOLVER_J2_RADIAL_LINE): same states, stresses AND iteration counts as
-    the general 7-dof Newton of the oracle, two load steps from a hardened previous state."""
-    sc = Scenario(ol.FULL_3D, "J2", {}, rot, False, B=B)
-    sc.desc.solver_flags = 1
-    check_update(backend, sc)
-    for gradu, xp, it_o in ((sc.gradu0, sc.xi0, sc.it1), (sc.gradu, sc.xi1, sc.it2)):
-        _, _, status = backend.update(sc, gradu, xp)
-        it_d = (status.astype(np.uint32) & 0xFFFF).astype(np.int32)
-        assert np.mean(it_d == it_o) > 0.99, np.bincount(np.abs(it_d - it_o))
-    check_vjp(backend, sc)
+    """J2 / FULL_3D / plain Newton: the default kernels restrict the iteration to the radial line it never leaves;
+    CM_SOLVER_GENERAL_NEWTON (solver_flags = 2) forces the general 7-dof iteration.  Both must give the same
+    states, stresses AND iteration counts as the oracle's general Newton, two load steps from a hardened state."""
+    for flags in (0, 2):
+        sc = Scenario(ol.FULL_3D, "J2", {}, rot, False, B=B)
+        sc.desc.solver_flags = flags
+        check_update(backend, sc)
+        for gradu, xp, it_o in ((sc.gradu0, sc.xi0, sc.it1), (sc.gradu, sc.xi1, sc.it2)):
+            _, _, status = backend.update(sc, gradu, xp)
+            it_d = (status.astype(np.uint32) & 0xFFFF).astype(np.int32)
+            assert np.mean(it_d == it_o) > 0.99, (flags, np.bincount(np.abs(it_d - it_o)))
+        check_vjp(backend, sc)
 
 
 def check_edge_cases(backend):

@@ -132,15 +132,15 @@ def test_rate_model_update(def_type, yield_kind, kw, ls):
 @pytest.mark.parametrize("rot", [False, True])
 def test_j2_radial_line_newton_matches_general_path(backend, rot):
     pc.check_j2_radial_line(backend, B=8192, rot=rot)
-    # the fused kernel with the flag set gives the same state and gradient as without it
+    # the fused kernel gives the same state and gradient with the restriction (default) and without it
     import torch
     from cmad_amd.models.device import DeviceEvaluator, NewtonSettings, build_desc
     from cmad_amd.synthetic import gauss_point_batch, j2_voce_values
     B = 4096
     g = torch.from_numpy(gauss_point_batch(B)).cuda(); xp = torch.zeros((7, B), dtype=torch.float64, device="cuda")
     sb = torch.randn((6, B), dtype=torch.float64, device="cuda")
-    a = DeviceEvaluator(*build_desc(j2_voce_values(), newton=NewtonSettings())).update_and_vjp(g, xp, sb)
-    b = DeviceEvaluator(*build_desc(j2_voce_values(), newton=NewtonSettings(j2_radial_line=True))).update_and_vjp(g, xp, sb)
+    a = DeviceEvaluator(*build_desc(j2_voce_values(), newton=NewtonSettings(j2_radial_line=False))).update_and_vjp(g, xp, sb)
+    b = DeviceEvaluator(*build_desc(j2_voce_values(), newton=NewtonSettings())).update_and_vjp(g, xp, sb)
     np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(b[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-10, atol=1e-8)
     np.testing.assert_allclose(b[2].cpu().numpy(), a[2].cpu().numpy(), rtol=1e-9, atol=1e-9 * a[2].abs().max().item())

@@ -13,4 +13,6 @@ run --workload j2_update --def-type plane_stress
 run --workload j2_objective_grad --def-type plane_stress
 run --workload hosford_update --steps 5
 run --workload hybrid_update --points 5000000 --steps 5
-run --workload j2_update_vjp --j2-radial-line
+run --workload j2_update_vjp --general-newton
+run --workload j2_update --general-newton
+run --workload j2_objective_grad --general-newton
