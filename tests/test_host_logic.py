@@ -36,6 +36,7 @@ def test_elastic_constants_all_pairs():
 
 
 def test_build_desc_and_errors():
+    from cmad_amd.models.device import NewtonSettings
     from cmad_amd.models.device import NewtonSettings, build_desc
     from cmad_amd.synthetic import hosford_values, j2_voce_values
     d, info = build_desc(j2_voce_values(), newton=NewtonSettings.traced(max_iters=20, abs_tol=1e-12, rel_tol=1e-12))
@@ -45,9 +46,15 @@ def test_build_desc_and_errors():
     assert info["elastic_names"] == ("E", "nu")
     d, _ = build_desc(hosford_values())
     assert d.yield_kind == 2 and d.yc[0] == 100.
-    bad = j2_voce_values(); bad["plastic"]["effective stress"] = {"barlat": {}}
+    from cmad_amd.models.device import BARLAT_NAMES
+    bar = j2_voce_values(); bar["plastic"]["effective stress"] = {"barlat": {n: 1.0 + 0.01 * i for i, n in enumerate(BARLAT_NAMES)}}
+    d, _ = build_desc(bar)
+    assert d.yield_kind == 5 and d.yc[0] == 1.0 and d.yc[18] == pytest.approx(1.18)
+    bad = j2_voce_values(); bad["plastic"]["effective stress"] = {"tresca": {}}
     with pytest.raises(NotImplementedError):
         build_desc(bad)
+    assert build_desc(j2_voce_values())[0].solver_flags == 0                              # radial-line restriction on
+    assert build_desc(j2_voce_values(), newton=NewtonSettings(j2_radial_line=False))[0].solver_flags == 2
 
 
 def test_fold_weight_and_data_is_exact():
