@@ -432,8 +432,13 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
 // (derivation in DESIGN.md section 3).  Same iterates, same iteration counts, same convergence test (||C|| = |f|)
 // as newton_s; ~50 instead of ~275 instructions per iteration.  An iterate that falls on the elastic side of the
 // branch select (cannot happen for concave hardening) sends the lane to the general path.
+// LS: with the line search on, a step on the line is the first trial (alpha = 1) of the reference's search; its
+// merit is f^2 / 2 (C[0:6] = 0 on the line), so the Armijo test is f_new^2 <= (1 - 2 c1) f_old^2.  A lane whose
+// full step fails it (or is not finite) leaves for the general line-search path; every other lane produces the
+// iterates the general path would.
+template <bool LS = false>
 CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
-                             EvalS<CM_YIELD_J2>& ev) {
+                             EvalS<CM_YIELD_J2>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
     double C[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x[k] = xp[k];
@@ -452,11 +457,17 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
         if (running && it >= m.max_iters) running = false;
         if (!__any(running)) break;
         if (running) {
+            const double f_old = f;
             alpha -= f * rcp(-(three_mu + dH) * i2mu);
             const Hard hd = hardening(m, alpha);
             f = (phi_tr - three_mu * (alpha - alpha_p) - (m.Y + hd.H)) * i2mu;
             dH = hd.dH;
             if (!((f > m.yield_tol) || (fabs(f) < m.yield_tol))) { fallback = true; running = false; }
+            if constexpr (LS) {
+                // phi(1) <= phi(0) + c1 phi'(0) with phi = f^2 / 2, phi'(0) = -f_old^2
+                const double ph = 0.5 * f * f, ph0 = 0.5 * f_old * f_old;
+                if (!(isfinite(ph) && ph <= ph0 + m.ls_c1 * (-(f_old * f_old)))) { fallback = true; running = false; }
+            }
             ++it;
         }
     }
@@ -475,7 +486,7 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
         if (!((nsq < rel2) || (nsq < abs2))) fallback = true;
     }
     if (__any(fallback)) {
-        if (fallback) st = newton_s<CM_YIELD_J2, false>(m, eg, xp, x, lane_valid, ev);
+        if (fallback) st = newton_s<CM_YIELD_J2, LS>(m, eg, xp, x, lane_valid, ev, stage);
     }
     return st;
 }
@@ -636,8 +647,8 @@ CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const doubl
     if constexpr (STRUCT && has_structured<DEF, YK>()) {
         EvalS<YK> ev;
         if constexpr (RL) {
-            static_assert(DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS, "radial line: J2, FULL_3D, plain Newton only");
-            return newton_j2_line(m, eg, xp, x, valid, ev);
+            static_assert(DEF == CM_FULL_3D && YK == CM_YIELD_J2, "radial line: J2, FULL_3D only");
+            return newton_j2_line<LS>(m, eg, xp, x, valid, ev, stage);
         }
         else return newton_s<YK, LS, DEF>(m, eg, xp, x, valid, ev, stage, z);
     }

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     __shared__ double ls_stage[(SFAST && LS) ? kLsSlots * kBlock : 1];
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
-            if constexpr (RL) newton_j2_line(m, eg, xp, x, valid, evs);
+            if constexpr (RL) newton_j2_line<LS>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
@@ -534,7 +534,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
     const bool found = dispatch<!TANGENT>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && !LS) {
+        if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
                 return;
@@ -568,9 +568,9 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         // CM_DEBUG_DYN_LDS=<bytes>: occupancy experiments only (extra dynamic LDS per block limits blocks per CU)
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
         const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) {
+            if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && (MODE == 1 || MODE == 3)) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
-                    hipLaunchKernelGGL((k_reverse<D, Y, R, false, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
+                    hipLaunchKernelGGL((k_reverse<D, Y, R, LS, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                        hist_in, xi_out, sigma_out, xpbar, gbar, partials);
                     return;
                 }

@@ -28,8 +28,9 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         uint32_t st;
         bool done = false;
         if constexpr (DEF == CM_FULL_3D && YK == CM_YIELD_J2) {     // same choice as launch_update (cmad_hip.hip)
-            if (!g_dense && !ls && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
-                st = newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
+            if (!g_dense && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                st = ls ? newton_any<DEF, YK, true, true, true>(m, eg, z, xp, x, true, stage)
+                        : newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
                 done = true;
             }
         }

@@ -277,11 +277,12 @@ def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed
 
 
 def check_j2_radial_line(backend, B=4096, rot=False):
-    """J2 / FULL_3D / plain Newton: the default kernels restrict the iteration to the radial line it never leaves;
+    """J2 / FULL_3D (plain Newton, and the traced Newton whose full steps pass the Armijo test): the default kernels
+    restrict the iteration to the radial line it never leaves;
     CM_SOLVER_GENERAL_NEWTON (solver_flags = 2) forces the general 7-dof iteration.  Both must give the same
     states, stresses AND iteration counts as the oracle's general Newton, two load steps from a hardened state."""
-    for flags in (0, 2):
-        sc = Scenario(ol.FULL_3D, "J2", {}, rot, False, B=B)
+    for flags, ls in ((0, False), (2, False), (0, True), (2, True)):
+        sc = Scenario(ol.FULL_3D, "J2", {}, rot, ls, B=B)
         sc.desc.solver_flags = flags
         check_update(backend, sc)
         for gradu, xp, it_o in ((sc.gradu0, sc.xi0, sc.it1), (sc.gradu, sc.xi1, sc.it2)):
