@@ -180,28 +180,28 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
 }
 
 // ---- block reduction of NV doubles per lane into partials[blockIdx][NV] ----------------------------
+// Through LDS instead of 6 x NV cross-lane shuffles: every lane parks its NV values (row k at sh[k * kRedStride],
+// conflict-free), then thread (k, j) = (t / 16, t % 16) adds the 16 entries i * 16 + j of row k and the 16 partial
+// sums of a row are combined with four 16-lane shuffles.  ~60 instead of ~230 instructions per lane; fixed
+// summation order, so the result is reproducible bit for bit.  `sh` may alias storage the Newton loop used
+// (hence the leading barrier); it needs NV * kRedStride doubles.
+constexpr int kRedStride = kBlock + 16;      // rows start 32 banks apart: the four 16-lane groups of a wave do not collide
 template <int NV>
-__device__ __forceinline__ void block_reduce_store(double* v, double* __restrict__ partials) {
-    __shared__ double sh[kBlock / 64][NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double a = v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-        v[k] = a;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) sh[wave][k] = v[k];
-    }
+__device__ __forceinline__ void block_reduce_store(const double* v, double* __restrict__ partials, double* sh) {
+    static_assert(kBlock == 256 && NV * 16 <= kBlock, "thread (k, j) layout assumes 256 lanes and NV <= 16");
     __syncthreads();
-    if (threadIdx.x < NV) {
-        double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
-        partials[(int64_t)blockIdx.x * NV + threadIdx.x] = s;
+    for (int k = 0; k < NV; ++k) sh[k * kRedStride + threadIdx.x] = v[k];
+    __syncthreads();
+    const int k = threadIdx.x >> 4, j = threadIdx.x & 15;
+    double a = 0.0;
+    if (k < NV) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += sh[k * kRedStride + i * 16 + j];
     }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) a += __shfl_xor(a, off, 16);
+    if (k < NV && j == 0) partials[(int64_t)blockIdx.x * NV + k] = a;
 }
 
 // deterministic two-stage reduction of the block partials (fixed order, no atomics):
@@ -307,7 +307,10 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
     constexpr bool SFAST = (has_structured<DEF, YK>() && (MODE == 1 || MODE == 3));
     EvalS<SFAST ? YK : CM_YIELD_J2> evs;
-    __shared__ double ls_stage[(SFAST && LS) ? kLsSlots * kBlock : 1];
+    // one LDS buffer: the line search's parked iterates during the Newton loop, the gradient reduction afterwards
+    constexpr int kLdsDoubles = ((SFAST && LS) ? kLsSlots * kBlock : 0) > kRed * kRedStride ? kLsSlots * kBlock : kRed * kRedStride;
+    __shared__ double lds_buf[kLdsDoubles];
+    double* const ls_stage = lds_buf;
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
             if constexpr (RL) newton_j2_line<LS>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
 #pragma unroll
         for (int k = 0; k < kRed; ++k) red[k] = 0.0;
     }
-    block_reduce_store<kRed>(red, partials);
+    block_reduce_store<kRed>(red, partials, lds_buf);
 }
 
 // ---- cm_evaluate: residual / Jacobian block / stress / stress-derivative block at given states ----------
