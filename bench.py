@@ -71,6 +71,68 @@ def load_traffic(points):
     return None
 
 
+def history_workload(args, dev, rank, world, distributed):
+    """Side measurement for BASELINE.json configs[4] with a K-step history per point, the way the reference's
+    calibration objectives are used (tests/objectives/test_calibrations.py: PLANE_STRESS, biaxial ramp):
+    one evaluation = K forward launches (cm_update, states stored) + K adjoint launches (cm_adjoint_step) + one
+    all-reduce of (J, grad).  A "step" is one objective + gradient evaluation; value = point-steps per second."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cmad_amd.models import DefType, SmallElasticPlastic
+    from cmad_amd.objectives import BatchedCalibrationObjective
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.synthetic import gauss_point_batch, j2_voce_values
+    K = 10
+    B = min(args.points, 2_000_000)
+    from cmad_amd.parameters.parameters import tree_map
+    values = j2_voce_values()
+    flags = tree_map(lambda leaf: False, values)
+    flags["plastic"]["flow stress"] = tree_map(lambda leaf: True, flags["plastic"]["flow stress"])     # Y, S, D active
+    model = SmallElasticPlastic(Parameters(values, flags, tree_map(lambda leaf: None, values)), DefType.PLANE_STRESS)
+    g1 = torch.from_numpy(gauss_point_batch(B, seed=22 + rank, ndims=2)).to(dev)
+    ramp = torch.linspace(0.0, 1.5, K + 1, dtype=torch.float64, device=dev)
+    gradu_hist = (ramp[:, None, None] * g1[None]).contiguous()                    # proportional ramp to 6 eps_y
+    gen = torch.Generator(device=dev); gen.manual_seed(99 + rank)
+    data_hist = 50.0 * torch.randn((K + 1, 6, B), dtype=torch.float64, device=dev, generator=gen)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.0
+    obj = BatchedCalibrationObjective(model, gradu_hist, data_hist, weight)
+    for _ in range(max(1, args.warmup)):
+        r = obj.evaluate_native()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = obj.evaluate_native()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    assert np.isfinite(r.J) and np.isfinite(r.grad).all()
+    if rank == 0:
+        # forward: read grad u 32 + xi_prev 64, write xi 64; adjoint: read grad u 32 + xi_prev 64 + xi 64 + data 48
+        # + history 64, write history 64
+        bytes_per = 160 + 336
+        value = world * B * K * args.steps / elapsed
+        print(json.dumps({
+            "metric": METRIC, "value": value, "unit": "point-steps/s (objective + gradient)", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"J2 PLANE_STRESS calibration objective + gradient over a {K}-step history per point "
+                                   "(side measurement for configs[4])", "points_per_gpu": B, "history_steps": K},
+            "roofline": {"bound": "hbm", "achieved": bytes_per * B * K * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bytes_per * B * K * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_update + k_reverse<MODE 2> per history step",
+                         "kernel_ms": elapsed / args.steps * 1e3, "algorithmic_bytes_per_update": bytes_per}}))
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,7 +149,8 @@ def main():
     ap.add_argument("--def-type", default="full_3d", choices=["full_3d", "plane_stress"],
                     help="J2 workloads: plane_stress is a side measurement (the reference's material-point tests' type)")
     ap.add_argument("--workload", default="j2_update_vjp",
-                    choices=["j2_update_vjp", "j2_update", "j2_objective_grad", "hosford_update", "hybrid_update"],
+                    choices=["j2_update_vjp", "j2_update", "j2_objective_grad", "hosford_update", "hybrid_update",
+                             "ps_calibration_history"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
     args = ap.parse_args()
 
@@ -114,6 +177,8 @@ def main():
 
     B = args.points
     wl = args.workload
+    if wl == "ps_calibration_history":
+        return history_workload(args, dev, rank, world, distributed)
     values = j2_voce_values()
     newton = NewtonSettings(j2_radial_line=not args.general_newton)   # newton_solve defaults: 10 iters, 1e-14, no line search
     if args.ls_evals > 0:                          # make_newton_solve: same tolerances + Armijo line search

@@ -16,3 +16,4 @@ run --workload hybrid_update --points 5000000 --steps 5
 run --workload j2_update_vjp --general-newton
 run --workload j2_update --general-newton
 run --workload j2_objective_grad --general-newton
+run --workload ps_calibration_history --steps 5
