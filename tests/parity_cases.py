@@ -292,6 +292,27 @@ def check_j2_radial_line(backend, B=4096, rot=False):
         check_vjp(backend, sc)
 
 
+def check_line_search_rejections(backend, def_type=ol.FULL_3D, yield_kind="J2", kw=None, B=1024):
+    """A sufficient-decrease constant above 1/2 makes the Armijo test fail for every Newton step, so each iteration
+    walks the whole rejection machinery (contracted trials read back from the parked iterate, then the lowest-merit
+    step re-evaluated) -- and for J2 / FULL_3D every lane leaves the radial line for the general line-search path.
+    Device and oracle run the same settings and must agree on states, stresses and iteration counts."""
+    from cmad_amd.models.device import NewtonSettings, build_desc
+    sc = Scenario(def_type, yield_kind, kw or {}, False, True, B=B)
+    sc.st_o = ol.newton_settings(max_iters=30, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=3, c1=0.6)
+    sc.st_d = NewtonSettings.traced(max_iters=30, abs_tol=1e-12, rel_tol=1e-12,
+                                    line_search_settings={"max evals": 3, "sufficient decrease": 0.6})
+    sc.desc, sc.info = build_desc(sc.values, def_type=def_type, newton=sc.st_d)
+    sc.xi1, sc.sig1, sc.it1, sc.cv1 = sc.mat.update_batch(sc.st_o, sc.gradu0, sc.xi0)
+    sc.xi2, sc.sig2, sc.it2, sc.cv2 = sc.mat.update_batch(sc.st_o, sc.gradu, sc.xi1)
+    assert sc.cv1.all() and sc.cv2.all()
+    check_update(backend, sc)
+    for gradu, xp, it_o in ((sc.gradu0, sc.xi0, sc.it1), (sc.gradu, sc.xi1, sc.it2)):
+        _, _, status = backend.update(sc, gradu, xp)
+        it_d = (status.astype(np.uint32) & 0xFFFF).astype(np.int32)
+        assert np.mean(it_d == it_o) > 0.99, np.bincount(np.abs(it_d - it_o))
+
+
 def check_edge_cases(backend):
     """Zero strain (sigma = 0: the reference's normal is NaN there and masked by the branch select), iteration cap
     reached without convergence (the reference returns the last iterate silently; status reports it), and a

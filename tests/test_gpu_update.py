@@ -84,6 +84,14 @@ def test_hybrid_hill_icnn(backend, def_type):
     pc.check_hybrid_nn(backend, def_type, B=2048, rot=(def_type == ol.FULL_3D))
 
 
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "J2", {}), (ol.FULL_3D, "hill", {"hill": pc.HILL}),
+                                                    (ol.PLANE_STRESS, "J2", {}), (ol.FULL_3D, "hosford", {"a": 8.5})])
+def test_line_search_rejections(backend, def_type, yield_kind, kw):
+    """Every Armijo test fails (c1 = 0.6): the LDS-parked retry path of the line search and, for J2 / FULL_3D, the
+    fallback from the radial line to the general search."""
+    pc.check_line_search_rejections(backend, def_type, yield_kind, kw, B=4096)
+
+
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_barlat_calibrated_coefficients(backend, def_type):
     """Yld2004-18p, Al7079 coefficients, a = 18.2."""

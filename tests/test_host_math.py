@@ -95,6 +95,12 @@ def test_hybrid_hill_icnn(def_type, rot):
     pc.check_hybrid_nn(BACKEND, def_type, B=192, rot=rot)
 
 
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "J2", {}), (ol.FULL_3D, "hill", {"hill": pc.HILL}),
+                                                    (ol.PLANE_STRESS, "J2", {}), (ol.FULL_3D, "hosford", {"a": 8.5})])
+def test_line_search_rejections(def_type, yield_kind, kw):
+    pc.check_line_search_rejections(BACKEND, def_type, yield_kind, kw, B=384)
+
+
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_barlat_calibrated_coefficients(def_type):
     pc.check_barlat_calibrated(BACKEND, def_type, B=256)
