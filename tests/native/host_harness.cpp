@@ -195,6 +195,7 @@ static int dispatch(const cm_model_desc* m, F&& f) {
 }
 
 extern "C" {
+double hh_quad_min(double phi0, double dphi0, double a, double phi) { return quad_min(phi0, dphi0, a, phi); }
 int hh_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
               double* xi, double* sigma, uint32_t* status, double* dsig) {
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_update<D, Y, R>(*m, B, gradu, xi_prev, xi, sigma, status, dsig); });

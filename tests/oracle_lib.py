@@ -76,6 +76,10 @@ def lib():
         L.orc_jacobian.argtypes = [C.POINTER(Desc), C.c_int] + [dp] * 6
         L.orc_cauchy.argtypes = [C.POINTER(Desc)] + [dp] * 4
         L.orc_dcauchy.argtypes = [C.POINTER(Desc), C.c_int] + [dp] * 6
+        L.orc_quad_min.argtypes = [C.c_double] * 4
+        L.orc_quad_min.restype = C.c_double
+        L.orc_line_search_linear.argtypes = [C.c_double] * 5 + [C.c_int] + [C.c_double] * 4 + [dp]
+        L.orc_line_search_linear.restype = C.c_double
         L.orc_yield.argtypes = [C.POINTER(Desc)] + [dp] * 6
         L.orc_newton.argtypes = [C.POINTER(Desc), C.POINTER(Newton)] + [dp] * 6 + [C.POINTER(C.c_int)]
         L.orc_newton.restype = C.c_int
@@ -107,6 +111,17 @@ def _pi(a):
 
 def f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def quad_min(phi0, dphi0, a, phi):
+    return lib().orc_quad_min(phi0, dphi0, a, phi)
+
+
+def line_search_linear(r0, r1, phi0, dphi0, init_aux=1.0, nan_above=np.inf, max_evals=4, c1=1e-4, lo=0.5, hi=0.9):
+    """The oracle's line search (the one its Newton uses) on the merit 1/2 (r0 + r1 alpha)^2 -> (alpha, aux)."""
+    aux = C.c_double()
+    alpha = lib().orc_line_search_linear(r0, r1, nan_above, phi0, dphi0, max_evals, c1, lo, hi, init_aux, C.byref(aux))
+    return alpha, aux.value
 
 
 class Material:

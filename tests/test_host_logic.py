@@ -167,3 +167,33 @@ def test_sharded_gradient_allreduce_gloo_world2():
     g, _, _ = hh.vjp(desc, gradu, xi_prev, xi, sbar)
     assert res[0] == B
     np.testing.assert_allclose(res[1:], g, rtol=1e-12, atol=1e-12 * np.abs(g).max())
+
+
+def test_affine_scaler_known_values():
+    """The reference's tests/neural_networks/test_affine_scaler.py:13-40 on cmad_amd's AffineScaler (the input /
+    output scalers of the ICNN yield term)."""
+    from cmad_amd.neural_networks import AffineScaler
+    samples = np.array([[0.0, 10.0], [2.0, 20.0], [4.0, 30.0]])           # column 0 spans [0, 4], column 1 [10, 30]
+    sc = AffineScaler().fit(samples)
+    scaled = sc.scale_ * samples + sc.min_
+    np.testing.assert_allclose(scaled.min(axis=0), [-1.0, -1.0])
+    np.testing.assert_allclose(scaled.max(axis=0), [1.0, 1.0])
+    sc = AffineScaler(feature_range=(0.0, 1.0)).fit(samples)
+    np.testing.assert_allclose(sc.scale_, [0.25, 0.05])
+    np.testing.assert_allclose(sc.min_, [0.0, -0.5])
+    const = np.array([[5.0], [5.0], [5.0]])
+    sc = AffineScaler(feature_range=(0.0, 1.0)).fit(const)
+    np.testing.assert_allclose(sc.scale_ * const + sc.min_, 0.0)
+
+
+def test_device_quad_min_known_value():
+    """The kernels' quad_min (cm_device.hpp, host build) on the reference's known answer
+    (tests/util/test_line_search.py:39-55) and its degenerate-denominator branch (line_search.py:74-85)."""
+    import ctypes as C
+    import host_harness_lib as hh
+    f = hh.lib().hh_quad_min
+    f.argtypes = [C.c_double] * 4
+    f.restype = C.c_double
+    q = lambda t: (t - 0.4) ** 2
+    assert f(q(0.0), 2.0 * (0.0 - 0.4), 1.0, q(1.0)) == pytest.approx(0.4, abs=1e-12)
+    assert f(1.0, -1.0, 0.5, 0.5) == 0.25                     # phi - phi0 - dphi0 a = 0 -> a / 2

@@ -121,3 +121,40 @@ def test_isotropic_barlat_is_j2(golden_dir):
     cauchy, model_alpha, iters = _run_history(mb, F, ol.newton_settings())
     assert np.linalg.norm(model_alpha - alpha) < 1e-6
     assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6
+
+
+# ---- the reference's own line-search unit tests (tests/util/test_line_search.py), on the oracle's search ----------
+
+def test_line_search_quad_min_recovers_quadratic_minimizer():
+    """reference :39-55: q(t) = (t - 0.4)^2 from its value and slope at 0 and its value at a = 1."""
+    q = lambda t: (t - 0.4) ** 2
+    assert ol.quad_min(q(0.0), 2.0 * (0.0 - 0.4), 1.0, q(1.0)) == pytest.approx(0.4, abs=1e-12)
+
+
+def test_line_search_full_step_accepted():
+    """reference :84-93: r(a) = 1 - a; the full step is accepted and its residual comes back."""
+    alpha, aux = ol.line_search_linear(1.0, -1.0, 0.5, -1.0, init_aux=1.0)
+    assert alpha == pytest.approx(1.0) and aux == pytest.approx(0.0)
+
+
+def test_line_search_backtracks_on_overshoot():
+    """reference :57-81, 96-118: r(a) = 1 - 3a, the full step triples the residual; the quadratic model damps it to
+    0 < alpha < 1 with sufficient decrease and returns the residual at the accepted step."""
+    phi = lambda a: 0.5 * (1.0 - 3.0 * a) ** 2
+    alpha, aux = ol.line_search_linear(1.0, -3.0, phi(0.0), -3.0, init_aux=1.0)
+    assert 0.0 < alpha < 1.0
+    assert phi(alpha) < phi(0.0) and phi(alpha) <= phi(0.0) + 1e-4 * alpha * (-3.0)
+    assert aux == pytest.approx(1.0 - 3.0 * alpha)
+
+
+def test_line_search_disabled_returns_full_step():
+    """reference :137-147: max evals = 0 takes the full step and returns init_aux unprobed."""
+    alpha, aux = ol.line_search_linear(1.0, -3.0, 0.5, -3.0, init_aux=7.0, max_evals=0)
+    assert alpha == 1.0 and aux == 7.0
+
+
+def test_line_search_nonfinite_probe_contracts():
+    """reference :173-190: the merit is NaN for alpha > 0.75; the step is halved into the finite region."""
+    alpha, aux = ol.line_search_linear(1.0, -1.0, 0.5, -1.0, init_aux=1.0, nan_above=0.75)
+    assert 0.0 < alpha <= 0.75
+    assert aux == pytest.approx(1.0 - alpha)
