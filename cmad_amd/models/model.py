@@ -273,10 +273,25 @@ class Model(ABC):
         return self._block_list(self._point_evaluate(DerivType.DXI_PREV, xi, xi_prev, params, U, U_prev=U_prev)[1])
 
     def dC_dp(self, xi, xi_prev, params, U, U_prev):
-        """Active-parameter columns (n_xi, num_active); the reference returns the full params pytree and
-        slices with `model_active_params_jacobian` -- callers only ever use the active slice."""
+        """d C / d params as a tree parallel to `params` (reference model.py:316-374: jacrev w.r.t. the params
+        pytree): leaf shape (n_xi,) + leaf.shape.  Leaves the kernels have no sensitivity for (rotation matrix,
+        Hosford exponent, Barlat coefficients, network weights, Hill coefficients of the network surfaces) come
+        back filled with NaN rather than with a silent zero."""
         _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U, U_prev=U_prev)
-        return self._active_columns(J, info)
+        n = self.num_dofs
+
+        def walk(node, path):
+            if isinstance(node, dict):
+                return {k: walk(v, path + (k,)) for k, v in node.items()}
+            if isinstance(node, (list, tuple)):
+                return type(node)(walk(v, path + (i,)) for i, v in enumerate(node))
+            shape = np.shape(node)
+            try:
+                col = np.asarray(kp_to_leaf_grad(path, J.T, info), dtype=np.float64)
+            except (NotImplementedError, KeyError):
+                return np.full((n,) + shape, np.nan)
+            return np.broadcast_to(col.reshape((n,) + (1,) * len(shape)), (n,) + shape).copy()
+        return walk(params, ())
 
     def dC_dU(self, xi, xi_prev, params, U, U_prev):
         J = self._point_evaluate(DerivType.DU, xi, xi_prev, params, U, U_prev=U_prev)[1]
