@@ -147,9 +147,50 @@ CM_D void residual_T(const cm_model_desc& m, const MatT<T>& p, const double eg[6
     }
 }
 
+// the rate-form residual (cm::residual_rate, cmad/models/small_rate_elastic_plastic.py:249-346) in arithmetic T:
+// the unknown x[0:6] is the material stress itself, `deg` the material strain increment (plain doubles).
+template <int DEF, int YK, class T>
+CM_D void residual_rate_T(const cm_model_desc& m, const MatT<T>& p, const double deg[6], const double* z,
+                          const T* x, const T* xp, T* C, T s[6]) {
+    static_assert(DEF != CM_UNIAXIAL_STRESS, "rate form: FULL_3D and PLANE_STRESS");
+    T e[6];
+    for (int k = 0; k < 6; ++k) {
+        s[k] = x[k];
+        e[k] = T{deg[k]};
+        if constexpr (DEF == CM_PLANE_STRESS) e[k] = e[k] + z[k] * (x[7] - xp[7]);
+    }
+    const T tr = e[0] + e[3] + e[5];
+    const T twomu = 2.0 * p.mu;
+    T phi, gt[6];
+    yield_T<YK, T>(p, s, phi, gt);
+    T H = T{0.0};
+    if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
+    if (m.has_linear) H = H + p.K * x[6];
+    const T f = (phi - (p.Y + H)) / twomu;
+    const T dg = x[6] - xp[6];
+    const double fv = t_val(f);
+    const bool plastic = (fv > m.yield_tol) || (fabs(fv) < m.yield_tol);
+    const T gd = gt[0] + gt[3] + gt[5];
+    T r7 = T{0.0};
+    for (int k = 0; k < 6; ++k) {
+        T dc = twomu * e[k];
+        if (kDiag[k]) dc = dc + p.lambda * tr;
+        if (plastic) {
+            T cn = (twomu * kIW[k]) * gt[k];
+            if (kDiag[k]) cn = cn + p.lambda * gd;
+            dc = dc - dg * cn;
+        }
+        C[k] = (x[k] - xp[k] - dc) / twomu;
+        if constexpr (DEF == CM_PLANE_STRESS) r7 = r7 + (kW[k] * z[k]) * dc;
+    }
+    C[6] = plastic ? f : dg;
+    if constexpr (DEF == CM_PLANE_STRESS) C[7] = r7 / twomu;
+}
+
 // one (a, b) pair: out_C[NX] = d2 C / dq_a dq_b, out_S[6] = d2 sigma_global / dq_a dq_b,
 // and the first derivatives wrt q_a (for cross-checks): out_Ca[NX], out_Sa[6]
-template <int DEF, int YK, bool ROT>
+// MK = CM_SMALL_RATE_ELASTIC_PLASTIC: G must already hold grad u - grad u_prev (the strain is linear in it).
+template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv, const double* xpv, int a, int b,
                        double* out_C, double* out_S, double* out_Ca, double* out_Sa) {
     constexpr int NX = Dims<DEF>::NX;
@@ -168,7 +209,8 @@ CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv
     const HD* pp = q + 2 * NX;
     p.lambda = pp[0]; p.mu = pp[1]; p.Y = pp[2]; p.S = pp[3]; p.D = pp[4]; p.K = pp[5];
     for (int k = 0; k < 6; ++k) p.yc[k] = pp[6 + k];
-    residual_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
+    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) residual_rate_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
+    else residual_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
     for (int k = 0; k < NX; ++k) { out_C[k] = C[k].ab; out_Ca[k] = C[k].a; }
     double s2[6], s1[6], g2[6], g1[6];
     for (int k = 0; k < 6; ++k) { s2[k] = s[k].ab; s1[k] = s[k].a; }

@@ -439,9 +439,10 @@ __global__ __launch_bounds__(64) void k_evaluate_rate(cm_model_desc m, int64_t B
 }
 
 // ---- cm_hessians: one thread per (point, pair of differentiation variables) -----------------------------------
-template <int DEF, int YK, bool ROT>
+template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 __global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
-        const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev,
+        const double* __restrict__ xi_prev, const double* __restrict__ xi,
         double* __restrict__ d2C, double* __restrict__ d2S, double* __restrict__ dC, double* __restrict__ dS) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS, NPAIR = NQ * (NQ + 1) / 2;
     const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -451,9 +452,12 @@ __global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
     while (rem >= NQ - a) { rem -= NQ - a; ++a; }         // pairs (a, b >= a) in row-major order
     const int b = a + rem;
     double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6];
-    for (int k = 0; k < NU; ++k) G[k] = gradu[(int64_t)k * B + pt];
+    for (int k = 0; k < NU; ++k) {
+        G[k] = gradu[(int64_t)k * B + pt];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_prev[(int64_t)k * B + pt];
+    }
     for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + pt]; x[k] = xi[(int64_t)k * B + pt]; }
-    hessian_pair<DEF, YK, ROT>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
+    hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
     if (d2C) for (int k = 0; k < NX; ++k) {
         d2C[((pt * NX + k) * NQ + a) * NQ + b] = oC[k];
         d2C[((pt * NX + k) * NQ + b) * NQ + a] = oC[k];
@@ -589,6 +593,31 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
     hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, accumulate);
     return check_launch();
 }
+
+#if CM_HAS_PART(6)
+template <int MK>
+int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                           const double* xi_prev, const double* xi,
+                           double* d2C, double* d2S, double* dC, double* dS, void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS) return CM_ERR_UNSUPPORTED;
+    if (B == 0) return CM_OK;
+    if (!gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
+    const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
+    const int64_t nthreads = B * (int64_t)(nq * (nq + 1) / 2);
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    const bool found = dispatch<(MK == CM_SMALL_ELASTIC_PLASTIC)>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (!is_dense_yield(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS))
+            hipLaunchKernelGGL((k_hessians<D, Y, R, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+#endif
 
 }  // namespace
 
@@ -737,22 +766,12 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
 #if CM_HAS_PART(6)
 int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream) {
-    if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
-    if (B == 0) return CM_OK;
-    if (!gradu || !xi_prev || !xi) return CM_ERR_BAD_ARG;
-    const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
-    const int64_t nthreads = B * (int64_t)(nq * (nq + 1) / 2);
-    const cm_model_desc md = *m;
-    (void)hipGetLastError();
-    const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
-    hipStream_t s = (hipStream_t)stream;
-    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!is_dense_yield(Y))
-            hipLaunchKernelGGL((k_hessians<D, Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, d2C, d2S, dC, dS);
-    });
-    if (!found) return CM_ERR_UNSUPPORTED;
-    return check_launch();
+    return launch_hessians<CM_SMALL_ELASTIC_PLASTIC>(m, B, gradu, nullptr, xi_prev, xi, d2C, d2S, dC, dS, stream);
+}
+int cm_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                     const double* xi_prev, const double* xi,
+                     double* d2C, double* d2S, double* dC, double* dS, void* stream) {
+    return launch_hessians<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS, stream);
 }
 #endif
 

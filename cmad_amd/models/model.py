@@ -174,8 +174,8 @@ class Model(ABC):
     def _second_derivative_pass(self):
         """cm_hessians for the gathered state -> raw arrays w.r.t. q = [xi, xi_prev, p(KP)]."""
         import torch
-        if self._model_kind != 0 or self._hybrid is not None:
-            raise NotImplementedError("second derivatives are built for the total-form model with J2 / Hill / Hosford")
+        if self._hybrid is not None:
+            raise NotImplementedError("second derivatives are built for J2 / Hill / Hosford")
         xi, xi_prev, params, U, U_prev = self.variables()
         desc, info = self._desc(params)
         L = _lib.lib()
@@ -187,9 +187,16 @@ class Model(ABC):
         e = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
         d2C, d2S, dC, dS = e(nx, nq, nq), e(6, nq, nq), e(nx, nq), e(6, nq)
         g, x0, x1 = t(G), t(self._flat(xi_prev)), t(self._flat(xi))       # keep the inputs alive across the launch
-        rc = L.cm_hessians(C.byref(desc), 1, _ptr(g), _ptr(x0), _ptr(x1),
-                           _ptr(d2C), _ptr(d2S), _ptr(dC), _ptr(dS), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        _lib.check(rc, "cm_hessians")
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self._model_kind == 1:                                         # rate form: the residual also takes grad u_prev
+            gp = t(np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1))
+            rc = L.cm_hessians_rate(C.byref(desc), 1, _ptr(g), _ptr(gp), _ptr(x0), _ptr(x1),
+                                    _ptr(d2C), _ptr(d2S), _ptr(dC), _ptr(dS), stream)
+            _lib.check(rc, "cm_hessians_rate")
+        else:
+            rc = L.cm_hessians(C.byref(desc), 1, _ptr(g), _ptr(x0), _ptr(x1),
+                               _ptr(d2C), _ptr(d2S), _ptr(dC), _ptr(dS), stream)
+            _lib.check(rc, "cm_hessians")
         return d2C.cpu().numpy(), d2S.cpu().numpy(), dC.cpu().numpy(), dS.cpu().numpy(), info, nx
 
     def evaluate_hessians(self) -> None:

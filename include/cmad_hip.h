@@ -239,6 +239,15 @@ int cm_hessians(const cm_model_desc* m, int64_t B,
                 const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream);
 
+/*
+ * cm_hessians_rate: cm_hessians for the rate-form model (small_rate_elastic_plastic.py:249-359; FULL_3D and
+ * PLANE_STRESS), whose residual also takes the previous grad u -- what the reference's Hessian checks run on
+ * SmallRateElasticPlastic (tests/objectives/test_J2_fd_checks.py:303-392).
+ */
+int cm_hessians_rate(const cm_model_desc* m, int64_t B,
+                     const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
+                     double* d2C, double* d2S, double* dC, double* dS, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

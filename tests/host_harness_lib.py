@@ -104,14 +104,20 @@ def evaluate_rate(desc, which, gradu, gradu_prev, xi_prev, xi, nx):
     return Cc, J.reshape(nx, ncols, B), s, S.reshape(6, ncols, B)
 
 
-def hessians(desc, gradu, xi_prev, xi, nx):
-    """d2C (B,nx,nq,nq), d2S (B,6,nq,nq), dC (B,nx,nq), dS (B,6,nq); q = [xi, xi_prev, p(KP)]."""
+def hessians(desc, gradu, xi_prev, xi, nx, gradu_prev=None):
+    """d2C (B,nx,nq,nq), d2S (B,6,nq,nq), dC (B,nx,nq), dS (B,6,nq); q = [xi, xi_prev, p(KP)].
+    gradu_prev: rate-form model (desc.model_kind = 1)."""
     L = lib()
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
     gradu, xi_prev, xi = c(gradu), c(xi_prev), c(xi)
     B = gradu.shape[1]
     nq = 2 * nx + 12
     d2C = np.zeros((B, nx, nq, nq)); d2S = np.zeros((B, 6, nq, nq)); dC = np.zeros((B, nx, nq)); dS = np.zeros((B, 6, nq))
-    rc = L.hh_hessians(C.byref(desc), C.c_int64(B), _p(gradu), _p(xi_prev), _p(xi), _p(d2C), _p(d2S), _p(dC), _p(dS))
+    if gradu_prev is not None:
+        gradu_prev = c(gradu_prev)
+        rc = L.hh_hessians_rate(C.byref(desc), C.c_int64(B), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi),
+                                _p(d2C), _p(d2S), _p(dC), _p(dS))
+    else:
+        rc = L.hh_hessians(C.byref(desc), C.c_int64(B), _p(gradu), _p(xi_prev), _p(xi), _p(d2C), _p(d2S), _p(dC), _p(dS))
     assert rc == 0
     return d2C, d2S, dC, dS

@@ -143,17 +143,17 @@ static void run_evaluate_rate(const cm_model_desc& m, int64_t B, int which, cons
     }
 }
 
-template <int DEF, int YK, bool ROT>
-static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
+static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                          double* d2C, double* d2S, double* dC, double* dS) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
-    if constexpr (!is_dense_yield(YK)) {
+    if constexpr (!is_dense_yield(YK) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS)) {
         for (int64_t pt = 0; pt < B; ++pt) {
             double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6];
-            for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt];
+            for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt] - (gradu_prev ? gradu_prev[k * B + pt] : 0.0);
             for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + pt]; x[k] = xi[k * B + pt]; }
             for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
-                hessian_pair<DEF, YK, ROT>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
+                hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
                 for (int k = 0; k < NX; ++k) { d2C[((pt * NX + k) * NQ + a) * NQ + b] = oC[k]; d2C[((pt * NX + k) * NQ + b) * NQ + a] = oC[k]; }
                 for (int k = 0; k < 6; ++k) { d2S[((pt * 6 + k) * NQ + a) * NQ + b] = oS[k]; d2S[((pt * 6 + k) * NQ + b) * NQ + a] = oS[k]; }
                 if (a == b) {
@@ -214,7 +214,12 @@ int hh_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
 }
 int hh_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS) {
-    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_hessians<D, Y, R>(*m, B, gradu, xi_prev, xi, d2C, d2S, dC, dS); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_hessians<D, Y, R>(*m, B, gradu, nullptr, xi_prev, xi, d2C, d2S, dC, dS); });
+}
+int hh_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
+                     const double* xi, double* d2C, double* d2S, double* dC, double* dS) {
+    return dispatch(m, [&]<int D, int Y, bool R>() {
+        run_hessians<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS); });
 }
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {

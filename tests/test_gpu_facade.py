@@ -346,8 +346,8 @@ def test_rate_model_calibration_recovers_truth():
     assert np.linalg.norm(model.parameters.flat_active_values() - true_params) < 1e-6
 
 
-def _hessian_problem(active_elastic=False, K=10):
-    from cmad_amd.models import DefType, SmallElasticPlastic
+def _hessian_problem(active_elastic=False, K=10, rate=False):
+    from cmad_amd.models import DefType, SmallElasticPlastic, SmallRateElasticPlastic
     from cmad_amd.qois import Calibration
     params = params_J2_voce()
     if active_elastic:
@@ -365,7 +365,7 @@ def _hessian_problem(active_elastic=False, K=10):
         tr["plastic"]["flow stress"]["hardening"]["voce"]["D"] = np.array([10., 30.])
         params = Parameters(values, flags, tr)
     F = plane_stress_F(0.02, K // 2)
-    model = SmallElasticPlastic(params, DefType.PLANE_STRESS)
+    model = (SmallRateElasticPlastic if rate else SmallElasticPlastic)(params, DefType.PLANE_STRESS)
     cauchy = _compute_cauchy(model, F)
     weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
     rng = np.random.default_rng(22)
@@ -375,13 +375,14 @@ def _hessian_problem(active_elastic=False, K=10):
     return model, qoi, F
 
 
-@pytest.mark.parametrize("active_elastic", [False, True])
-def test_direct_adjoint_hessian(active_elastic):
-    """tests/objectives/test_J2_fd_checks.py:66-98, 366-372: the Hessian of MPDirectAdjointObjective is
-    symmetric, matches central differences of the adjoint gradient, and its directional second derivative's FD
-    error drops by decades.  With E, nu active it also exercises the second-order elastic-constant chain."""
+@pytest.mark.parametrize("active_elastic,rate", [(False, False), (True, False), (False, True), (True, True)])
+def test_direct_adjoint_hessian(active_elastic, rate):
+    """tests/objectives/test_J2_fd_checks.py:66-98, 366-372, 390-396 (both SmallElasticPlastic and
+    SmallRateElasticPlastic): the Hessian of MPDirectAdjointObjective is symmetric, matches central differences of
+    the adjoint gradient, and its directional second derivative's FD error drops by decades.  With E, nu active it
+    also exercises the second-order elastic-constant chain."""
     from cmad_amd.objectives import MPAdjointObjective, MPDirectAdjointObjective
-    model, qoi, F = _hessian_problem(active_elastic)
+    model, qoi, F = _hessian_problem(active_elastic, rate=rate)
     x = model.parameters.flat_active_values(True)
     J, grad, H = MPDirectAdjointObjective(qoi, F).evaluate(x)
     Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
@@ -417,10 +418,19 @@ def test_evaluate_hessians_shapes_and_errors():
     assert m.d2C_dxi2.shape == (7, 7, 7) and m.d2C_dxi_dxi_prev.shape == (7, 7, 7) and m.d2C_dxi_prev2.shape == (7, 7, 7)
     assert m.d2C_dparams2.shape == (7, 3, 3) and m.d2C_dxi_dparams.shape == (7, 7, 3) and m.d2C_dxi_prev_dparams.shape == (7, 7, 3)
     assert np.abs(m.d2C_dxi2).max() > 0
-    r = SmallRateElasticPlastic(params_J2_voce(), DefType.FULL_3D)
+    r = SmallRateElasticPlastic(params_J2_voce(), DefType.FULL_3D)              # cm_hessians_rate
     r.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
+    newton_solve(r)
+    r.evaluate_hessians()
+    assert r.d2C_dxi2.shape == (7, 7, 7) and r.d2C_dparams2.shape == (7, 3, 3) and np.abs(r.d2C_dxi2).max() > 0
+    from cmad_amd.models import HybridHillEffectiveStress
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.synthetic import al7079_hybrid_setup
+    icnn, values = al7079_hybrid_setup()
+    hmodel = SmallElasticPlastic(Parameters(values), DefType.FULL_3D, effective_stress_fun=HybridHillEffectiveStress(icnn))
+    hmodel.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
     with pytest.raises(NotImplementedError):
-        r.evaluate_hessians()
+        hmodel.evaluate_hessians()
 
 
 def test_jvp_objective_agrees_with_direct_adjoint():

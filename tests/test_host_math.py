@@ -278,3 +278,51 @@ def test_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_
     npar = 12 if yield_kind == "hill" else 6
     np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], J[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
     np.testing.assert_allclose(dS[0][:, 2 * nx:2 * nx + npar], S[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(S).max()))
+
+
+@pytest.mark.parametrize("plastic", [True, False])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_form_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_variant):
+    """cm_hessians_rate (hyper-dual evaluation of the rate-form residual) vs the oracle's nested duals, both
+    branches; first derivatives of the same pass vs the hand-derived cm_evaluate_rate blocks."""
+    import numpy as np
+    import host_harness_lib as hh
+    from cmad_amd.models.device import build_desc
+    if solver_variant == "dense":
+        pytest.skip("not solver dependent")
+    rng = np.random.default_rng(21)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng), **kw)
+    E, nu = values["elastic"]["E"], values["elastic"]["nu"]
+    values["elastic"] = {"lambda": E * nu / ((1 + nu) * (1 - 2 * nu)), "mu": E / (2 * (1 + nu))}   # KP == native
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1)
+    nx, nd = mat.nx, (3 if def_type == ol.FULL_3D else 2)
+    for _ in range(200):
+        sdev = rng.normal(size=6) * (260.0 if plastic else 60.0)
+        xi = np.r_[sdev, abs(rng.normal()) * 2e-3] if nx == 7 else np.r_[sdev, abs(rng.normal()) * 2e-3, 1.0 + 1e-3 * rng.normal()]
+        xp = xi.copy(); xp[:6] -= rng.normal(size=6) * 20.0; xp[6] *= 0.5
+        if nx == 8:
+            xp[7] = 1.0 + 1e-3 * rng.normal()
+        U, Up = rng.normal(size=nd * nd) * 2e-3, rng.normal(size=nd * nd) * 1e-3
+        f = mat.yield_state(xi, U)[1]
+        if (f > 1e-6) == plastic and abs(f) > 1e-6:
+            break
+    else:
+        raise AssertionError("no state on the requested branch")
+    d2C, d2S, dC, dS = hh.hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx, gradu_prev=Up.reshape(-1, 1))
+    oC, oS = mat.second_derivs(xi, xp, U, Up)
+    kp2o = [ol.P_EL1, ol.P_EL0, ol.P_Y, ol.P_VOCE_S, ol.P_VOCE_D, ol.P_LIN_K] + [ol.P_YC + j for j in range(6)]
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in kp2o]
+    refC = oC[:, qmap][:, :, qmap]
+    keep = list(range(2 * nx + (12 if yield_kind == "hill" else 6))) + ([2 * nx + 6] if yield_kind == "hosford" else [])
+    sel = np.ix_(range(nx), keep, keep)
+    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refC[sel]).max()))
+    assert not d2S.any()                                       # sigma = Q x[0:6] Q^T is linear in the state
+    for which, lo in ((0, 0), (1, nx)):
+        C_, J, s_, S = hh.evaluate_rate(desc, which, U.reshape(-1, 1), Up.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+        np.testing.assert_allclose(dS[0][:, lo:lo + nx], S[:, :, 0], rtol=1e-9, atol=1e-12)
+    C_, J, s_, S = hh.evaluate_rate(desc, 2, U.reshape(-1, 1), Up.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    npar = 12 if yield_kind == "hill" else 6
+    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], J[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
