@@ -87,12 +87,17 @@ def _J_only(qoi, F):
     return float(J)
 
 
-def test_direct_equals_adjoint_and_fd_error_drops():
+@pytest.mark.parametrize("rate,scale_params", [(False, False), (True, True)])
+def test_direct_equals_adjoint_and_fd_error_drops(rate, scale_params):
+    """tests/objectives/test_J2_fd_checks.py:303-352, 390-396: Models = [SmallElasticPlastic,
+    SmallRateElasticPlastic] with scale_params = [False, True]."""
+    from cmad_amd.models import SmallRateElasticPlastic
     from cmad_amd.objectives import MPAdjointObjective, MPDirectObjective
     from cmad_amd.qois import Calibration
     DefType, SmallElasticPlastic = _models()
     F = plane_stress_F(0.02, 10)                       # 20 steps (reference uses 100; same two-leg path)
-    model = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+    model = (SmallRateElasticPlastic if rate else SmallElasticPlastic)(params_J2_voce(scale_params=scale_params),
+                                                                      DefType.PLANE_STRESS)
     cauchy = _compute_cauchy(model, F)
     weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
     qoi = Calibration(model, cauchy, weight)
@@ -106,7 +111,7 @@ def test_direct_equals_adjoint_and_fd_error_drops():
     rng = np.random.default_rng(22)
     d = rng.uniform(-1., 1., size=x.size)
     errs = []
-    for h in np.logspace(-1, -6, 6):
+    for h in np.logspace(0, -9, 10):                   # the reference's perturbation ladder (:335)
         model.parameters.set_active_values_from_flat(x + h * d)
         Jp = _J_only(qoi, F)
         model.parameters.set_active_values_from_flat(x - h * d)
