@@ -86,7 +86,7 @@ def lib():
     L.cm_evaluate.argtypes = [md, i64, C.c_int, dp, dp, dp, dp, dp, dp, dp, vp]; L.cm_evaluate.restype = C.c_int
     L.cm_evaluate_rate.argtypes = [md, i64, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, vp]; L.cm_evaluate_rate.restype = C.c_int
     L.cm_hessians.argtypes = [md, i64, dp, dp, dp, dp, dp, dp, dp, vp]; L.cm_hessians.restype = C.c_int
-    L.cm_hessians_rate.argtypes = [md, i64, dp, dp, dp, dp, dp, dp, dp, dp, vp]; L.cm_hessians_rate.restype = C.c_int
+    L.cm_hessians_rate.argtypes = [md, i64, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, vp]; L.cm_hessians_rate.restype = C.c_int
     L.cm_objective_grad.argtypes = [md, i64, dp, dp, dp, C.POINTER(C.c_double), dp, dp, vp, i64, vp]
     L.cm_objective_grad.restype = C.c_int
     L.cm_adjoint_step.argtypes = [md, i64, dp, dp, dp, dp, C.POINTER(C.c_double), dp, dp, dp, C.c_int, vp, i64, vp]

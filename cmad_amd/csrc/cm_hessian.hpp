@@ -187,16 +187,84 @@ CM_D void residual_rate_T(const cm_model_desc& m, const MatT<T>& p, const double
     if constexpr (DEF == CM_PLANE_STRESS) C[7] = r7 / twomu;
 }
 
+// local dofs of the AD-evaluated models: the rate form under UNIAXIAL_STRESS carries 12 (stress 6, alpha, two
+// off-axis stretches, three off-axis strain increments; small_rate_elastic_plastic.py:171-196), which the
+// hand-derived kernels (Dims<DEF>) do not implement
+template <int DEF, int MK>
+constexpr int nx_of() { return (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS) ? 12 : Dims<DEF>::NX; }
+
+// rate form, UNIAXIAL_STRESS (small_rate_elastic_plastic.py:34-75, 249-346): the global strain increment has the
+// on-axis entry dU from the caller, the off-axis normal entries from the stretch unknowns x[7:9] - xp[7:9] and the
+// shear entries x[9:12] themselves; every off-axis entry of the global stress increment must vanish.
+template <int YK, class T>
+CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, double dU,
+                                   const T* x, const T* xp, T* C, T s[6]) {
+    const int on = m.uniaxial_idx, ia = (on == 0) ? 1 : 0, ib = (on == 2) ? 1 : 2;
+    T eg[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) eg[i][j] = T{0.0};
+    eg[on][on] = T{dU};
+    eg[ia][ia] = x[7] - xp[7];
+    eg[ib][ib] = x[8] - xp[8];
+    eg[0][1] = eg[1][0] = x[9]; eg[0][2] = eg[2][0] = x[10]; eg[1][2] = eg[2][1] = x[11];
+    // material frame: e = Q^T eg Q  (Q = m.Q row-major, Q_ij = e_i(global) . e_j(material))
+    T em[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        T acc = T{0.0};
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc = acc + (m.Q[3 * a + i] * m.Q[3 * b + j]) * eg[a][b];
+        em[i][j] = acc;
+    }
+    const T e[6] = {em[0][0], em[0][1], em[0][2], em[1][1], em[1][2], em[2][2]};
+    for (int k = 0; k < 6; ++k) s[k] = x[k];
+    const T tr = e[0] + e[3] + e[5];
+    const T twomu = 2.0 * p.mu;
+    T phi, gt[6];
+    yield_T<YK, T>(p, s, phi, gt);
+    T H = T{0.0};
+    if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
+    if (m.has_linear) H = H + p.K * x[6];
+    const T f = (phi - (p.Y + H)) / twomu;
+    const T dg = x[6] - xp[6];
+    const double fv = t_val(f);
+    const bool plastic = (fv > m.yield_tol) || (fabs(fv) < m.yield_tol);
+    const T gd = gt[0] + gt[3] + gt[5];
+    T dc[6];
+    for (int k = 0; k < 6; ++k) {
+        dc[k] = twomu * e[k];
+        if (kDiag[k]) dc[k] = dc[k] + p.lambda * tr;
+        if (plastic) {
+            T cn = (twomu * kIW[k]) * gt[k];
+            if (kDiag[k]) cn = cn + p.lambda * gd;
+            dc[k] = dc[k] - dg * cn;
+        }
+        C[k] = (x[k] - xp[k] - dc[k]) / twomu;
+    }
+    C[6] = plastic ? f : dg;
+    // global stress increment Q dc Q^T
+    const T dm[3][3] = {{dc[0], dc[1], dc[2]}, {dc[1], dc[3], dc[4]}, {dc[2], dc[4], dc[5]}};
+    T dgl[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        T acc = T{0.0};
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc = acc + (m.Q[3 * i + a] * m.Q[3 * j + b]) * dm[a][b];
+        dgl[i][j] = acc;
+    }
+    C[7] = dgl[ia][ia] / twomu; C[8] = dgl[ib][ib] / twomu;
+    C[9] = dgl[0][1] / twomu; C[10] = dgl[0][2] / twomu; C[11] = dgl[1][2] / twomu;
+}
+
 // one (a, b) pair: out_C[NX] = d2 C / dq_a dq_b, out_S[6] = d2 sigma_global / dq_a dq_b,
 // and the first derivatives wrt q_a (for cross-checks): out_Ca[NX], out_Sa[6]
 // MK = CM_SMALL_RATE_ELASTIC_PLASTIC: G must already hold grad u - grad u_prev (the strain is linear in it).
 template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv, const double* xpv, int a, int b,
-                       double* out_C, double* out_S, double* out_Ca, double* out_Sa) {
-    constexpr int NX = Dims<DEF>::NX;
+                       double* out_C, double* out_S, double* out_Ca, double* out_Sa,
+                       double* out_C0 = nullptr, double* out_S0 = nullptr) {
+    constexpr int NX = nx_of<DEF, MK>();
+    constexpr bool RATE_UNI = (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS);
     double eg[6], z[Dims<DEF>::NZ];
-    strain_from_gradu<DEF, ROT>(m, G, eg);
-    strain_z<DEF, ROT>(m, z);
+    if constexpr (!RATE_UNI) {
+        strain_from_gradu<DEF, ROT>(m, G, eg);
+        strain_z<DEF, ROT>(m, z);
+    }
     HD x[NX], xp[NX], C[NX], s[6];
     MatT<HD> p;
     double pv[CM_NUM_PARAMS] = {m.lambda, m.mu, m.Y, m.voce_S, m.voce_D, m.lin_K,
@@ -209,14 +277,17 @@ CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv
     const HD* pp = q + 2 * NX;
     p.lambda = pp[0]; p.mu = pp[1]; p.Y = pp[2]; p.S = pp[3]; p.D = pp[4]; p.K = pp[5];
     for (int k = 0; k < 6; ++k) p.yc[k] = pp[6 + k];
-    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) residual_rate_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
+    if constexpr (RATE_UNI) residual_rate_uniaxial_T<YK, HD>(m, p, G[0], x, xp, C, s);
+    else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) residual_rate_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
     else residual_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
     for (int k = 0; k < NX; ++k) { out_C[k] = C[k].ab; out_Ca[k] = C[k].a; }
-    double s2[6], s1[6], g2[6], g1[6];
-    for (int k = 0; k < 6; ++k) { s2[k] = s[k].ab; s1[k] = s[k].a; }
+    double s2[6], s1[6], s0[6], g2[6], g1[6], g0[6];
+    for (int k = 0; k < 6; ++k) { s2[k] = s[k].ab; s1[k] = s[k].a; s0[k] = s[k].v; }
     to_global<ROT>(m, s2, g2);
     to_global<ROT>(m, s1, g1);
     for (int k = 0; k < 6; ++k) { out_S[k] = g2[k]; out_Sa[k] = g1[k]; }
+    if (out_C0) for (int k = 0; k < NX; ++k) out_C0[k] = C[k].v;
+    if (out_S0) { to_global<ROT>(m, s0, g0); for (int k = 0; k < 6; ++k) out_S0[k] = g0[k]; }
 }
 
 }  // namespace cm

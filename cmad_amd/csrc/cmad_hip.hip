@@ -443,21 +443,23 @@ template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 __global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ gradu_prev,
         const double* __restrict__ xi_prev, const double* __restrict__ xi,
-        double* __restrict__ d2C, double* __restrict__ d2S, double* __restrict__ dC, double* __restrict__ dS) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS, NPAIR = NQ * (NQ + 1) / 2;
+        double* __restrict__ d2C, double* __restrict__ d2S, double* __restrict__ dC, double* __restrict__ dS,
+        double* __restrict__ C0, double* __restrict__ S0) {
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS, NPAIR = NQ * (NQ + 1) / 2;
     const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (tid >= B * NPAIR) return;
     const int64_t pt = tid / NPAIR;
     int rem = (int)(tid % NPAIR), a = 0;
     while (rem >= NQ - a) { rem -= NQ - a; ++a; }         // pairs (a, b >= a) in row-major order
     const int b = a + rem;
-    double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6];
+    double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6], oC0[NX], oS0[6];
     for (int k = 0; k < NU; ++k) {
         G[k] = gradu[(int64_t)k * B + pt];
         if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_prev[(int64_t)k * B + pt];
     }
     for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + pt]; x[k] = xi[(int64_t)k * B + pt]; }
-    hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
+    const bool first = (a == 0 && b == 0);
+    hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa, first ? oC0 : nullptr, first ? oS0 : nullptr);
     if (d2C) for (int k = 0; k < NX; ++k) {
         d2C[((pt * NX + k) * NQ + a) * NQ + b] = oC[k];
         d2C[((pt * NX + k) * NQ + b) * NQ + a] = oC[k];
@@ -469,6 +471,10 @@ __global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
     if (a == b) {
         if (dC) for (int k = 0; k < NX; ++k) dC[(pt * NX + k) * NQ + a] = oCa[k];
         if (dS) for (int k = 0; k < 6; ++k) dS[(pt * 6 + k) * NQ + a] = oSa[k];
+    }
+    if (first) {                                          // values: residual and global stress at the given state
+        if (C0) for (int k = 0; k < NX; ++k) C0[pt * NX + k] = oC0[k];
+        if (S0) for (int k = 0; k < 6; ++k) S0[pt * 6 + k] = oS0[k];
     }
 }
 
@@ -597,11 +603,10 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
 #if CM_HAS_PART(6)
 template <int MK>
 int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
-                           const double* xi_prev, const double* xi,
-                           double* d2C, double* d2S, double* dC, double* dS, void* stream) {
+                    const double* xi_prev, const double* xi,
+                    double* d2C, double* d2S, double* dC, double* dS, double* C0, double* S0, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
     if (!supported(m, MK) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
-    if (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
@@ -610,9 +615,10 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
     (void)hipGetLastError();
     const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    const bool found = dispatch<(MK == CM_SMALL_ELASTIC_PLASTIC)>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!is_dense_yield(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS))
-            hipLaunchKernelGGL((k_hessians<D, Y, R, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS);
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (!is_dense_yield(Y))
+            hipLaunchKernelGGL((k_hessians<D, Y, R, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi,
+                               d2C, d2S, dC, dS, C0, S0);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
@@ -766,12 +772,12 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
 #if CM_HAS_PART(6)
 int cm_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream) {
-    return launch_hessians<CM_SMALL_ELASTIC_PLASTIC>(m, B, gradu, nullptr, xi_prev, xi, d2C, d2S, dC, dS, stream);
+    return launch_hessians<CM_SMALL_ELASTIC_PLASTIC>(m, B, gradu, nullptr, xi_prev, xi, d2C, d2S, dC, dS, nullptr, nullptr, stream);
 }
 int cm_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
                      const double* xi_prev, const double* xi,
-                     double* d2C, double* d2S, double* dC, double* dS, void* stream) {
-    return launch_hessians<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS, stream);
+                     double* d2C, double* d2S, double* dC, double* dS, double* C0, double* sigma0, void* stream) {
+    return launch_hessians<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS, C0, sigma0, stream);
 }
 #endif
 

@@ -17,6 +17,7 @@ import numpy as np
 
 from .. import _lib
 from ..parameters.parameters import Parameters
+from .deformation_types import DefType
 from .deriv_types import DerivType
 from .device import DeviceEvaluator, NewtonSettings, _ptr, build_desc, kp_to_leaf_grad
 from .global_fields import GlobalFieldsAtPoint
@@ -107,6 +108,25 @@ class Model(ABC):
         J = torch.empty((nx * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
         S = torch.empty((6 * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self._model_kind == 1 and self._def_type == DefType.UNIAXIAL_STRESS:
+            # 12-dof variant: residual, stress and first-derivative blocks by dual-number evaluation (cm_hessians_rate)
+            if int(which) in (int(DerivType.DU), int(DerivType.DU_PREV)):
+                raise NotImplementedError("d/dU of the rate form under UNIAXIAL_STRESS is not available in the HIP path")
+            Gp = np.zeros_like(G) if U_prev is None else np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
+            gp = t(Gp)
+            nq = 2 * nx + _lib.CM_NUM_PARAMS
+            need = want_jac and which != DerivType.DNONE
+            dC = torch.empty((nx, nq), dtype=torch.float64, device=dev) if need else None
+            dS = torch.empty((6, nq), dtype=torch.float64, device=dev) if need else None
+            C0 = torch.empty((1, nx), dtype=torch.float64, device=dev)
+            S0 = torch.empty((1, 6), dtype=torch.float64, device=dev)
+            rc = L.cm_hessians_rate(C.byref(desc), 1, _ptr(g), _ptr(gp), _ptr(x0), _ptr(x1), None, None,
+                                    _ptr(dC), _ptr(dS), _ptr(C0), _ptr(S0), stream)
+            _lib.check(rc, "cm_hessians_rate")
+            cols = {0: slice(0, nx), 1: slice(nx, 2 * nx), 2: slice(2 * nx, nq)}.get(int(which))
+            out_J = dC.cpu().numpy()[:, cols] if need else None
+            out_S = dS.cpu().numpy()[:, cols] if need else None
+            return C0.cpu().numpy()[0], out_J, S0.cpu().numpy()[0], out_S, info
         if self._model_kind == 1:
             Gp = np.zeros_like(G) if U_prev is None else np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
             gp = t(Gp)                                    # named: must outlive the launch
@@ -191,7 +211,7 @@ class Model(ABC):
         if self._model_kind == 1:                                         # rate form: the residual also takes grad u_prev
             gp = t(np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1))
             rc = L.cm_hessians_rate(C.byref(desc), 1, _ptr(g), _ptr(gp), _ptr(x0), _ptr(x1),
-                                    _ptr(d2C), _ptr(d2S), _ptr(dC), _ptr(dS), stream)
+                                    _ptr(d2C), _ptr(d2S), _ptr(dC), _ptr(dS), None, None, stream)
             _lib.check(rc, "cm_hessians_rate")
         else:
             rc = L.cm_hessians(C.byref(desc), 1, _ptr(g), _ptr(x0), _ptr(x1),

@@ -16,7 +16,7 @@ from .device import DEFAULT_LINE_SEARCH_SETTINGS, NewtonSettings
 
 def newton_solve(model, max_iters: int = 10, abs_tol: float = 1e-14, rel_tol: float = 1e-14,
                  max_ls_evals: int = 0):
-    if max_ls_evals == 0 and hasattr(model, "device_newton"):
+    if max_ls_evals == 0 and hasattr(model, "device_newton") and getattr(model, "has_device_newton", True):
         iters, _ = model.device_newton(max_iters, abs_tol, rel_tol)
         model.seed_none()
         model.evaluate()

@@ -5,8 +5,10 @@ material Cauchy stress.  Host mirror of /root/reference/cmad/models/small_rate_e
 
 Built on the device for FULL_3D and PLANE_STRESS: the stress update (`cm_update_rate`) and the stateful
 evaluate surface (`cm_evaluate_rate`: residual, every Jacobian block including d/dU_prev, Sigma, dSigma), so
-the material-point objectives run on it unchanged.  The batched tangent / reverse kernels of the rate form
-are not built yet."""
+the material-point objectives run on it unchanged; second derivatives through `cm_hessians_rate`.
+UNIAXIAL_STRESS (12 local dofs, :171-196) is served by `cm_hessians_rate` alone -- residual, stress, first and
+second derivatives by dual-number evaluation -- with the Newton loop of `newton_solve` on the host.
+The batched tangent / reverse kernels of the rate form are not built yet."""
 from __future__ import annotations
 
 from typing import ClassVar
@@ -42,8 +44,10 @@ class SmallRateElasticPlastic(Model):
             num_residuals = 2
         elif def_type == DefType.PLANE_STRESS:
             num_residuals = 3
+        elif def_type == DefType.UNIAXIAL_STRESS:
+            num_residuals = 4                       # reference :145-146
         else:
-            raise NotImplementedError("UNIAXIAL_STRESS of the rate form has no HIP kernel yet")
+            raise NotImplementedError
         self._init_residuals(num_residuals)
         self.var_names[0] = "cauchy"; self.resid_names[0] = "stress rate"
         self._var_types[0] = VarType.SYM_TENSOR
@@ -57,6 +61,14 @@ class SmallRateElasticPlastic(Model):
             self._var_types[2] = VarType.SCALAR
             self._num_eqs[2] = 1
             self._init_xi += [np.ones(1)]
+        elif def_type == DefType.UNIAXIAL_STRESS:                              # reference :181-196
+            self.var_names[2] = "off-axis stretches"; self.resid_names[2] = "off-axis normal stress"
+            self._var_types[2] = VarType.VECTOR
+            self._num_eqs[2] = get_num_eqs(VarType.VECTOR, 2)
+            self.var_names[3] = "off-axis delta strains"; self.resid_names[3] = "off-axis shear stress"
+            self._var_types[3] = VarType.VECTOR
+            self._num_eqs[3] = get_num_eqs(VarType.VECTOR, 3)
+            self._init_xi += [np.ones(self._num_eqs[2]), np.zeros(self._num_eqs[3])]
         self._init_state_variables()
         self.set_xi_to_init_vals()
         self.parameters = parameters
@@ -72,6 +84,12 @@ class SmallRateElasticPlastic(Model):
 
     def derived_output_field_names(self):
         return ["cauchy"]
+
+    @property
+    def has_device_newton(self) -> bool:
+        """UNIAXIAL_STRESS (12 local dofs) is served by dual-number evaluation only (cm_hessians_rate): its Newton
+        loop runs in `newton_solve` on the host with the device-evaluated residual and Jacobian."""
+        return self._def_type != DefType.UNIAXIAL_STRESS
 
     def device_newton(self, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search=None):
         import torch

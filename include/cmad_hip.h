@@ -240,15 +240,20 @@ int cm_hessians(const cm_model_desc* m, int64_t B,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream);
 
 /*
- * cm_hessians_rate: cm_hessians for the rate-form model (small_rate_elastic_plastic.py:249-359; FULL_3D and
- * PLANE_STRESS), whose residual also takes the previous grad u -- what the reference's Hessian checks run on
- * SmallRateElasticPlastic (tests/objectives/test_J2_fd_checks.py:303-392).
+ * cm_hessians_rate: cm_hessians for the rate-form model (small_rate_elastic_plastic.py:249-359), whose residual
+ * also takes the previous grad u -- what the reference's Hessian checks run on SmallRateElasticPlastic
+ * (tests/objectives/test_J2_fd_checks.py:303-392).  All three deformation types; under UNIAXIAL_STRESS the rate
+ * form has 12 local dofs (stress 6, alpha, two off-axis stretches, three off-axis strain increments, :171-196) and
+ * this entry point -- residual values, first and second derivatives by dual-number evaluation -- is how that
+ * variant is served (the hand-derived kernels cm_update_rate / cm_evaluate_rate cover FULL_3D and PLANE_STRESS).
+ *   out (all optional): d2C, d2S, dC, dS as cm_hessians; C0[B][n_xi] residual values, sigma0[B][6] global stress.
  */
 int cm_hessians_rate(const cm_model_desc* m, int64_t B,
                      const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
-                     double* d2C, double* d2S, double* dC, double* dS, void* stream);
+                     double* d2C, double* d2S, double* dC, double* dS, double* C0, double* sigma0, void* stream);
 
 #ifdef __cplusplus
 }
 #endif
-#endif /* CMAD_HIP_H */
+
+#endif

@@ -104,7 +104,7 @@ def evaluate_rate(desc, which, gradu, gradu_prev, xi_prev, xi, nx):
     return Cc, J.reshape(nx, ncols, B), s, S.reshape(6, ncols, B)
 
 
-def hessians(desc, gradu, xi_prev, xi, nx, gradu_prev=None):
+def hessians(desc, gradu, xi_prev, xi, nx, gradu_prev=None, values=False):
     """d2C (B,nx,nq,nq), d2S (B,6,nq,nq), dC (B,nx,nq), dS (B,6,nq); q = [xi, xi_prev, p(KP)].
     gradu_prev: rate-form model (desc.model_kind = 1)."""
     L = lib()
@@ -115,8 +115,12 @@ def hessians(desc, gradu, xi_prev, xi, nx, gradu_prev=None):
     d2C = np.zeros((B, nx, nq, nq)); d2S = np.zeros((B, 6, nq, nq)); dC = np.zeros((B, nx, nq)); dS = np.zeros((B, 6, nq))
     if gradu_prev is not None:
         gradu_prev = c(gradu_prev)
+        C0 = np.zeros((B, nx)); S0 = np.zeros((B, 6))
         rc = L.hh_hessians_rate(C.byref(desc), C.c_int64(B), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi),
-                                _p(d2C), _p(d2S), _p(dC), _p(dS))
+                                _p(d2C), _p(d2S), _p(dC), _p(dS), _p(C0), _p(S0))
+        assert rc == 0
+        if values:
+            return d2C, d2S, dC, dS, C0, S0
     else:
         rc = L.hh_hessians(C.byref(desc), C.c_int64(B), _p(gradu), _p(xi_prev), _p(xi), _p(d2C), _p(d2S), _p(dC), _p(dS))
     assert rc == 0

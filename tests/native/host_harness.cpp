@@ -145,20 +145,25 @@ static void run_evaluate_rate(const cm_model_desc& m, int64_t B, int which, cons
 
 template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
-                         double* d2C, double* d2S, double* dC, double* dS) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
-    if constexpr (!is_dense_yield(YK) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS)) {
+                         double* d2C, double* d2S, double* dC, double* dS, double* C0 = nullptr, double* S0 = nullptr) {
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
+    if constexpr (!is_dense_yield(YK)) {
         for (int64_t pt = 0; pt < B; ++pt) {
-            double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6];
+            double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6], oC0[NX], oS0[6];
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt] - (gradu_prev ? gradu_prev[k * B + pt] : 0.0);
             for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + pt]; x[k] = xi[k * B + pt]; }
             for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
-                hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa);
+                const bool first = (a == 0 && b == 0);
+                hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa, first ? oC0 : nullptr, first ? oS0 : nullptr);
                 for (int k = 0; k < NX; ++k) { d2C[((pt * NX + k) * NQ + a) * NQ + b] = oC[k]; d2C[((pt * NX + k) * NQ + b) * NQ + a] = oC[k]; }
                 for (int k = 0; k < 6; ++k) { d2S[((pt * 6 + k) * NQ + a) * NQ + b] = oS[k]; d2S[((pt * 6 + k) * NQ + b) * NQ + a] = oS[k]; }
                 if (a == b) {
                     for (int k = 0; k < NX; ++k) dC[(pt * NX + k) * NQ + a] = oCa[k];
                     for (int k = 0; k < 6; ++k) dS[(pt * 6 + k) * NQ + a] = oSa[k];
+                }
+                if (first) {
+                    if (C0) for (int k = 0; k < NX; ++k) C0[pt * NX + k] = oC0[k];
+                    if (S0) for (int k = 0; k < 6; ++k) S0[pt * 6 + k] = oS0[k];
                 }
             }
         }
@@ -217,9 +222,9 @@ int hh_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const do
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_hessians<D, Y, R>(*m, B, gradu, nullptr, xi_prev, xi, d2C, d2S, dC, dS); });
 }
 int hh_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
-                     const double* xi, double* d2C, double* d2S, double* dC, double* dS) {
-    return dispatch(m, [&]<int D, int Y, bool R>() {
-        run_hessians<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS); });
+                     const double* xi, double* d2C, double* d2S, double* dC, double* dS, double* C0, double* S0) {
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() {
+        run_hessians<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS, C0, S0); });
 }
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {

@@ -215,14 +215,15 @@ def test_facade_error_behaviour():
         m.dSigma()
 
 
-@pytest.mark.parametrize("def_name", ["FULL_3D", "PLANE_STRESS"])
+@pytest.mark.parametrize("def_name", ["FULL_3D", "PLANE_STRESS", "UNIAXIAL_STRESS"])
 def test_rate_model_reproduces_analytical_fields(golden_dir, def_name):
-    """`small rate` leg of tests/models/test_elastic_plastic_models.py:15-125 through the facade."""
+    """`small rate` leg of tests/models/test_elastic_plastic_models.py:15-125, 138-146 through the facade
+    (UNIAXIAL_STRESS: 12 local dofs, dual-number blocks + host Newton loop)."""
     from cmad_amd.models import DefType, SmallRateElasticPlastic, mp_U_from_F, newton_solve
     def_type = getattr(DefType, def_name)
-    nd = 3 if def_type == DefType.FULL_3D else 2
+    nd = {"FULL_3D": 3, "PLANE_STRESS": 2, "UNIAXIAL_STRESS": 1}[def_name]
     g = np.load(os.path.join(golden_dir, "j2_voce_analytical.npz"))
-    for name in ("uniaxial", "biaxial"):
+    for name in (("uniaxial",) if nd == 1 else ("uniaxial", "biaxial")):
         stress, strain, alpha = g[f"{name}_stress"], g[f"{name}_strain"], g[f"{name}_alpha"]
         F = np.repeat(np.eye(nd)[:, :, None], 101, axis=2)
         F[:, :, 1:] += strain[:nd, :nd, :]
