@@ -34,15 +34,32 @@ using namespace cm;
 // SoA row access.  `p` is the block's base (array + blockIdx.x * kBlock, wave-uniform -> SGPR pair) and `t`
 // the lane's offset inside the block, so each access is `global_load/store v, v_off, s[base]` with the row
 // stride added on the scalar unit -- no per-lane 64-bit address arithmetic.
+// Row k of a block's slice is the wave-uniform base p + k * B plus a 32-bit lane offset.  Each base is pinned to
+// an SGPR pair (empty asm with an "s" constraint, in the global address space) so that every access is the
+// `global_load/store v, v_lane_offset, s[base:base+1]` form: one shared VGPR offset, scalar-unit address arithmetic.
+// Left to itself the compiler re-associates the address into (p + lane) + k * B and spends a 64-bit VALU add and a
+// VGPR pair per row.
+typedef const __attribute__((address_space(1))) char* cm_gcptr;
+typedef __attribute__((address_space(1))) char* cm_gptr;
 template <int N>
 __device__ __forceinline__ void load_soa(const double* __restrict__ p, int64_t B, unsigned t, double* out) {
+    const uint32_t off = t * 8u;                  // t < kBlock
 #pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = (p + (int64_t)k * B)[t];
+    for (int k = 0; k < N; ++k) {
+        cm_gcptr row = (cm_gcptr)(p + (int64_t)k * B);
+        asm volatile("" : "+s"(row));
+        out[k] = *(const __attribute__((address_space(1))) double*)(row + off);
+    }
 }
 template <int N>
 __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, unsigned t, const double* v) {
+    const uint32_t off = t * 8u;
 #pragma unroll
-    for (int k = 0; k < N; ++k) (p + (int64_t)k * B)[t] = v[k];
+    for (int k = 0; k < N; ++k) {
+        cm_gptr row = (cm_gptr)(p + (int64_t)k * B);
+        asm volatile("" : "+s"(row));
+        *(__attribute__((address_space(1))) double*)(row + off) = v[k];
+    }
 }
 
 // minimum waves per SIMD requested from the register allocator (512 VGPRs per lane-slot / waves, in steps of 8:
