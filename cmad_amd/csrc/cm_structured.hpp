@@ -104,7 +104,8 @@ struct EvalS {
 
 // DEF = PLANE_STRESS: x[7] = F33 enters the strain through z = V(q3 q3^T) and adds the row C[7] = sigma_33 / 2mu
 // (cm::strain_stress, cm::residual); `z` is not read for FULL_3D.
-template <int YK, int DEF = CM_FULL_3D>
+// KNOWN_HD: ev.hd already holds hardening(x[6]) (the caller evaluated it at this very alpha) -- skips the exp.
+template <int YK, int DEF = CM_FULL_3D, bool KNOWN_HD = false>
 CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* z, const double* x, const double* xp,
                      EvalS<YK>& ev, double* C) {
     static_assert(DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS, "structured path: FULL_3D and PLANE_STRESS");
@@ -118,7 +119,7 @@ CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* z
 #pragma unroll
     for (int k = 0; k < 6; ++k) ev.s[k] = twomu * ev.e[k] + (kDiag[k] ? lt : 0.0);
     yield_eval_s<YK>(m, ev.s, ev.y);
-    ev.hd = hardening(m, x[6]);
+    if constexpr (!KNOWN_HD) ev.hd = hardening(m, x[6]);
     const double i2mu = 0.5 / m.mu;
     ev.f = (ev.y.phi - (m.Y + ev.hd.H)) * i2mu;
     ev.dgam = x[6] - xp[6];
@@ -460,6 +461,7 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
             const double f_old = f;
             alpha -= f * rcp(-(three_mu + dH) * i2mu);
             const Hard hd = hardening(m, alpha);
+            ev.hd = hd;                                              // hardening at the current alpha (reused below)
             f = (phi_tr - three_mu * (alpha - alpha_p) - (m.Y + hd.H)) * i2mu;
             dH = hd.dH;
             if (!((f > m.yield_tol) || (fabs(f) < m.yield_tol))) { fallback = true; running = false; }
@@ -480,7 +482,8 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
     // residual there -- the scalar f of the line and the 7-dof residual differ by round-off, and a lane that stopped
     // within that distance of the tolerance must behave exactly like the general path (e.g. re-applying the same
     // strain to the returned state is a 0-iteration step).  Such a lane (about one in 10^6) takes the general path.
-    residual_s<CM_YIELD_J2>(m, eg, x, xp, ev, C);
+    // ev.hd is hardening(x[6]) already: from the last step of the loop, or from the trial evaluation when no step was taken
+    residual_s<CM_YIELD_J2, CM_FULL_3D, true>(m, eg, nullptr, x, xp, ev, C);
     if (flags & CM_STATUS_CONVERGED) {
         const double nsq = dot<7>(C, C);
         if (!((nsq < rel2) || (nsq < abs2))) fallback = true;
