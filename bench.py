@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--ls-evals", type=int, default=0,
                     help="J2 workloads: line-search evaluations per Newton iteration (0 = newton_solve defaults, "
                          "4 = make_newton_solve defaults)")
+    ap.add_argument("--yield-surface", default="j2", choices=["j2", "hill", "hosford8", "barlat8"],
+                    help="j2_* workloads with another yield surface (side measurements): Al7079 Hill coefficients, "
+                         "Hosford a = 8, Yld2004-18p with the Al7079 coefficients and a = 8")
     ap.add_argument("--def-type", default="full_3d", choices=["full_3d", "plane_stress"],
                     help="J2 workloads: plane_stress is a side measurement (the reference's material-point tests' type)")
     ap.add_argument("--workload", default="j2_update_vjp",
@@ -180,6 +183,16 @@ def main():
     if wl == "ps_calibration_history":
         return history_workload(args, dev, rank, world, distributed)
     values = j2_voce_values()
+    if args.yield_surface != "j2":
+        assert wl.startswith("j2_"), "--yield-surface applies to the j2_* workloads"
+        from cmad_amd.synthetic import AL7079_HILL
+        al_barlat = [0.4555, 1.0274, 0.7101, 1.3755, 0.5314, 0.8817, 1.0558, 1.1133, 0.9220,
+                     1.2431, 1.5438, 1.2204, 0.7632, 0.5327, 0.3015, 0.9722, 0.7399, 1.0760, 8.0]
+        from cmad_amd.models.device import BARLAT_NAMES
+        values["plastic"]["effective stress"] = {
+            "hill": {"hill": dict(zip("FGHLMN", AL7079_HILL))},
+            "hosford8": {"hosford": {"a": 8.0}},
+            "barlat8": {"barlat": dict(zip(BARLAT_NAMES, al_barlat))}}[args.yield_surface]
     newton = NewtonSettings(j2_radial_line=not args.general_newton)   # newton_solve defaults: 10 iters, 1e-14, no line search
     if args.ls_evals > 0:                          # make_newton_solve: same tolerances + Armijo line search
         newton = NewtonSettings.traced(line_search_settings={"max evals": args.ls_evals})
@@ -298,7 +311,7 @@ def main():
                              "j2_objective_grad": "fused J2 calibration objective + gradient, single step (configs[4] per GPU)",
                              "hosford_update": "Hosford a=100 stress update, notch_hosford.yaml material (configs[2])",
                              "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])"}[wl],
-                "def_type": args.def_type, "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
+                "def_type": args.def_type, "yield_surface": args.yield_surface, "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
                 "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
                            "line_search_max_evals": newton.line_search["max evals"],
                            "solver": ("general 7-dof Newton, structured block solve"
@@ -316,7 +329,8 @@ def main():
                                     "j2_objective_grad": "k_reverse<FULL_3D,J2,noROT,fused objective+grad>"}.get(wl, "k_update"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_update": bytes_per_update},
         }
-        if n == 1 and wl == "j2_update_vjp" and not ps and args.ls_evals == 0 and not args.general_newton:
+        if (n == 1 and wl == "j2_update_vjp" and not ps and args.ls_evals == 0 and not args.general_newton
+                and args.yield_surface == "j2"):
             # the same workload (i) on the general 7-dof Newton path (no J2 specialisation) and (ii) with
             # make_newton_solve's default line search (4 evaluations; for J2 every full step passes the Armijo test,
             # so the iterates are the same and the acceptance bookkeeping is the only extra work).
