@@ -1,4 +1,5 @@
-// Structured linear algebra for the FULL_3D stress update with a pressure-independent yield surface.
+// Structured linear algebra for the FULL_3D / PLANE_STRESS stress update with a pressure-independent yield surface
+// (J2, Hill, Hosford); PLANE_STRESS borders the same 7x7 block with the F33 column and the sigma_33 row (solve_s).
 //
 // Same Newton iteration, same residual, same Jacobian as cm_device.hpp -- only the 7x7 solve is done by
 // block elimination instead of a dense LU, using what the Jacobian looks like for J2 / Hill / Hosford:
@@ -426,7 +427,7 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
 }
 
 // ---- J2, FULL_3D, plain Newton: the same iteration restricted to its invariant subspace ---------------------
-// Opt-in (cm_model_desc.solver_flags & CM_SOLVER_J2_RADIAL_LINE).  For J2 the 7-dof Newton iterates started at
+// Default for J2 / FULL_3D (cm_model_desc.solver_flags & CM_SOLVER_GENERAL_NEWTON turns it off).  For J2 the 7-dof Newton iterates started at
 // x_prev never leave the radial line v = v_prev + dgam n_trial: C[0:6] vanishes on it, dC/dx maps it to itself,
 // and the step reduces *exactly* to the scalar Newton step on f(alpha):
 //     phi(dgam) = phi_trial - 3 mu dgam ,  f = (phi - Y - H(alpha)) / 2mu ,  d alpha = f / ( -(3 mu + H') / 2mu )
@@ -642,7 +643,7 @@ template <int DEF, int YK>
 constexpr bool has_structured() {
     return (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS) && !is_dense_yield(YK);
 }
-// RL: the opt-in J2 radial-line iteration (cm_model_desc.solver_flags & CM_SOLVER_J2_RADIAL_LINE); a compile-time
+// RL: the J2 radial-line iteration (default; cm_model_desc.solver_flags & CM_SOLVER_GENERAL_NEWTON disables it); a compile-time
 // variant chosen by the launcher so that the default kernels do not carry its code and registers.
 template <int DEF, int YK, bool LS, bool STRUCT = true, bool RL = false>
 CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x, bool valid,

@@ -80,7 +80,7 @@ class Model(ABC):
 
     def device_evaluator(self, newton: NewtonSettings | None = None) -> DeviceEvaluator:
         """A `DeviceEvaluator` for the CURRENT parameter values (rebuilt per call: parameters change between
-        objective evaluations, and the description is 296 bytes)."""
+        objective evaluations, and the description is a few hundred bytes)."""
         return DeviceEvaluator(*self._desc(newton=newton))
 
     @staticmethod

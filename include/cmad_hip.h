@@ -134,7 +134,8 @@ int cm_update(const cm_model_desc* m, int64_t B,
  * (cmad/models/small_rate_elastic_plastic.py:249-346) followed by its _cauchy_fn (:351-359).
  *   in : gradu[n_gradu][B], gradu_prev[n_gradu][B], xi_prev[n_xi][B] (xi = [sigma(6), alpha (, F33)])
  *   out: xi[n_xi][B], sigma[6][B] (global axes, may be NULL), status[B] (may be NULL)
- * Sensitivity entry points for the rate form are not built yet (they return CM_ERR_UNSUPPORTED).
+ * The batched sensitivity entry points (cm_update_tangent / _vjp / cm_objective_grad ...) exist for the total form
+ * only and return CM_ERR_UNSUPPORTED for this model; cm_evaluate_rate and cm_hessians_rate give its derivative blocks.
  */
 int cm_update_rate(const cm_model_desc* m, int64_t B,
                    const double* gradu, const double* gradu_prev, const double* xi_prev,
