@@ -176,7 +176,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is reserved for the one JSON
+        # line, so the communicator is created (init + one tiny all-reduce) with fd 1 pointed at stderr.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            probe = torch.zeros(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     B = args.points
     wl = args.workload
