@@ -1316,6 +1316,45 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
 }
 
 
+// ---- forward tangent of the rate-form model at a converged state ------------------------------------------------
+// T[r][l] = d s_r / d (d eg)_l : the unknown x[0:6] IS the material stress, so T is the first six rows of
+// dx / d deg = -A^-1 dC/d deg with dC_k/d deg_l = -Cel_kl / 2mu (both branches) and, under PLANE_STRESS,
+// dC_7/d deg_l = (Cel (w o z))_l / 2mu  (small_rate_elastic_plastic.py:249-346; IFT rule nonlinear_solver.py:158-171).
+template <int DEF, int YK>
+CM_D bool tangent_point_rate(const cm_model_desc& m, const double deg[6], const double z[6],
+                             const double* x, const double* xp, double (&T)[6][6]) {
+    static_assert(DEF != CM_UNIAXIAL_STRESS, "batched rate-form tangent: FULL_3D and PLANE_STRESS");
+    constexpr int NX = Dims<DEF>::NX;
+    Eval<DEF> ev;
+    double C[NX], Ht[6][6], A[NX][NX];
+    residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
+    jacobian_rate<DEF, false>(m, z, ev, Ht, A);
+    const bool ok = lu_factor<NX>(A);
+    const double i2mu = 0.5 / m.mu;
+    double czw[6];
+    if constexpr (DEF == CM_PLANE_STRESS) {
+        double zw[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) zw[k] = kW[k] * z[k];
+        apply_cel(m, zw, czw);
+    }
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        double unit[6], col[6], b[NX];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) unit[k] = (k == l) ? 1.0 : 0.0;
+        apply_cel(m, unit, col);                                 // Cel e_l
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = col[k] * i2mu;        // -dC_k / d deg_l
+        b[6] = 0.0;
+        if constexpr (DEF == CM_PLANE_STRESS) b[7] = -czw[l] * i2mu;
+        lu_subst<NX>(A, b);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) T[r][l] = b[r];
+    }
+    return ok;
+}
+
 // ---- explicit derivative blocks at an arbitrary state (the reference's stateful evaluate() surface) ----
 // cmad/models/model.py:168-190 (Jac for DXI / DXI_PREV / DPARAMS / DU) and :273-293 (dSigma).
 // Column counts: DXI, DXI_PREV -> NX ; DPARAMS -> CM_NUM_PARAMS (KP order) ; DU -> NU.

@@ -164,10 +164,10 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>()))
 }
 
 // ---- cm_update_rate: rate-form model (small_rate_elastic_plastic) ------------------------------------------
-template <int DEF, int YK, bool ROT, bool LS>
+template <int DEF, int YK, bool ROT, bool LS, bool TANGENT = false>
 __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
-        double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
+        double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
     gradu += blk0; gradu_prev += blk0; xi_prev += blk0; xi += blk0;
     if (sigma) sigma += blk0;
     if (status) status += blk0;
+    if (dsig) dsig += blk0;
     double G[NU], Gp[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NU>(gradu_prev, B, b, Gp);
@@ -196,6 +197,31 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
         store_soa<NX>(xi, B, b, x);
         if (sigma) store_soa<6>(sigma, B, b, sg);
         if (status) status[b] = st;
+    }
+    if constexpr (TANGENT) {
+        // d sig_g / d G_c = Rg T Rm dE/dG_c (and minus that w.r.t. grad u_prev): the same chain as k_update
+        double T[6][6];
+        const bool ok = tangent_point_rate<DEF, YK>(m, deg, z, x, xp, T);
+        if (!ok && valid && status) status[b] = st | CM_STATUS_SINGULAR;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            double Gd[NU], dm[6], t[6], tg[6];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gd, dm);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < 6; ++l) s += T[r][l] * dm[l];
+                t[r] = s;
+            }
+            to_global<ROT>(m, t, tg);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) (dsig + (int64_t)(r * NU + c) * B)[b] = tg[r];
+            }
+        }
     }
 }
 
@@ -706,7 +732,28 @@ int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
     const cm_model_desc md = *m;
     (void)hipGetLastError();
     const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
-        hipLaunchKernelGGL((k_update_rate<D, Y, R, LS>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma, status);
+        hipLaunchKernelGGL((k_update_rate<D, Y, R, LS, false>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma, nullptr, status);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+#endif
+
+#if CM_HAS_PART(5)
+int cm_update_rate_tangent(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                           const double* xi_prev, double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status,
+                           void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC)) return CM_ERR_UNSUPPORTED;
+    if (B == 0) return CM_OK;
+    if (!gradu || !gradu_prev || !xi_prev || !xi || !dsigma_dgradu) return CM_ERR_BAD_ARG;
+    const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+        hipLaunchKernelGGL((k_update_rate<D, Y, R, LS, true>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma,
+                           dsigma_dgradu, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();

@@ -26,9 +26,11 @@ from ..models.device import NewtonSettings
 _V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
 
 
-def local_update_with_tangent(model, grad_u, xi_prev, newton: NewtonSettings | None = None):
+def local_update_with_tangent(model, grad_u, xi_prev, newton: NewtonSettings | None = None, grad_u_prev=None):
     """`newton` defaults to the FE binding's local settings (global_residual.py:292-297 / io/deck.py:71-82):
-    20 iterations, 1e-12 tolerances, line search with 4 evaluations."""
+    20 iterations, 1e-12 tolerances, line search with 4 evaluations.
+    `grad_u_prev` (same layout as grad_u) is required for `SmallRateElasticPlastic` blocks, whose local residual
+    sees grad u - grad u_prev (`cm_update_rate_tangent`); d sigma / d grad u_prev is minus the returned tangent."""
     import torch
     newton = newton or NewtonSettings.traced(max_iters=20, abs_tol=1e-12, rel_tol=1e-12)
     ne, nip, nd, _ = grad_u.shape
@@ -36,7 +38,14 @@ def local_update_with_tangent(model, grad_u, xi_prev, newton: NewtonSettings | N
     nx = xi_prev.shape[-1]
     g = grad_u.reshape(B, nd * nd).t().contiguous()                 # (nd*nd, B) SoA
     xp = xi_prev.reshape(B, nx).t().contiguous()
-    xi, sig6, status, ds = model.device_evaluator(newton).update(g, xp, tangent=True)
+    if getattr(model, "_model_kind", 0) == 1:
+        if grad_u_prev is None:
+            raise ValueError("the rate-form model needs grad_u_prev")
+        gp = grad_u_prev.reshape(B, nd * nd).t().contiguous()
+        xi, sig6, status, ds = model.device_evaluator(newton).update_rate(g, gp, xp, tangent=True)
+        ds = ds.reshape(6, nd * nd, B)
+    else:
+        xi, sig6, status, ds = model.device_evaluator(newton).update(g, xp, tangent=True)
     xi_aos = xi.t().reshape(ne, nip, nx)
     sigma = torch.empty((B, 3, 3), dtype=torch.float64, device=g.device)
     dsig = torch.empty((B, 3, 3, nd * nd), dtype=torch.float64, device=g.device)

@@ -290,8 +290,10 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_update")
         return xi, sigma, status
 
-    def update_rate(self, gradu, gradu_prev, xi_prev, want_sigma=True, want_status=True):
-        """Rate-form model (`small_rate_elastic_plastic`): xi = [sigma(6), alpha (, F33)]."""
+    def update_rate(self, gradu, gradu_prev, xi_prev, want_sigma=True, want_status=True, tangent=False):
+        """Rate-form model (`small_rate_elastic_plastic`): xi = [sigma(6), alpha (, F33)].
+        tangent=True also returns d sigma / d gradu (6 * n_gradu, B) (`cm_update_rate_tangent`); the derivative
+        w.r.t. gradu_prev is its negative."""
         torch = _torch()
         B = gradu.shape[1]
         _check_soa(gradu, self.nu, B, "gradu"); _check_soa(gradu_prev, self.nu, B, "gradu_prev")
@@ -300,6 +302,12 @@ class DeviceEvaluator:
         xi = torch.empty((self.nx, B), dtype=torch.float64, device=dev)
         sigma = torch.empty((6, B), dtype=torch.float64, device=dev) if want_sigma else None
         status = torch.empty((B,), dtype=torch.int32, device=dev) if want_status else None
+        if tangent:
+            dsig = torch.empty((6 * self.nu, B), dtype=torch.float64, device=dev)
+            rc = self.L.cm_update_rate_tangent(C.byref(self.desc), B, _ptr(gradu), _ptr(gradu_prev), _ptr(xi_prev), _ptr(xi),
+                                               _ptr(sigma), _ptr(dsig), _ptr(status), self._stream())
+            _lib.check(rc, "cm_update_rate_tangent")
+            return xi, sigma, status, dsig
         rc = self.L.cm_update_rate(C.byref(self.desc), B, _ptr(gradu), _ptr(gradu_prev), _ptr(xi_prev), _ptr(xi),
                                    _ptr(sigma), _ptr(status), self._stream())
         _lib.check(rc, "cm_update_rate")

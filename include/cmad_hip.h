@@ -134,12 +134,24 @@ int cm_update(const cm_model_desc* m, int64_t B,
  * (cmad/models/small_rate_elastic_plastic.py:249-346) followed by its _cauchy_fn (:351-359).
  *   in : gradu[n_gradu][B], gradu_prev[n_gradu][B], xi_prev[n_xi][B] (xi = [sigma(6), alpha (, F33)])
  *   out: xi[n_xi][B], sigma[6][B] (global axes, may be NULL), status[B] (may be NULL)
- * The batched sensitivity entry points (cm_update_tangent / _vjp / cm_objective_grad ...) exist for the total form
- * only and return CM_ERR_UNSUPPORTED for this model; cm_evaluate_rate and cm_hessians_rate give its derivative blocks.
+ * The reverse-mode batched entry points (cm_update_vjp / cm_objective_grad / cm_adjoint_step) exist for the total
+ * form only and return CM_ERR_UNSUPPORTED for this model; cm_update_rate_tangent, cm_evaluate_rate and
+ * cm_hessians_rate give its forward tangent and derivative blocks.
  */
 int cm_update_rate(const cm_model_desc* m, int64_t B,
                    const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status, void* stream);
+
+/*
+ * cm_update_rate_tangent: cm_update_rate plus the IFT-consistent tangent d sigma / d gradu (FULL_3D, PLANE_STRESS);
+ * d sigma / d gradu_prev is its negative (the residual sees grad u - grad u_prev only).  What
+ * GlobalResidual._for_model_coupled (global_residuals/global_residual.py:373-394) obtains by jacfwd through the
+ * custom_jvp rule when the block's model is SmallRateElasticPlastic (tests/fem/test_mixed_up_plastic.py:140-147).
+ *   out: dsigma_dgradu[6*n_gradu][B], entry (r, c) at [(r*n_gradu + c)*B + b]
+ */
+int cm_update_rate_tangent(const cm_model_desc* m, int64_t B,
+                           const double* gradu, const double* gradu_prev, const double* xi_prev,
+                           double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream);
 
 /*
  * cm_update_tangent: cm_update plus the IFT-consistent tangent d sigma / d gradu.

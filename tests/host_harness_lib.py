@@ -91,6 +91,18 @@ def update_rate(desc, gradu, gradu_prev, xi_prev, nx):
     return xi, sig, st
 
 
+def tangent_rate(desc, gradu, gradu_prev, xi_prev, xi):
+    """d sigma / d gradu (6 * n_gradu, B) of the rate form at converged states."""
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu, gradu_prev, xi_prev, xi = c(gradu), c(gradu_prev), c(xi_prev), c(xi)
+    B, nu = gradu.shape[1], gradu.shape[0]
+    ds = np.zeros((6 * nu, B))
+    rc = L.hh_tangent_rate(C.byref(desc), C.c_int64(B), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi), _p(ds))
+    assert rc == 0
+    return ds
+
+
 def evaluate_rate(desc, which, gradu, gradu_prev, xi_prev, xi, nx):
     L = lib()
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)

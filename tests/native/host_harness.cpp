@@ -124,6 +124,29 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
     }
 }
 
+// d sigma_global / d grad u of the rate form at converged states (the epilogue of k_update_rate<TANGENT>)
+template <int DEF, int YK, bool ROT>
+static void run_tangent_rate(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev,
+                             const double* xi_prev, const double* xi, double* dsig) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    for (int64_t b = 0; b < B; ++b) {
+        double G[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], T[6][6];
+        for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
+        for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; }
+        strain_from_gradu<DEF, ROT>(m, G, deg);
+        strain_z<DEF, ROT>(m, z);
+        tangent_point_rate<DEF, YK>(m, deg, z, x, xp, T);
+        for (int c = 0; c < NU; ++c) {
+            double Gd[NU], dm[6], t[6], tg[6];
+            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gd, dm);
+            for (int r = 0; r < 6; ++r) { double s = 0.0; for (int l = 0; l < 6; ++l) s += T[r][l] * dm[l]; t[r] = s; }
+            to_global<ROT>(m, t, tg);
+            for (int r = 0; r < 6; ++r) dsig[(int64_t)(r * NU + c) * B + b] = tg[r];
+        }
+    }
+}
+
 template <int DEF, int YK, bool ROT>
 static void run_evaluate_rate(const cm_model_desc& m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                               const double* xi_prev, const double* xi, double* C_out, double* J_out, double* s_out, double* S_out) {
@@ -212,6 +235,10 @@ int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double*
 int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
+}
+int hh_tangent_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                    const double* xi_prev, const double* xi, double* dsig) {
+    return dispatch(m, [&]<int D, int Y, bool R>() { run_tangent_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, dsig); });
 }
 int hh_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                      const double* xi_prev, const double* xi, double* C, double* J, double* s, double* S) {

@@ -271,6 +271,36 @@ def test_fe_coupled_bridge_layouts():
     assert ((status.cpu().numpy().astype(np.uint32) >> 16) & 1).all()
 
 
+def test_fe_coupled_bridge_rate_model():
+    """The same bridge for a SmallRateElasticPlastic block (cm_update_rate_tangent; the reference's FE tests run this
+    model, tests/fem/test_mixed_up_plastic.py:140-147) vs the oracle's IFT tangent with the previous grad u."""
+    import torch
+    from cmad_amd.global_residuals import local_update_with_tangent
+    from cmad_amd.models import DefType, SmallRateElasticPlastic
+    ne, nip = 19, 8
+    B = ne * nip
+    from cmad_amd.synthetic import gauss_point_batch
+    model = SmallRateElasticPlastic(params_J2_voce(scale_params=False), DefType.FULL_3D)
+    g = gauss_point_batch(B, seed=6, skew=True)
+    mat = ol.Material(ol.j2_voce_values(), model_kind=ol.SMALL_RATE_EP)
+    st_o = ol.newton_settings(max_iters=20, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=4)
+    xp, _, _, _ = mat.update_batch(st_o, 0.7 * g, np.zeros((7, B)), gradu_prev=np.zeros_like(g))
+    xi_o, sig_o, _, cv = mat.update_batch(st_o, g, xp, gradu_prev=0.7 * g)
+    ds_o, _ = mat.tangent_batch(g, xp, xi_o, gradu_prev=0.7 * g)
+    aos = lambda a, n: torch.from_numpy(a.T.reshape(ne, nip, *n).copy()).cuda()
+    xi, sigma, dsig, status = local_update_with_tangent(model, aos(g, (3, 3)), aos(xp, (7,)), grad_u_prev=aos(0.7 * g, (3, 3)))
+    np.testing.assert_allclose(xi.cpu().numpy().reshape(B, 7).T[:6], xi_o[:6], rtol=1e-10, atol=1e-7)
+    V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    d = dsig.cpu().numpy().reshape(B, 3, 3, 9)
+    for r, (i, j) in enumerate(V6):
+        np.testing.assert_allclose(sigma.cpu().numpy().reshape(B, 3, 3)[:, i, j], sig_o[r], rtol=1e-10, atol=1e-7)
+        np.testing.assert_allclose(d[:, i, j, :].T, ds_o[r], rtol=1e-8, atol=1e-9 * np.abs(ds_o).max())
+        np.testing.assert_allclose(d[:, j, i, :], d[:, i, j, :])
+    with pytest.raises(ValueError):
+        local_update_with_tangent(model, aos(g, (3, 3)), aos(xp, (7,)))
+
+
+
 @pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
 def test_uniaxial_stress_model_reproduces_analytical_fields(golden_dir, yield_kind):
     """test_small_uniaxial_stress of tests/models/test_elastic_plastic_models.py (n_xi = 9, 1x1 grad u)."""

@@ -96,3 +96,19 @@ def test_adjoint_history(backend, def_type, yield_kind, kw):
     np.testing.assert_allclose(res[0], J_o, rtol=1e-10)
     got, ref = pc.leaf_grads(res[1:], sc.info, mat, yield_kind, g_o)
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_form_tangent(def_type, yield_kind, kw, rot):
+    """cm_update_rate_tangent: the update reproduces the oracle's state and the tangent its IFT Jacobian."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator
+
+    def run(desc, info, g, gp, xp, x_expected):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        xi, sig, st, ds = DeviceEvaluator(desc, info).update_rate(t(g), t(gp), t(xp), tangent=True)
+        np.testing.assert_allclose(xi.cpu().numpy()[:6], x_expected[:6], rtol=1e-10, atol=1e-7)
+        return ds.cpu().numpy()
+    pc.check_rate_tangent(run, def_type, yield_kind, kw, rot, B=1024)

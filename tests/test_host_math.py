@@ -377,3 +377,13 @@ def test_rate_form_uniaxial_by_dual_numbers(yield_kind, kw, idx, plastic, solver
     keep = list(range(2 * nx + npar))
     sel = np.ix_(range(nx), keep, keep)
     np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refC[sel]).max()))
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_form_tangent(def_type, yield_kind, kw, rot, solver_variant):
+    import host_harness_lib as hh
+    if solver_variant == "dense":
+        pytest.skip("rate form always uses the dense path")
+    pc.check_rate_tangent(lambda desc, info, g, gp, xp, x: hh.tangent_rate(desc, g, gp, xp, x), def_type, yield_kind, kw, rot, B=192)
