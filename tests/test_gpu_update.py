@@ -304,3 +304,42 @@ def test_full_size_hosford_a100():
     lo, n = 7_000_001, 65_537
     xi_s, sig_s, _ = ev.update(gradu[:, lo:lo + n].contiguous(), xi_prev[:, lo:lo + n].contiguous())
     assert torch.equal(xi_s, xi[:, lo:lo + n]) and torch.equal(sig_s, sig[:, lo:lo + n])
+
+
+def test_full_size_hybrid_network_surface():
+    """configs[3] at its full size (5 x 10^6 points, hybrid Hill + ICNN [6,16,1], traced Newton with line search):
+    convergence, a random sample against the oracle, launch-size independence, idempotence."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, HybridHillEffectiveStress, NewtonSettings, build_desc
+    from cmad_amd.synthetic import al7079_hybrid_setup, gauss_point_batch
+    B = 5_000_000
+    icnn, values = al7079_hybrid_setup()
+    newton = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})
+    desc, info = build_desc(values, newton=newton, hybrid=HybridHillEffectiveStress(icnn))
+    ev = DeviceEvaluator(desc, info)
+    g_host = gauss_point_batch(B, seed=25, eps_y=525.0 / 70.2e3)
+    gradu = torch.from_numpy(g_host).cuda()
+    xi_prev = torch.zeros((7, B), dtype=torch.float64, device="cuda")
+    xi, sig, st = ev.update(gradu, xi_prev)
+    st = st.to(torch.int64)
+    ok = ((st >> 16) & 1).bool()
+    assert float(ok.double().mean()) > 0.9999
+    plastic = ((st >> 17) & 1).bool() & ok
+    assert 0.3 < plastic.double().mean().item() < 0.9
+    assert float((xi[0] + xi[3] + xi[5]).abs().max()) < 1e-14          # the surface is pressure independent
+    idx = np.sort(np.random.default_rng(8).choice(B, 512, replace=False))
+    tidx = torch.from_numpy(idx).cuda()
+    mat = ol.Material(values, nn=icnn.pack_for_device())
+    st_o = ol.newton_settings(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=10)
+    xi_o, sig_o, it_o, cv_o = mat.update_batch(st_o, g_host[:, idx], np.zeros((7, idx.size)))
+    both = cv_o.astype(bool) & ok[tidx].cpu().numpy()
+    assert both.mean() > 0.99
+    np.testing.assert_allclose(xi[:, tidx].cpu().numpy()[:, both], xi_o[:, both], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(sig[:, tidx].cpu().numpy()[:, both], sig_o[:, both], rtol=1e-9, atol=1e-7)
+    lo, n = 1_234_567, 50_001
+    xi_s, sig_s, _ = ev.update(gradu[:, lo:lo + n].contiguous(), xi_prev[:, lo:lo + n].contiguous())
+    assert torch.equal(xi_s, xi[:, lo:lo + n]) and torch.equal(sig_s, sig[:, lo:lo + n])
+    sel = slice(0, 200_000)
+    xi2, sig2, st2 = ev.update(gradu[:, sel].contiguous(), xi[:, sel].contiguous())
+    it2 = st2.to(torch.int64) & 0xFFFF
+    assert float((it2[ok[sel]] == 0).double().mean()) > 0.999              # re-applying the strain: elastic, no iterations
