@@ -583,3 +583,34 @@ def test_isotropic_barlat_reproduces_the_j2_analytical_fields(history):
         alphas[step - 1] = model.xi()[1][0]
     assert np.linalg.norm(alphas - alpha) < 1e-6
     assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6
+
+
+@pytest.mark.gpu
+def test_config0_uniaxial_ramp_on_the_fe_layout(golden_dir):
+    """BASELINE.json configs[0] (examples/elastic_plastic_uniaxial.yaml: J2 + Voce cube under a uniaxial-stress ramp,
+    1331 hexes x 8 integration points = 10 648 Gauss points at --n 11) without the FE solver, which is out of scope:
+    every integration point follows the homogeneous solution's strain path through the FE COUPLED bridge with the FE
+    binding's local solver settings, and must reproduce the reference's closed form (compute_plastic_fields; the
+    reference's own FE round trip checks it at rtol 1e-3, tests/cli/test_primal_fe_roundtrip.py:183-234)."""
+    import torch
+    from cmad_amd.global_residuals import local_update_with_tangent
+    DefType, SmallElasticPlastic = _models()
+    g = np.load(os.path.join(golden_dir, "j2_voce_analytical.npz"))
+    strain, stress, alpha = g["uniaxial30_strain"], g["uniaxial30_stress"], g["uniaxial30_alpha"]
+    ne, nip = 1331, 8
+    model = SmallElasticPlastic(params_J2_voce(scale_params=False), DefType.FULL_3D)
+    xi = torch.zeros((ne, nip, 7), dtype=torch.float64, device="cuda")
+    for step in range(strain.shape[2]):
+        grad_u = torch.from_numpy(strain[:, :, step]).cuda().expand(ne, nip, 3, 3).contiguous()
+        xi, sigma, dsig, status = local_update_with_tangent(model, grad_u, xi)
+        assert bool(((status.to(torch.int64) >> 16) & 1).all())
+        s = sigma.reshape(-1, 3, 3)
+        assert float((s - s[0]).abs().max()) == 0.0                      # every point identical, bit for bit
+        np.testing.assert_allclose(s[0].cpu().numpy(), stress[:, :, step], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(float(xi[0, 0, 6]), alpha[step], rtol=1e-6, atol=1e-9)
+    # consistent tangent at the final state: d sigma_xx / d eps_xx under the constrained (uniaxial-strain) perturbation
+    # is finite, symmetric in the minor indices and softer than the elastic modulus
+    d = dsig.reshape(-1, 3, 3, 3, 3)[0].cpu().numpy()
+    np.testing.assert_allclose(d, d.transpose(1, 0, 2, 3), rtol=0, atol=1e-9)
+    lam, mu = 200e3 * 0.3 / (1.3 * 0.4), 200e3 / 2.6
+    assert 0.0 < d[0, 0, 0, 0] < lam + 2 * mu
