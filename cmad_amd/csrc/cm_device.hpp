@@ -1316,6 +1316,127 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
 }
 
 
+// ---- reverse sweep of the rate-form model at a converged state --------------------------------------------------
+// Same contract as reverse_point for small_rate_elastic_plastic.py:249-359.  The unknown x[0:6] is the material stress,
+// so (d s / d x)^T sbar_m = [sbar_m ; 0] and the stress has no direct dependence on parameters or strain:
+//   lam = A^-T ([sbar_m ; 0] + xin) ,  pbar = -(dC/dp)^T lam ,  xpbar = -(dC/dx_prev)^T lam ,
+//   degbar = -(dC/d deg)^T lam   (cotangent of the material strain INCREMENT; grad u gets +, grad u_prev gets -).
+// Block formulas: evaluate_blocks_rate below (checked there against the oracle's dual-number Jacobians).
+template <int DEF, int YK>
+CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const double z[6],
+                             const double* x, const double* xp, const double sbm[6], const double* xin,
+                             double* pbar, double* xpbar, double* degbar) {
+    static_assert(DEF != CM_UNIAXIAL_STRESS, "batched rate-form reverse sweep: FULL_3D and PLANE_STRESS");
+    constexpr int NX = Dims<DEF>::NX;
+    constexpr bool PS = (DEF == CM_PLANE_STRESS);
+    Eval<DEF> ev;
+    double C[NX], Ht[6][6], At[NX][NX], lam[NX];
+    residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
+    jacobian_rate<DEF, true>(m, z, ev, Ht, At);
+    const bool ok = lu_factor<NX>(At);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lam[k] = sbm[k];
+#pragma unroll
+    for (int k = 6; k < NX; ++k) lam[k] = 0.0;
+    if (xin) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) lam[k] += xin[k];
+    }
+    lu_subst<NX>(At, lam);
+    const double i2mu = 0.5 / m.mu;
+    const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
+    const double dgp = ev.plastic ? ev.dgam : 0.0;
+    double n[6], cn[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n[k] = ev.plastic ? ev.gt[k] * kIW[k] : 0.0;
+    apply_cel(m, n, cn);
+    const double lam6 = ev.plastic ? lam[6] : 0.0;
+    const double ld = lam[0] + lam[3] + lam[5];
+    double zw[6], czw[6], zt = 0.0, lam7 = 0.0;
+    if constexpr (PS) {
+        zt = z[0] + z[3] + z[5];
+        lam7 = lam[7];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) zw[k] = kW[k] * z[k];
+        apply_cel(m, zw, czw);
+    }
+    if (pbar) {
+        double le = 0.0, ln = 0.0, lc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { le += lam[k] * ev.e[k]; ln += lam[k] * n[k]; lc += lam[k] * C[k]; }
+        // lam . dC/dlambda , lam . dC/dmu
+        double cl = ld * (-ev.tr + dgp * gd) * i2mu;
+        double cm_ = (-2.0 * le + dgp * 2.0 * ln) * i2mu - lc / m.mu + lam6 * (-ev.f / m.mu);
+        if constexpr (PS) {
+            double zwe = 0.0, zwn = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { zwe += zw[k] * ev.e[k]; zwn += zw[k] * n[k]; }
+            cl += lam7 * zt * (ev.tr - dgp * gd) * i2mu;
+            cm_ += lam7 * ((2.0 * zwe - dgp * 2.0 * zwn) * i2mu - C[7] / m.mu);
+        }
+        pbar[CM_P_LAMBDA] = -cl;
+        pbar[CM_P_MU] = -cm_;
+        pbar[CM_P_Y] = lam6 * i2mu;
+        pbar[CM_P_VOCE_S] = m.has_voce ? lam6 * (1.0 - ev.hd.expo) * i2mu : 0.0;
+        pbar[CM_P_VOCE_D] = m.has_voce ? lam6 * m.voce_S * x[6] * ev.hd.expo * i2mu : 0.0;
+        pbar[CM_P_LIN_K] = m.has_linear ? lam6 * x[6] * i2mu : 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pbar[CM_P_YC0 + j] = 0.0;
+        if constexpr (YK == CM_YIELD_HILL) {
+            if (ev.plastic) {
+                const double* s = ev.s;
+                const double ip = 1.0 / ev.phi;
+                const double d12 = s[3] - s[5], d20 = s[5] - s[0], d01 = s[0] - s[3];
+                const double qj[6] = {d12 * d12, d20 * d20, d01 * d01, 2.0 * s[4] * s[4], 2.0 * s[2] * s[2], 2.0 * s[1] * s[1]};
+                // u = Cel (lam_v - lam7 (w o z)) : lam . dC/dc_j = dgam i2mu u . dn/dc_j + lam6 q_j / (2 phi) i2mu
+                double lv[6], u[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) lv[k] = lam[k] - (PS ? lam7 * zw[k] : 0.0);
+                apply_cel(m, lv, u);
+                // dn_k/dc_j = (dAs_jk / phi - gt_k q_j / (2 phi^2)) / w_k ; u . (dAs_j o 1/w) in closed form:
+                const double uw[6] = {u[0], u[1] * 0.5, u[2] * 0.5, u[3], u[4] * 0.5, u[5]};
+                const double uAs[6] = {(uw[3] - uw[5]) * d12, (uw[5] - uw[0]) * d20, (uw[0] - uw[3]) * d01,
+                                       2.0 * uw[4] * s[4], 2.0 * uw[2] * s[2], 2.0 * uw[1] * s[1]};
+                double ugw = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ugw += uw[k] * ev.gt[k];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double udn = uAs[j] * ip - ugw * qj[j] * 0.5 * ip * ip;
+                    pbar[CM_P_YC0 + j] = -(ev.dgam * udn * i2mu + lam6 * qj[j] * 0.5 * ip * i2mu);
+                }
+            }
+        }
+    }
+    if (xpbar) {
+        double lcn = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { xpbar[k] = lam[k] * i2mu; lcn += lam[k] * cn[k]; }
+        double zcn = 0.0;
+        if constexpr (PS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) zcn += zw[k] * cn[k];
+        }
+        xpbar[6] = ev.plastic ? (lcn * i2mu - (PS ? lam7 * zcn * i2mu : 0.0)) : lam[6];
+        if constexpr (PS) {
+            double cz[6], lcz = 0.0, zcz = 0.0;
+            apply_cel(m, z, cz);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { lcz += lam[k] * cz[k]; zcz += zw[k] * cz[k]; }
+            xpbar[7] = -(lcz * i2mu - lam7 * zcz * i2mu);
+        }
+    }
+    if (degbar) {
+        double lv[6], cl[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lv[k] = lam[k] - (PS ? lam7 * zw[k] : 0.0);
+        apply_cel(m, lv, cl);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) degbar[k] = cl[k] * i2mu;
+    }
+    return ok;
+}
+
 // ---- forward tangent of the rate-form model at a converged state ------------------------------------------------
 // T[r][l] = d s_r / d (d eg)_l : the unknown x[0:6] IS the material stress, so T is the first six rows of
 // dx / d deg = -A^-1 dC/d deg with dC_k/d deg_l = -Cel_kl / 2mu (both branches) and, under PLANE_STRESS,

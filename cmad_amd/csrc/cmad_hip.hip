@@ -441,6 +441,100 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     block_reduce_store<kRed>(red, partials, lds_buf);
 }
 
+// ---- reverse-mode kernels of the rate-form model (same MODEs as k_reverse; dense LU path) ----------------------
+// grad u enters through deg = strain(grad u - grad u_prev): the cotangent written to gbar_out is the one of grad u,
+// the one of grad u_prev is its negative.
+template <int DEF, int YK, bool ROT, bool LS, int MODE>
+__global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
+        const double* __restrict__ xi_in, const double* __restrict__ sbar_or_data, Wsq wsq,
+        const double* __restrict__ hist_in, double* __restrict__ xi_out, double* __restrict__ sigma_out,
+        double* __restrict__ xpbar_out, double* __restrict__ gbar_out, double* __restrict__ partials) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
+    gradu += blk0; gradu_prev += blk0; xi_prev += blk0; sbar_or_data += blk0;
+    if (xi_in) xi_in += blk0;
+    if (hist_in) hist_in += blk0;
+    if (xi_out) xi_out += blk0;
+    if (sigma_out) sigma_out += blk0;
+    if (xpbar_out) xpbar_out += blk0;
+    if (gbar_out) gbar_out += blk0;
+    __shared__ double lds_buf[kRed * kRedStride];
+    double G[NU], Gp[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], sd[6];
+    load_soa<NU>(gradu, B, b, G);
+    load_soa<NU>(gradu_prev, B, b, Gp);
+    load_soa<NX>(xi_prev, B, b, xp);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) G[k] -= Gp[k];
+    strain_from_gradu<DEF, ROT>(m, G, deg);
+    strain_z<DEF, ROT>(m, z);
+    if constexpr (MODE == 1 || MODE == 3) {
+        newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
+        if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
+    } else {
+        load_soa<NX>(xi_in, B, b, x);
+    }
+    load_soa<6>(sbar_or_data, B, b, sd);
+    double sg[6];
+    to_global<ROT>(m, x, sg);                                    // sigma_global = Q x[0:6] Q^T
+    if constexpr (MODE == 3) {
+        if (sigma_out && valid) store_soa<6>(sigma_out, B, b, sg);
+    }
+    double red[kRed], sb[6];
+    red[0] = 0.0;
+    if constexpr (MODE == 0 || MODE == 3) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sb[k] = sd[k];
+    } else {
+        double J = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double mm = sg[k] - sd[k];
+            sb[k] = wsq.w[k] * mm;
+            J += 0.5 * sb[k] * mm;
+        }
+        red[0] = J;
+    }
+    double sbm[6], xin[NX], xpbar[NX], degbar[6];
+    cotangent_to_material<ROT>(m, sb, sbm);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) xin[k] = 0.0;
+    if constexpr (MODE == 2) {
+        if (hist_in) {
+            load_soa<NX>(hist_in, B, b, xin);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xin[k] = -xin[k];       // history vector = -(cotangent of xi)
+        }
+    }
+    constexpr bool BARS = (MODE == 0 || MODE == 2);
+    reverse_point_rate<DEF, YK>(m, deg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
+                                BARS ? degbar : nullptr);
+    if (BARS && xpbar_out && valid) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xpbar[k] = -xpbar[k];
+        }
+        store_soa<NX>(xpbar_out, B, b, xpbar);
+    }
+    if (BARS && gbar_out) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            double Gd[NU], dm[6];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+            strain_from_gradu<DEF, ROT>(m, Gd, dm);
+            if (valid) (gbar_out + (int64_t)c * B)[b] = dot<6>(degbar, dm);
+        }
+    }
+    if (!valid) {
+#pragma unroll
+        for (int k = 0; k < kRed; ++k) red[k] = 0.0;
+    }
+    block_reduce_store<kRed>(red, partials, lds_buf);
+}
+
 // ---- cm_evaluate: residual / Jacobian block / stress / stress-derivative block at given states ----------
 template <int DEF, int YK, bool ROT>
 __global__ __launch_bounds__(64) void k_evaluate(cm_model_desc m, int64_t B, int which,
@@ -637,6 +731,39 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
             }
             hipLaunchKernelGGL((k_reverse<D, Y, R, (MODE == 1 || MODE == 3) ? LS : false, MODE>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                hist_in, xi_out, sigma_out, xpbar, gbar, partials);
+        });
+        if (!found) return CM_ERR_UNSUPPORTED;
+        if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
+    }
+    double* stage = partials + nb * kRed;
+    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
+    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, accumulate);
+    return check_launch();
+}
+
+template <int MODE>
+int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                        const double* xi_prev, const double* xi_in, const double* sd, const double* wsq6,
+                        const double* hist_in, double* xi_out, double* sigma_out, double* xpbar, double* gbar,
+                        double* out, int out_offset, int accumulate, void* workspace, int64_t wbytes, void* stream) {
+    if (!m || B < 0 || !out || !workspace) return CM_ERR_BAD_ARG;
+    if (B > 0 && (!gradu || !gradu_prev || !xi_prev || !sd)) return CM_ERR_BAD_ARG;
+    if (B > 0 && (MODE == 0 || MODE == 2) && !xi_in) return CM_ERR_BAD_ARG;
+    if ((MODE == 1 || MODE == 2) && !wsq6) return CM_ERR_BAD_ARG;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = (double*)workspace;
+    const int64_t nb = nblocks_of(B);
+    Wsq w; for (int k = 0; k < 6; ++k) w.w[k] = wsq6 ? wsq6[k] : 0.0;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    if (B > 0) {
+        const dim3 grid((unsigned)nb), block(kBlock);
+        const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (!is_dense_yield(Y))
+                hipLaunchKernelGGL((k_reverse_rate<D, Y, R, (MODE == 1 || MODE == 3) ? LS : false, MODE>), grid, block, 0, s, md, B,
+                                   gradu, gradu_prev, xi_prev, xi_in, sd, w, hist_in, xi_out, sigma_out, xpbar, gbar, partials);
         });
         if (!found) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
@@ -865,6 +992,43 @@ int cm_adjoint_step(const cm_model_desc* m, int64_t B, const double* gradu, cons
     if (!hist_out) return CM_ERR_BAD_ARG;
     return launch_reverse<2>(m, B, gradu, xi_prev, xi, data, wsq6, hist_in, nullptr, nullptr, hist_out, nullptr,
                              out, 0, accumulate, workspace, workspace_bytes, stream);
+}
+#endif
+
+#if CM_HAS_PART(1)
+int cm_update_rate_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                       const double* xi_prev, const double* xi, const double* sigma_bar,
+                       double* grad_p, double* xi_prev_bar, double* gradu_bar,
+                       void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!grad_p) return CM_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    return launch_reverse_rate<0>(m, B, gradu, gradu_prev, xi_prev, xi, sigma_bar, nullptr, nullptr, nullptr, nullptr,
+                                  xi_prev_bar, gradu_bar, grad_p, 1, 0, workspace, workspace_bytes, stream);
+}
+int cm_adjoint_step_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                         const double* xi_prev, const double* xi, const double* data, const double* wsq6,
+                         const double* hist_in, double* hist_out, double* out, int accumulate,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!hist_out) return CM_ERR_BAD_ARG;
+    return launch_reverse_rate<2>(m, B, gradu, gradu_prev, xi_prev, xi, data, wsq6, hist_in, nullptr, nullptr, hist_out,
+                                  nullptr, out, 0, accumulate, workspace, workspace_bytes, stream);
+}
+#endif
+
+#if CM_HAS_PART(2)
+int cm_update_rate_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                           const double* xi_prev, const double* sigma_bar, double* xi, double* sigma, double* grad_p,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!grad_p || (B > 0 && !xi)) return CM_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    return launch_reverse_rate<3>(m, B, gradu, gradu_prev, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr,
+                                  nullptr, grad_p, 1, 0, workspace, workspace_bytes, stream);
+}
+int cm_objective_grad_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
+                           const double* xi_prev, const double* data, const double* wsq6, double* out, double* xi,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    return launch_reverse_rate<1>(m, B, gradu, gradu_prev, xi_prev, nullptr, data, wsq6, nullptr, xi, nullptr, nullptr,
+                                  nullptr, out, 0, 0, workspace, workspace_bytes, stream);
 }
 #endif
 

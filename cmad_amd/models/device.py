@@ -313,7 +313,19 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_update_rate")
         return xi, sigma, status
 
-    def update_vjp(self, gradu, xi_prev, xi, sigma_bar, want_xi_prev_bar=False, want_gradu_bar=False):
+    def _rate_prev(self, gradu_prev, B):
+        """The rate-form model (desc.model_kind = 1) takes the previous grad u in every entry point."""
+        if self.desc.model_kind != 1:
+            if gradu_prev is not None:
+                raise ValueError("gradu_prev only applies to the rate-form model")
+            return None
+        if gradu_prev is None:
+            raise ValueError("the rate-form model needs gradu_prev")
+        _check_soa(gradu_prev, self.nu, B, "gradu_prev")
+        return gradu_prev
+
+    def update_vjp(self, gradu, xi_prev, xi, sigma_bar, want_xi_prev_bar=False, want_gradu_bar=False, gradu_prev=None):
+        """gradu_prev: rate-form model only (the returned gradu cotangent's negative is the one of gradu_prev)."""
         torch = _torch()
         B = gradu.shape[1]
         _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
@@ -323,12 +335,18 @@ class DeviceEvaluator:
         xb = torch.empty((self.nx, B), dtype=torch.float64, device=dev) if want_xi_prev_bar else None
         ub = torch.empty((self.nu, B), dtype=torch.float64, device=dev) if want_gradu_bar else None
         ws, need = self._workspace(B, dev)
+        gp = self._rate_prev(gradu_prev, B)
+        if gp is not None:
+            rc = self.L.cm_update_rate_vjp(C.byref(self.desc), B, _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(xi),
+                                           _ptr(sigma_bar), _ptr(g), _ptr(xb), _ptr(ub), _ptr(ws), need, self._stream())
+            _lib.check(rc, "cm_update_rate_vjp")
+            return g, xb, ub
         rc = self.L.cm_update_vjp(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma_bar),
                                   _ptr(g), _ptr(xb), _ptr(ub), _ptr(ws), need, self._stream())
         _lib.check(rc, "cm_update_vjp")
         return g, xb, ub
 
-    def update_and_vjp(self, gradu, xi_prev, sigma_bar, want_sigma=True, out=None):
+    def update_and_vjp(self, gradu, xi_prev, sigma_bar, want_sigma=True, out=None, gradu_prev=None):
         """Fused cm_update + cm_update_vjp; returns xi, sigma, grad_kp (device, KP order)."""
         torch = _torch()
         B = gradu.shape[1]
@@ -341,12 +359,18 @@ class DeviceEvaluator:
                  torch.empty((6, B), dtype=torch.float64, device=dev)) if want_sigma else None
         g = o.get("grad") if o.get("grad") is not None else torch.empty(_lib.CM_NUM_PARAMS, dtype=torch.float64, device=dev)
         ws, need = self._workspace(B, dev)
+        gp = self._rate_prev(gradu_prev, B)
+        if gp is not None:
+            rc = self.L.cm_update_rate_and_vjp(C.byref(self.desc), B, _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(sigma_bar),
+                                               _ptr(xi), _ptr(sigma), _ptr(g), _ptr(ws), need, self._stream())
+            _lib.check(rc, "cm_update_rate_and_vjp")
+            return xi, sigma, g
         rc = self.L.cm_update_and_vjp(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(sigma_bar), _ptr(xi),
                                       _ptr(sigma), _ptr(g), _ptr(ws), need, self._stream())
         _lib.check(rc, "cm_update_and_vjp")
         return xi, sigma, g
 
-    def objective_grad(self, gradu, xi_prev, data6, wsq6, want_xi=False, out=None):
+    def objective_grad(self, gradu, xi_prev, data6, wsq6, want_xi=False, out=None, gradu_prev=None):
         torch = _torch()
         B = gradu.shape[1]
         _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
@@ -356,17 +380,30 @@ class DeviceEvaluator:
         xi = torch.empty((self.nx, B), dtype=torch.float64, device=dev) if want_xi else None
         w = (C.c_double * 6)(*[float(v) for v in wsq6])
         ws, need = self._workspace(B, dev)
+        gp = self._rate_prev(gradu_prev, B)
+        if gp is not None:
+            rc = self.L.cm_objective_grad_rate(C.byref(self.desc), B, _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(data6), w,
+                                               _ptr(res), _ptr(xi), _ptr(ws), need, self._stream())
+            _lib.check(rc, "cm_objective_grad_rate")
+            return res, xi
         rc = self.L.cm_objective_grad(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(data6), w,
                                       _ptr(res), _ptr(xi), _ptr(ws), need, self._stream())
         _lib.check(rc, "cm_objective_grad")
         return res, xi
 
-    def adjoint_step(self, gradu, xi_prev, xi, data6, wsq6, hist_in, hist_out, out, accumulate=True):
+    def adjoint_step(self, gradu, xi_prev, xi, data6, wsq6, hist_in, hist_out, out, accumulate=True, gradu_prev=None):
         B = gradu.shape[1]
         _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")
         _check_soa(xi, self.nx, B, "xi"); _check_soa(data6, 6, B, "data"); _check_soa(hist_out, self.nx, B, "hist_out")
         w = (C.c_double * 6)(*[float(v) for v in wsq6])
         ws, need = self._workspace(B, gradu.device)
+        gp = self._rate_prev(gradu_prev, B)
+        if gp is not None:
+            rc = self.L.cm_adjoint_step_rate(C.byref(self.desc), B, _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(xi), _ptr(data6), w,
+                                             _ptr(hist_in), _ptr(hist_out), _ptr(out), int(bool(accumulate)),
+                                             _ptr(ws), need, self._stream())
+            _lib.check(rc, "cm_adjoint_step_rate")
+            return hist_out, out
         rc = self.L.cm_adjoint_step(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(data6), w,
                                     _ptr(hist_in), _ptr(hist_out), _ptr(out), int(bool(accumulate)),
                                     _ptr(ws), need, self._stream())

@@ -74,17 +74,22 @@ class BatchedCalibrationObjective:
         ev = model.device_evaluator(self._newton)
         g, d, K = self._g, self._d, self._K
         out = self._out
+        rate = getattr(model, "_model_kind", 0) == 1          # the rate form also takes the previous step's grad u
+        prev = (lambda k: {"gradu_prev": g[k - 1]}) if rate else (lambda k: {})
         if K == 1:
-            ev.objective_grad(g[1], self._xi0, d[1], self._wsq6, out=out)
+            ev.objective_grad(g[1], self._xi0, d[1], self._wsq6, out=out, **prev(1))
         else:
             xs = [self._xi0]
             for k in range(1, K + 1):
-                x, _, _ = ev.update(g[k], xs[-1], want_sigma=False, want_status=False)
+                if rate:
+                    x, _, _ = ev.update_rate(g[k], g[k - 1], xs[-1], want_sigma=False, want_status=False)
+                else:
+                    x, _, _ = ev.update(g[k], xs[-1], want_sigma=False, want_status=False)
                 xs.append(x)
             out.zero_()
             hist = torch.zeros_like(self._xi0)
             for k in range(K, 0, -1):
-                ev.adjoint_step(g[k], xs[k - 1], xs[k], d[k], self._wsq6, hist, hist, out, accumulate=True)
+                ev.adjoint_step(g[k], xs[k - 1], xs[k], d[k], self._wsq6, hist, hist, out, accumulate=True, **prev(k))
         allreduce_sum_(out, self._group)
         res = out.cpu().numpy()
         grad = model.active_grad_from_kp(res[1:], ev.info)

@@ -134,9 +134,9 @@ int cm_update(const cm_model_desc* m, int64_t B,
  * (cmad/models/small_rate_elastic_plastic.py:249-346) followed by its _cauchy_fn (:351-359).
  *   in : gradu[n_gradu][B], gradu_prev[n_gradu][B], xi_prev[n_xi][B] (xi = [sigma(6), alpha (, F33)])
  *   out: xi[n_xi][B], sigma[6][B] (global axes, may be NULL), status[B] (may be NULL)
- * The reverse-mode batched entry points (cm_update_vjp / cm_objective_grad / cm_adjoint_step) exist for the total
- * form only and return CM_ERR_UNSUPPORTED for this model; cm_update_rate_tangent, cm_evaluate_rate and
- * cm_hessians_rate give its forward tangent and derivative blocks.
+ * The total-form entry points return CM_ERR_UNSUPPORTED for this model; its own are cm_update_rate_tangent,
+ * cm_update_rate_vjp, cm_update_rate_and_vjp, cm_objective_grad_rate, cm_adjoint_step_rate, cm_evaluate_rate and
+ * cm_hessians_rate below.
  */
 int cm_update_rate(const cm_model_desc* m, int64_t B,
                    const double* gradu, const double* gradu_prev, const double* xi_prev,
@@ -251,6 +251,32 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which,
 int cm_hessians(const cm_model_desc* m, int64_t B,
                 const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream);
+
+/*
+ * Reverse-mode entry points of the rate-form model (FULL_3D, PLANE_STRESS; J2 / Hill / Hosford): cm_update_vjp,
+ * cm_update_and_vjp, cm_objective_grad and cm_adjoint_step with the additional input gradu_prev[n_gradu][B].
+ * Same outputs and conventions; gradu_bar is the cotangent of grad u, the one of grad u_prev is its negative
+ * (the residual sees grad u - grad u_prev only).  They replace the same reference lines as their total-form
+ * counterparts, applied to SmallRateElasticPlastic (small_rate_elastic_plastic.py:249-359), e.g. the adjoint pass
+ * of tests/objectives/test_calibrations.py:86-109.
+ */
+int cm_update_rate_vjp(const cm_model_desc* m, int64_t B,
+                       const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
+                       const double* sigma_bar, double* grad_p, double* xi_prev_bar, double* gradu_bar,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+int cm_update_rate_and_vjp(const cm_model_desc* m, int64_t B,
+                           const double* gradu, const double* gradu_prev, const double* xi_prev, const double* sigma_bar,
+                           double* xi, double* sigma, double* grad_p,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int cm_objective_grad_rate(const cm_model_desc* m, int64_t B,
+                           const double* gradu, const double* gradu_prev, const double* xi_prev,
+                           const double* data, const double* wsq6, double* out, double* xi,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int cm_adjoint_step_rate(const cm_model_desc* m, int64_t B,
+                         const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
+                         const double* data, const double* wsq6, const double* hist_in,
+                         double* hist_out, double* out, int accumulate,
+                         void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * cm_hessians_rate: cm_hessians for the rate-form model (small_rate_elastic_plastic.py:249-359), whose residual

@@ -67,6 +67,18 @@ def vjp(desc, gradu, xi_prev, xi, sbar, xin=None):
     return g, xb, ub
 
 
+def vjp_rate(desc, gradu, gradu_prev, xi_prev, xi, sbar, xin=None):
+    L = lib()
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    gradu, gradu_prev, xi_prev, xi, sbar, xin = c(gradu), c(gradu_prev), c(xi_prev), c(xi), c(sbar), c(xin)
+    B = gradu.shape[1]
+    g = np.zeros(12); xb = np.zeros_like(xi); ub = np.zeros_like(gradu)
+    rc = L.hh_vjp_rate(C.byref(desc), C.c_int64(B), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi), _p(sbar), _p(xin),
+                       _p(g), _p(xb), _p(ub))
+    assert rc == 0
+    return g, xb, ub
+
+
 def evaluate(desc, which, gradu, xi_prev, xi, nx):
     """Explicit blocks at given states: C (nx,B), J (nx,ncols,B), sigma6 (6,B), S (6,ncols,B)."""
     L = lib()

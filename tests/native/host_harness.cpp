@@ -87,6 +87,33 @@ static void run_vjp(const cm_model_desc& m, int64_t B, const double* gradu, cons
 }
 
 template <int DEF, int YK, bool ROT>
+static void run_vjp_rate(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
+                         const double* xi, const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] = 0.0;
+    if constexpr (!is_dense_yield(YK)) {
+        for (int64_t b = 0; b < B; ++b) {
+            double G[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], sb[6], sbm[6], pb[CM_NUM_PARAMS], xb[NX], eb[6], xi_in[NX];
+            for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
+            for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; if (xin) xi_in[k] = xin[k * B + b]; }
+            for (int k = 0; k < 6; ++k) sb[k] = sbar[k * B + b];
+            strain_from_gradu<DEF, ROT>(m, G, deg);
+            strain_z<DEF, ROT>(m, z);
+            cotangent_to_material<ROT>(m, sb, sbm);
+            reverse_point_rate<DEF, YK>(m, deg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+            for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
+            if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
+            if (gbar) for (int c = 0; c < NU; ++c) {
+                double Gd[NU], dm[6];
+                for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+                strain_from_gradu<DEF, ROT>(m, Gd, dm);
+                gbar[c * B + b] = dot<6>(eb, dm);
+            }
+        }
+    }
+}
+
+template <int DEF, int YK, bool ROT>
 static void run_evaluate(const cm_model_desc& m, int64_t B, int which, const double* gradu, const double* xi_prev,
                          const double* xi, double* C_out, double* J_out, double* s_out, double* S_out) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
@@ -235,6 +262,10 @@ int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double*
 int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
+}
+int hh_vjp_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
+                const double* xi, const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
+    return dispatch(m, [&]<int D, int Y, bool R>() { run_vjp_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
 }
 int hh_tangent_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
                     const double* xi_prev, const double* xi, double* dsig) {

@@ -297,6 +297,32 @@ def check_rate_tangent(tangent_rate, def_type, yield_kind, kw, rot, B=512, seed=
     np.testing.assert_allclose(ds_d, ds_o, rtol=1e-9, atol=1e-10 * np.abs(ds_o).max())
 
 
+def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
+    """Reverse sweep of the rate form at converged states vs the oracle (transpose of the custom_jvp rule with the
+    previous grad u): parameter gradient, xi_prev cotangent, grad u cotangent.
+    `vjp_rate(desc, info, gradu, gradu_prev, xi_prev, xi, sbar) -> (grad_kp, xi_prev_bar, gradu_bar)`."""
+    from cmad_amd.models.device import build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+    rng = np.random.default_rng(seed)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+    nd = 3 if def_type == ol.FULL_3D else 2
+    st_o, st_d = settings_pair(False)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d)
+    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
+    xp = np.tile(mat.init_xi()[:, None], (1, B))
+    x1, _, _, cv1 = mat.update_batch(st_o, 0.9 * g0, xp, gradu_prev=np.zeros_like(g0))
+    x2, _, it2, cv2 = mat.update_batch(st_o, 1.5 * g0, x1, gradu_prev=0.9 * g0)
+    assert cv1.all() and cv2.all() and (it2 > 0).mean() > 0.2
+    sbar = np.random.default_rng(5).normal(size=(6, B))
+    g_o, xb_o, ub_o = mat.update_vjp_batch(1.5 * g0, x1, x2, sbar, gradu_prev=0.9 * g0)
+    g_d, xb_d, ub_d = vjp_rate(desc, info, 1.5 * g0, 0.9 * g0, x1, x2, sbar)
+    np.testing.assert_allclose(xb_d, xb_o, rtol=1e-9, atol=1e-9 * np.abs(xb_o).max())
+    np.testing.assert_allclose(ub_d, ub_o, rtol=1e-9, atol=1e-9 * np.abs(ub_o).max())
+    got, ref = leaf_grads(g_d, info, mat, yield_kind, g_o)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+
+
 def check_j2_radial_line(backend, B=4096, rot=False):
     """J2 / FULL_3D (plain Newton, and the traced Newton whose full steps pass the Armijo test): the default kernels
     restrict the iteration to the radial line it never leaves;

@@ -382,6 +382,45 @@ def test_rate_model_calibration_recovers_truth():
     assert np.linalg.norm(model.parameters.flat_active_values() - true_params) < 1e-6
 
 
+@pytest.mark.parametrize("def_type_name", ["FULL_3D", "PLANE_STRESS"])
+def test_rate_model_batched_objective_matches_pointwise(def_type_name):
+    """BatchedCalibrationObjective on SmallRateElasticPlastic (cm_update_rate + cm_adjoint_step_rate) == the sum of
+    the reference-style pointwise adjoint objectives, per-point data, canonical gradient."""
+    import torch
+    from cmad_amd.models import DefType, SmallRateElasticPlastic
+    from cmad_amd.objectives import BatchedCalibrationObjective, MPAdjointObjective
+    from cmad_amd.qois import Calibration
+    def_type = getattr(DefType, def_type_name)
+    if def_type == DefType.PLANE_STRESS:
+        F = plane_stress_F(0.02, 4)
+    else:
+        Fp = plane_stress_F(0.02, 4)
+        F = np.tile(np.eye(3)[:, :, None], (1, 1, Fp.shape[2]))
+        F[:2, :2, :] = Fp
+        F[2, 2, :] = 1. - 0.4 * (Fp[0, 0, :] - 1.)
+    nd = F.shape[0]
+    K = F.shape[2] - 1
+    model = SmallRateElasticPlastic(params_J2_voce(), def_type)
+    cauchy = _compute_cauchy(model, F)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.; weight[0, 1] = weight[1, 0] = 0.5
+    rng = np.random.default_rng(23)
+    B = 3
+    datas = [cauchy + rng.normal(0., 5., cauchy.shape) for _ in range(B)]
+    datas = [0.5 * (d + d.transpose(1, 0, 2)) for d in datas]
+    model.parameters.set_active_values_from_flat(1.05 * model.parameters.flat_active_values(False), False)
+    x = model.parameters.flat_active_values(True)
+    J_ref, g_ref = 0., 0.
+    for d in datas:
+        r = MPAdjointObjective(Calibration(model, d, weight), F).evaluate(x)
+        J_ref += r.J; g_ref = g_ref + r.grad
+    gh = torch.from_numpy(np.stack([np.tile((F[:, :, k] - np.eye(nd)).reshape(nd * nd, 1), (1, B)) for k in range(K + 1)])).cuda()
+    V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    dh = torch.from_numpy(np.stack([np.stack([[d[i, j, k] for d in datas] for i, j in V6]) for k in range(K + 1)])).cuda()
+    r = BatchedCalibrationObjective(model, gh.contiguous(), dh.contiguous(), weight).evaluate(x)
+    np.testing.assert_allclose(r.J, J_ref, rtol=1e-11)
+    np.testing.assert_allclose(r.grad, g_ref, rtol=1e-8, atol=1e-10 * np.abs(g_ref).max())
+
+
 def _hessian_problem(active_elastic=False, K=10, rate=False):
     from cmad_amd.models import DefType, SmallElasticPlastic, SmallRateElasticPlastic
     from cmad_amd.qois import Calibration

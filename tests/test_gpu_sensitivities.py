@@ -112,3 +112,92 @@ def test_rate_form_tangent(def_type, yield_kind, kw, rot):
         np.testing.assert_allclose(xi.cpu().numpy()[:6], x_expected[:6], rtol=1e-10, atol=1e-7)
         return ds.cpu().numpy()
     pc.check_rate_tangent(run, def_type, yield_kind, kw, rot, B=1024)
+
+
+def _rate_case(def_type, yield_kind, kw, rot, B, seed=22):
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+    rng = np.random.default_rng(seed)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng) if rot else None, **kw)
+    st_o, st_d = pc.settings_pair(False)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d)
+    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=3 if def_type == ol.FULL_3D else 2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return mat, st_o, DeviceEvaluator(desc, info), info, g0, t
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_form_vjp_and_fused(def_type, yield_kind, kw, rot):
+    """cm_update_rate_vjp vs the oracle's reverse sweep; cm_update_rate_and_vjp gives the same numbers from
+    xi_prev alone (cmad/models/small_rate_elastic_plastic.py under cmad/objectives/mp_objective.py:95-147)."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator
+    seen = {}
+
+    def run(desc, info, g, gp, xp, x, sbar):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        ev = DeviceEvaluator(desc, info)
+        gk, xb, ub = ev.update_vjp(t(g), t(xp), t(x), t(sbar), want_xi_prev_bar=True, want_gradu_bar=True, gradu_prev=t(gp))
+        xi_f, sig_f, g_f = ev.update_and_vjp(t(g), t(xp), t(sbar), gradu_prev=t(gp))
+        np.testing.assert_allclose(xi_f.cpu().numpy()[:6], x[:6], rtol=1e-10, atol=1e-7)
+        np.testing.assert_allclose(xi_f.cpu().numpy()[6:], x[6:], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(sig_f.cpu().numpy(), x[:6], rtol=1e-10, atol=1e-7)       # sigma IS the state
+        seen["fused"], seen["split"] = g_f.cpu().numpy(), gk.cpu().numpy()
+        return gk.cpu().numpy(), xb.cpu().numpy(), ub.cpu().numpy()
+    pc.check_rate_vjp(run, def_type, yield_kind, kw, rot, B=1000)
+    np.testing.assert_allclose(seen["fused"], seen["split"], rtol=1e-8, atol=1e-11 * np.abs(seen["split"]).max())
+
+
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_form_adjoint_history(def_type, yield_kind, kw):
+    """K-step calibration history of the rate form: cm_update_rate forward + cm_adjoint_step_rate backward, and
+    the single-step fused cm_objective_grad_rate, vs the oracle's adjoint (previous grad u = the history's
+    previous step)."""
+    import torch
+    from cmad_amd.models.device import fold_weight_and_data
+    K, B = 4, 600
+    mat, st_o, ev, info, g0, t = _rate_case(def_type, yield_kind, kw, True, B)
+    gh = np.stack([k * 0.5 * g0 for k in range(K + 1)])
+    xi0 = np.tile(mat.init_xi()[:, None], (1, B))
+    xs, plastic = [xi0], 0.0
+    for k in range(1, K + 1):
+        x, s, it, cv = mat.update_batch(st_o, gh[k], xs[-1], gradu_prev=gh[k - 1])
+        assert cv.all()
+        plastic = max(plastic, (it > 0).mean())
+        xs.append(x)
+    assert plastic > 0.2
+    rng = np.random.default_rng(11)
+    data6 = [x[:6] + rng.normal(0., 5., size=(6, B)) for x in xs]
+    dh = np.stack([d[IDX9, :] for d in data6])
+    w = np.zeros((3, 3)); w[0, 0] = 1.; w[1, 1] = 1.; w[0, 1] = 0.5; w[1, 0] = 0.5; w[2, 2] = 0.25
+    if def_type == ol.PLANE_STRESS:
+        w[2, 2] = 0.
+    J_o, g_o, _, xk = mat.objective_grad_batch(st_o, gh, dh, w, xi0)
+    wsq6 = fold_weight_and_data(w)
+    xd = [t(xi0)]
+    for k in range(1, K + 1):
+        x, _, _ = ev.update_rate(t(gh[k]), t(gh[k - 1]), xd[-1], want_sigma=False, want_status=False)
+        xd.append(x)
+    np.testing.assert_allclose(xd[-1].cpu().numpy()[:6], xk[:6], rtol=1e-10, atol=1e-7)
+    out = torch.zeros(13, dtype=torch.float64, device="cuda")
+    hist = torch.zeros((mat.nx, B), dtype=torch.float64, device="cuda")
+    for k in range(K, 0, -1):
+        ev.adjoint_step(t(gh[k]), xd[k - 1], xd[k], t(data6[k]), wsq6, hist, hist, out, accumulate=True,
+                        gradu_prev=t(gh[k - 1]))
+    res = out.cpu().numpy()
+    np.testing.assert_allclose(res[0], J_o, rtol=1e-10)
+    got, ref = pc.leaf_grads(res[1:], info, mat, yield_kind, g_o)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-11 * np.abs(ref).max())
+    # single step, fused (state enters only through xi_prev and the two grad u)
+    J1, g1, _, x1 = mat.objective_grad_batch(st_o, gh[2:4], dh[2:4], w, xs[2])
+    res1, xi1 = ev.objective_grad(t(gh[3]), xd[2], t(data6[3]), wsq6, want_xi=True, gradu_prev=t(gh[2]))
+    res1 = res1.cpu().numpy()
+    np.testing.assert_allclose(xi1.cpu().numpy()[:6], x1[:6], rtol=1e-10, atol=1e-7)
+    np.testing.assert_allclose(res1[0], J1, rtol=1e-9)
+    got, ref = pc.leaf_grads(res1[1:], info, mat, yield_kind, g1)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-11 * np.abs(ref).max())

@@ -387,3 +387,13 @@ def test_rate_form_tangent(def_type, yield_kind, kw, rot, solver_variant):
     if solver_variant == "dense":
         pytest.skip("rate form always uses the dense path")
     pc.check_rate_tangent(lambda desc, info, g, gp, xp, x: hh.tangent_rate(desc, g, gp, xp, x), def_type, yield_kind, kw, rot, B=192)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_form_vjp(def_type, yield_kind, kw, rot, solver_variant):
+    import host_harness_lib as hh
+    if solver_variant == "dense":
+        pytest.skip("rate form always uses the dense path")
+    pc.check_rate_vjp(lambda desc, info, g, gp, xp, x, sb: hh.vjp_rate(desc, g, gp, xp, x, sb), def_type, yield_kind, kw, rot, B=192)
