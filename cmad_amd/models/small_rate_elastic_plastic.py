@@ -8,8 +8,10 @@ evaluate surface (`cm_evaluate_rate`: residual, every Jacobian block including d
 the material-point objectives run on it unchanged; second derivatives through `cm_hessians_rate`.
 UNIAXIAL_STRESS (12 local dofs, :171-196) is served by `cm_hessians_rate` alone -- residual, stress, first and
 second derivatives by dual-number evaluation -- with the Newton loop of `newton_solve` on the host.
-The batched forward tangent is `cm_update_rate_tangent` (`DeviceEvaluator.update_rate(tangent=True)`); batched
-reverse kernels of the rate form are not built."""
+The batched forward tangent is `cm_update_rate_tangent` (`DeviceEvaluator.update_rate(tangent=True)`); the batched
+reverse sweep is `cm_update_rate_vjp` / `cm_update_rate_and_vjp` / `cm_objective_grad_rate` /
+`cm_adjoint_step_rate` (the `gradu_prev=` keyword of the `DeviceEvaluator` methods), which is what
+`BatchedCalibrationObjective` runs on this model."""
 from __future__ import annotations
 
 from typing import ClassVar

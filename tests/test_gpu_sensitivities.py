@@ -145,7 +145,8 @@ def test_rate_form_vjp_and_fused(def_type, yield_kind, kw, rot):
         xi_f, sig_f, g_f = ev.update_and_vjp(t(g), t(xp), t(sbar), gradu_prev=t(gp))
         np.testing.assert_allclose(xi_f.cpu().numpy()[:6], x[:6], rtol=1e-10, atol=1e-7)
         np.testing.assert_allclose(xi_f.cpu().numpy()[6:], x[6:], rtol=1e-10, atol=1e-12)
-        np.testing.assert_allclose(sig_f.cpu().numpy(), x[:6], rtol=1e-10, atol=1e-7)       # sigma IS the state
+        _, sig_u, _ = ev.update_rate(t(g), t(gp), t(xp))
+        np.testing.assert_allclose(sig_f.cpu().numpy(), sig_u.cpu().numpy(), rtol=1e-12, atol=1e-9)
         seen["fused"], seen["split"] = g_f.cpu().numpy(), gk.cpu().numpy()
         return gk.cpu().numpy(), xb.cpu().numpy(), ub.cpu().numpy()
     pc.check_rate_vjp(run, def_type, yield_kind, kw, rot, B=1000)
