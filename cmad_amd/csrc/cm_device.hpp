@@ -1171,7 +1171,6 @@ template <int DEF, int YK>
 CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double z[6],
                         const double* x, const double* xp, const double sbm[6], const double* xin,
                         double* pbar, double* xpbar, double* egbar) {
-    static_assert(DEF != CM_UNIAXIAL_STRESS, "batched reverse sweep not built for UNIAXIAL_STRESS (use cm_evaluate blocks)");
     constexpr int NX = Dims<DEF>::NX;
     Eval<DEF> ev;
     double C[NX], Ht[6][6], At[NX][NX], lam[NX];
@@ -1180,8 +1179,16 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
     const bool ok = lu_factor<NX>(At);
     double csb[6];
     apply_cel(m, sbm, csb);                                  // Cel sbar_m (Cel symmetric)
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        // d s / d v = -Cel Pi (Pi[:, l] = w_l sum_i Z^i Z^i_l), d s / d x7 = Cel Z^a, d s / d x8 = Cel Z^b
+        const double zc[3] = {dot<6>(z, csb), dot<6>(z + 6, csb), dot<6>(z + 12, csb)};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) lam[k] = -csb[k];            // d s / d v = -Cel
+        for (int l = 0; l < 6; ++l) lam[l] = -kW[l] * (z[l] * zc[0] + z[6 + l] * zc[1] + z[12 + l] * zc[2]);
+        lam[7] = zc[1]; lam[8] = zc[2];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lam[k] = -csb[k];        // d s / d v = -Cel
+    }
     lam[6] = 0.0;
     if constexpr (DEF == CM_PLANE_STRESS) lam[7] = dot<6>(z, csb);   // d s / d F33 = Cel z
     if (xin) {
@@ -1216,6 +1223,18 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
             for (int k = 0; k < 6; ++k) zwe += kW[k] * z[k] * ev.e[k];
             cl += lam[7] * zt * ev.tr * i2mu;
             cm_ += lam[7] * (2.0 * zwe * i2mu - C[7] / m.mu);
+        }
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                    // the two off-axis normal-stress rows
+                const double* Z = z + 6 * (1 + j);
+                const double zt = Z[0] + Z[3] + Z[5];
+                double zwe = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) zwe += kW[k] * Z[k] * ev.e[k];
+                cl += lam[7 + j] * zt * ev.tr * i2mu;
+                cm_ += lam[7 + j] * (2.0 * zwe * i2mu - C[7 + j] / m.mu);
+            }
         }
         pbar[CM_P_LAMBDA] = sbd * ev.tr - cl;
         pbar[CM_P_MU] = 2.0 * sbe - cm_;
@@ -1254,6 +1273,7 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
         for (int k = 0; k < 6; ++k) s += ev.gt[k] * kIW[k] * lam[k];
         xpbar[6] = ev.plastic ? -s : lam[6];
         if constexpr (DEF == CM_PLANE_STRESS) xpbar[7] = 0.0;
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) { xpbar[7] = 0.0; xpbar[8] = 0.0; }
     }
     if (egbar) {
         // dC_k/deg_l = -dgam/w_k (Ht Cel)_kl ; dC_6/deg_l = (gt Cel)_l / 2mu ; PS row: (Cel (w o z))_l / 2mu
@@ -1263,6 +1283,10 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
         if constexpr (DEF == CM_PLANE_STRESS) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) t[k] += lam[7] * kW[k] * z[k] * i2mu;
+        }
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t[k] += kW[k] * (lam[7] * z[6 + k] + lam[8] * z[12 + k]) * i2mu;
         }
         apply_cel(m, t, ct);
 #pragma unroll
@@ -1277,7 +1301,6 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
 template <int DEF, int YK>
 CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double z[6],
                         const double* x, const double* xp, double (&T)[6][6]) {
-    static_assert(DEF != CM_UNIAXIAL_STRESS, "batched tangent not built for UNIAXIAL_STRESS");
     constexpr int NX = Dims<DEF>::NX;
     Eval<DEF> ev;
     double C[NX], Ht[6][6], A[NX][NX];
@@ -1300,12 +1323,33 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
             const double zt = z[0] + z[3] + z[5];
             b[7] = -(twomu * kW[l] * z[l] + (kDiag[l] ? lam * zt : 0.0)) * i2mu;
         }
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double* Z = z + 6 * (1 + j);
+                b[7 + j] = -(twomu * kW[l] * Z[l] + (kDiag[l] ? lam * (Z[0] + Z[3] + Z[5]) : 0.0)) * i2mu;
+            }
+        }
         lu_subst<NX>(A, b);                                  // b = dx/deg_l
         double de[6];
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+            // e = eg + (x7 - 1) Z^a + (x8 - 1) Z^b - Pi v
+            double t3[3] = {0.0, b[7], b[8]};
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            de[k] = ((k == l) ? 1.0 : 0.0) - b[k];
-            if constexpr (DEF == CM_PLANE_STRESS) de[k] += z[k] * b[7];
+            for (int i = 0; i < 3; ++i) {
+                double pv = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) pv += kW[k] * z[6 * i + k] * b[k];
+                t3[i] -= pv;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) de[k] = ((k == l) ? 1.0 : 0.0) + t3[0] * z[k] + t3[1] * z[6 + k] + t3[2] * z[12 + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                de[k] = ((k == l) ? 1.0 : 0.0) - b[k];
+                if constexpr (DEF == CM_PLANE_STRESS) de[k] += z[k] * b[7];
+            }
         }
         double ds[6];
         apply_cel(m, de, ds);

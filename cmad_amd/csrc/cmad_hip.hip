@@ -637,7 +637,7 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
 
 // calls F.template operator()<DEF, YK, ROT>() for the runtime (def_type, yield_kind, rotation) triple
 // returns false when no specialisation exists (the caller reports CM_ERR_UNSUPPORTED -- never a silent no-op)
-// UNIAXIAL_STRESS is built for cm_update and cm_evaluate only (`uni` = the caller has those specialisations)
+// UNIAXIAL_STRESS is built for the total-form entries and cm_hessians_rate (`UNI` = the caller has those specialisations)
 template <bool UNI = false, class F>
 inline bool dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity, ls = m->ls_max_evals > 0;
@@ -687,7 +687,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
-    const bool found = dispatch<!TANGENT>(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
@@ -721,7 +721,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         const dim3 grid((unsigned)nb), block(kBlock);
         // CM_DEBUG_DYN_LDS=<bytes>: occupancy experiments only (extra dynamic LDS per block limits blocks per CU)
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-        const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+        const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && (MODE == 1 || MODE == 3)) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_reverse<D, Y, R, LS, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,

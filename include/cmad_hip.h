@@ -154,7 +154,8 @@ int cm_update_rate_tangent(const cm_model_desc* m, int64_t B,
                            double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream);
 
 /*
- * cm_update_tangent: cm_update plus the IFT-consistent tangent d sigma / d gradu.
+ * cm_update_tangent: cm_update plus the IFT-consistent tangent d sigma / d gradu.  All three deformation types
+ * (UNIAXIAL_STRESS: n_gradu = 1, the derivative of the six stress entries w.r.t. the axial strain).
  * Replaces jacfwd through the custom_jvp rule (cmad/models/nonlinear_solver.py:158-171) as used by
  * GlobalResidual._for_model_coupled (cmad/global_residuals/global_residual.py:373-394).
  *   out: dsigma_dgradu[6*n_gradu][B], entry (r, c) at [(r*n_gradu + c)*B + b]
@@ -165,6 +166,8 @@ int cm_update_tangent(const cm_model_desc* m, int64_t B,
 
 /*
  * cm_update_vjp: reverse-mode sensitivities of one converged update for a given stress cotangent.
+ * This entry and cm_update_and_vjp / cm_objective_grad / cm_adjoint_step serve FULL_3D, PLANE_STRESS and
+ * UNIAXIAL_STRESS (9 local dofs, the setting of cmad/calibrations/al7079/multi_experiment_hill_calibration.py).
  * Replaces the transpose of the custom_jvp rule (nonlinear_solver.py:158-171):
  *   lam = (dC/dxi)^-T (dsigma/dxi)^T sbar ;  pbar = (dsigma/dp)^T sbar - (dC/dp)^T lam  (same for xi_prev, gradu)
  *   in : gradu, xi_prev, xi (converged, from cm_update), sigma_bar[6][B] (cotangent of the 6 stored entries)

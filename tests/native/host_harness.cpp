@@ -44,7 +44,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
         if (sigma) for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
         if (status) status[b] = st;
-        if constexpr (DEF != CM_UNIAXIAL_STRESS) if (dsig) {
+        if (dsig) {
             double T[6][6];
             if (g_dense) tangent_any<DEF, YK, false>(m, eg, z, x, xp, T); else tangent_any<DEF, YK, true>(m, eg, z, x, xp, T);
             for (int c = 0; c < NU; ++c) {
@@ -257,7 +257,7 @@ int hh_update(const cm_model_desc* m, int64_t B, const double* gradu, const doub
 }
 int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
            const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
-    return dispatch(m, [&]<int D, int Y, bool R>() { run_vjp<D, Y, R>(*m, B, gradu, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_vjp<D, Y, R>(*m, B, gradu, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
 }
 int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status) {

@@ -41,6 +41,20 @@ def test_vjp(def_type, yield_kind, kw, rot):
     pc.check_vjp(BACKEND, pc.Scenario(def_type, yield_kind, kw, rot, False, B=256))
 
 
+@pytest.mark.parametrize("uidx", [0, 1, 2])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+def test_uniaxial_stress_tangent_and_vjp(yield_kind, kw, rot, uidx, solver_variant):
+    """UNIAXIAL_STRESS (9 local dofs, one grad-u entry): IFT tangent and reverse sweep of the dense path vs the
+    oracle, the way cmad/calibrations/al7079/multi_experiment_hill_calibration.py differentiates it."""
+    if solver_variant == "dense":
+        pytest.skip("always dense")
+    sc = pc.Scenario(ol.UNIAXIAL_STRESS, yield_kind, kw, rot, False, B=192, uniaxial_idx=uidx)
+    pc.check_update(BACKEND, sc)
+    pc.check_tangent(BACKEND, sc)
+    pc.check_vjp(BACKEND, sc, grad_atol=1e-10)
+
+
 @pytest.mark.parametrize("plastic", [True, False])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.SENS_YIELDS)
