@@ -323,6 +323,53 @@ def test_uniaxial_stress_model_reproduces_analytical_fields(golden_dir, yield_ki
     assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6
 
 
+def test_uniaxial_stress_batched_objective_matches_pointwise():
+    """BatchedCalibrationObjective on a UNIAXIAL_STRESS Hill model with active Hill coefficients (the parameter set
+    of cmad/calibrations/al7079/multi_experiment_hill_calibration.py): cm_update + cm_adjoint_step over the history
+    == the sum of the pointwise adjoint objectives on the axial stress."""
+    import copy
+    import torch
+    from cmad_amd.models import DefType, SmallElasticPlastic
+    from cmad_amd.objectives import BatchedCalibrationObjective, MPAdjointObjective
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.parameters.parameters import tree_map
+    from cmad_amd.qois import Calibration
+    K, B, idx = 12, 3, 1
+    F = np.repeat(np.eye(1)[:, :, None], K + 1, axis=2)
+    F[0, 0, :] += np.linspace(0., 0.006, K + 1)
+    base = params_J2_voce(yield_kind="hill")
+    values = copy.deepcopy(base.values)
+    hill = values["plastic"]["effective stress"]["hill"]
+    for key, v in zip(sorted(hill), [0.45, 0.55, 0.5, 1.4, 1.6, 1.5]):
+        hill[key] = v
+    flags = tree_map(lambda a: False, copy.deepcopy(values))
+    flags["plastic"]["effective stress"]["hill"] = tree_map(lambda a: True, flags["plastic"]["effective stress"]["hill"])
+    flags["plastic"]["flow stress"] = tree_map(lambda a: True, flags["plastic"]["flow stress"])
+    transforms = tree_map(lambda a: None, copy.deepcopy(values))
+    rng = np.random.default_rng(4)
+    Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    values["rotation matrix"] = Q * np.sign(np.linalg.det(Q))
+    model = SmallElasticPlastic(Parameters(values, flags, transforms), DefType.UNIAXIAL_STRESS, uniaxial_stress_idx=idx)
+    cauchy = _compute_cauchy(model, F)
+    assert abs(cauchy[idx, idx, -1]) > 150.
+    weight = np.zeros((3, 3)); weight[idx, idx] = 1.
+    datas = [cauchy + rng.normal(0., 5., cauchy.shape) for _ in range(B)]
+    datas = [0.5 * (d + d.transpose(1, 0, 2)) for d in datas]
+    model.parameters.set_active_values_from_flat(1.05 * model.parameters.flat_active_values(False), False)
+    x = model.parameters.flat_active_values(True)
+    J_ref, g_ref = 0., 0.
+    for d in datas:
+        r = MPAdjointObjective(Calibration(model, d, weight), F).evaluate(x)
+        J_ref += r.J; g_ref = g_ref + r.grad
+    gh = torch.from_numpy(np.stack([np.full((1, B), F[0, 0, k] - 1.) for k in range(K + 1)])).cuda()
+    V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    dh = torch.from_numpy(np.stack([np.stack([[d[i, j, k] for d in datas] for i, j in V6]) for k in range(K + 1)])).cuda()
+    r = BatchedCalibrationObjective(model, gh.contiguous(), dh.contiguous(), weight).evaluate(x)
+    assert len(r.grad) == 9
+    np.testing.assert_allclose(r.J, J_ref, rtol=1e-11)
+    np.testing.assert_allclose(r.grad, g_ref, rtol=1e-8, atol=1e-10 * np.abs(g_ref).max())
+
+
 def test_uniaxial_calibration_direct_equals_adjoint_and_fd():
     """UniaxialCalibration QoI (stress + lateral strains) on a UNIAXIAL_STRESS Hill model: the two sensitivity
     strategies agree and match central finite differences."""

@@ -209,18 +209,20 @@ def test_rate_form_adjoint_history(def_type, yield_kind, kw):
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
 def test_uniaxial_stress_sensitivities(backend, yield_kind, kw, rot, uidx):
     """UNIAXIAL_STRESS (9 local dofs, one grad-u entry): update, IFT tangent, reverse sweep, fused update + vjp and
-    the single-step fused objective vs the oracle."""
+    the single-step fused objective vs the oracle.  (d/d nu vanishes analytically here -- the axial stress of a
+    uniaxial-stress state does not see nu -- and is left with the round-off of O(1e6)-scaled cancelling lambda / mu
+    terms, hence the absolute tolerance relative to the largest gradient entry.)"""
     from cmad_amd.models.device import fold_weight_and_data, kp_to_leaf_grad
     sc = pc.Scenario(ol.UNIAXIAL_STRESS, yield_kind, kw, rot, False, B=1000, uniaxial_idx=uidx)
     pc.check_update(backend, sc)
     pc.check_tangent(backend, sc)
-    sbar, ref = pc.check_vjp(backend, sc, grad_atol=1e-10)
+    sbar, ref = pc.check_vjp(backend, sc, grad_atol=1e-9)
     t = backend.t
     xi_f, sig_f, g_f = backend.ev(sc).update_and_vjp(t(sc.gradu), t(sc.xi1), t(sbar))
     np.testing.assert_allclose(xi_f.cpu().numpy(), sc.xi2, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(sig_f.cpu().numpy(), sc.sig2, rtol=1e-10, atol=1e-8)
     got_f = np.array([kp_to_leaf_grad(p, g_f.cpu().numpy(), sc.info) for p in pc.param_paths(yield_kind)])
-    np.testing.assert_allclose(got_f, ref, rtol=1e-9, atol=1e-10 * np.abs(ref).max())
+    np.testing.assert_allclose(got_f, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
     # objective: the axial stress entry only (UniaxialCalibration's stress term, qois/uniaxial_calibration.py)
     mat, B = sc.mat, sc.B
     data6 = sc.sig2 + np.random.default_rng(7).normal(0., 5., size=sc.sig2.shape)
@@ -233,4 +235,4 @@ def test_uniaxial_stress_sensitivities(backend, yield_kind, kw, rot, uidx):
     np.testing.assert_allclose(xi_d.cpu().numpy(), xk, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(res[0], J_o, rtol=1e-10)
     got, ref = pc.leaf_grads(res[1:], sc.info, mat, yield_kind, g_o)
-    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-10 * np.abs(ref).max())
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
