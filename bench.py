@@ -74,8 +74,8 @@ def load_traffic(points):
 def history_workload(args, dev, rank, world, distributed):
     """Side measurement for BASELINE.json configs[4] with a K-step history per point, the way the reference's
     calibration objectives are used (tests/objectives/test_calibrations.py: PLANE_STRESS, biaxial ramp):
-    one evaluation = K forward launches (cm_update, states stored) + K adjoint launches (cm_adjoint_step) + one
-    all-reduce of (J, grad).  A "step" is one objective + gradient evaluation; value = point-steps per second."""
+    one evaluation = one cm_objective_grad_history launch (K updates forward with the states stored, K adjoint steps
+    backward; --per-step-history: K cm_update launches + K cm_adjoint_step launches) + one all-reduce of (J, grad).  A "step" is one objective + gradient evaluation; value = point-steps per second."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -96,7 +96,8 @@ def history_workload(args, dev, rank, world, distributed):
     gen = torch.Generator(device=dev); gen.manual_seed(99 + rank)
     data_hist = 50.0 * torch.randn((K + 1, 6, B), dtype=torch.float64, device=dev, generator=gen)
     weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.0
-    obj = BatchedCalibrationObjective(model, gradu_hist, data_hist, weight)
+    fused = not args.per_step_history
+    obj = BatchedCalibrationObjective(model, gradu_hist, data_hist, weight, fused_history=fused)
     for _ in range(max(1, args.warmup)):
         r = obj.evaluate_native()
     if distributed:
@@ -115,9 +116,11 @@ def history_workload(args, dev, rank, world, distributed):
     elapsed = float(tmax.item())
     assert np.isfinite(r.J) and np.isfinite(r.grad).all()
     if rank == 0:
-        # forward: read grad u 32 + xi_prev 64, write xi 64; adjoint: read grad u 32 + xi_prev 64 + xi 64 + data 48
-        # + history 64, write history 64
-        bytes_per = 160 + 336
+        # one launch per evaluation (cm_objective_grad_history): forward read grad u 32, write xi 64; adjoint read
+        # grad u 32 + previous xi 64 + data 48.  --per-step-history (one launch per step and direction): forward read
+        # grad u 32 + xi_prev 64, write xi 64; adjoint read grad u 32 + xi_prev 64 + xi 64 + data 48 + history 64,
+        # write history 64
+        bytes_per = (96 + 144) if fused else (160 + 336)
         value = world * B * K * args.steps / elapsed
         print(json.dumps({
             "metric": METRIC, "value": value, "unit": "point-steps/s (objective + gradient)", "n_gpus": world,
@@ -127,7 +130,7 @@ def history_workload(args, dev, rank, world, distributed):
                                    "(side measurement for configs[4])", "points_per_gpu": B, "history_steps": K},
             "roofline": {"bound": "hbm", "achieved": bytes_per * B * K * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_per * B * K * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_update + k_reverse<MODE 2> per history step",
+                         "traffic": None, "kernel": "k_history" if fused else "k_update + k_reverse<MODE 2> per history step",
                          "kernel_ms": elapsed / args.steps * 1e3, "algorithmic_bytes_per_update": bytes_per}}))
     if distributed:
         dist.destroy_process_group()
@@ -140,6 +143,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000, help="Gauss points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-step-history", action="store_true",
+                    help="ps_calibration_history workload: one launch per step and direction instead of cm_objective_grad_history")
     ap.add_argument("--general-newton", action="store_true",
                     help="CM_SOLVER_GENERAL_NEWTON: force the general 7-dof Newton where the J2 radial-line "
                          "restriction (same iterates) would apply; side measurement")

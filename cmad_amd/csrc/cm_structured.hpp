@@ -672,4 +672,75 @@ CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z
     else return tangent_point<DEF, YK>(m, eg, z, x, xp, T);
 }
 
+
+// ---- a whole load history of one point: K updates forward, K adjoint steps backward ---------------------------------
+// cmad/objectives/mp_objective.py:62-89 (forward pass with storage) and :112-142 (adjoint recursion) with the QoI of
+// cmad/qois/calibration.py:56-66, for one Gauss point.  The state stays in registers from step to step: per step the
+// forward pass reads grad u and writes xi, the backward pass reads grad u, the previous xi and the data.
+//   gradu_hist[(K+1)][NU] rows, data_hist[(K+1)][6] rows, xi_hist[(K+1)][NX] rows (slot 0 = initial state, filled here)
+// IO supplies the row access (the kernels: SGPR-based SoA rows; the host build: plain indexing):
+//   io.load<N>(base, step_row0, out) / io.store<N>(base, step_row0, v) / io.phase_barrier()
+// red[0] += J, red[1 + j] += dJ/dp_j (KP order).  MK selects the total-form or the rate-form model (the latter takes
+// grad u of the previous step as well).
+template <int DEF, int YK, bool ROT, bool LS, int MK, class IO>
+CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* data_hist, const double wsq[6],
+                        const double* xi0, double* xi_hist, bool valid, LaneStage stage, const IO& io, double* red) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    double x[NX], xp[NX], z[Dims<DEF>::NZ];
+    strain_z<DEF, ROT>(m, z);
+    io.template load<NX>(xi0, 0, x);
+    if (valid) io.template store<NX>(xi_hist, 0, x);
+    auto strain_at = [&](int k, double eg[6]) {
+        double G[NU];
+        io.template load<NU>(gradu_hist, (int64_t)k * NU, G);
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) {
+            double Gp[NU];
+            io.template load<NU>(gradu_hist, (int64_t)(k - 1) * NU, Gp);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) G[i] -= Gp[i];
+        }
+        strain_from_gradu<DEF, ROT>(m, G, eg);
+    };
+    for (int k = 1; k <= K; ++k) {
+        double eg[6];
+        strain_at(k, eg);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xp[i] = x[i];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) newton<DEF, YK, MK, LS>(m, eg, z, xp, x, valid);
+        else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid, stage);
+        if (valid) io.template store<NX>(xi_hist, (int64_t)k * NX, x);
+    }
+    io.phase_barrier();          // tail lanes shadow another lane's point: its stored states must be visible to them
+    double xin[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xin[i] = 0.0;
+    for (int k = K; k >= 1; --k) {
+        double eg[6], sd[6], sg[6], sb[6], sbm[6], pbar[CM_NUM_PARAMS], xpbar[NX];
+        strain_at(k, eg);
+        io.template load<NX>(xi_hist, (int64_t)(k - 1) * NX, xp);
+        io.template load<6>(data_hist, (int64_t)k * 6, sd);
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) to_global<ROT>(m, x, sg);
+        else {
+            Eval<DEF> ev;
+            strain_stress<DEF>(m, eg, z, x, ev);
+            to_global<ROT>(m, ev.s, sg);
+        }
+        double J = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double mm = sg[i] - sd[i];
+            sb[i] = wsq[i] * mm;
+            J += 0.5 * sb[i] * mm;
+        }
+        cotangent_to_material<ROT>(m, sb, sbm);
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) reverse_point_rate<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr);
+        else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr);
+        red[0] += J;
+#pragma unroll
+        for (int j = 0; j < CM_NUM_PARAMS; ++j) red[1 + j] += pbar[j];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xin[i] = xpbar[i]; x[i] = xp[i]; }
+    }
+}
+
 }  // namespace cm

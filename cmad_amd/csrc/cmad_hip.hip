@@ -6,7 +6,7 @@
 #include "cm_structured.hpp"
 #include "cm_hessian.hpp"
 
-// The library can be built from this one file in seven independent pieces (hipcc -DCM_PART=0..6, see
+// The library can be built from this one file in nine independent pieces (hipcc -DCM_PART=0..8, see
 // cmad_amd/build.py) so the template instantiations compile in parallel; without CM_PART everything is one TU.
 //   0: cm_update            2: cm_update_vjp, cm_adjoint_step   4: cm_update_tangent          6: cm_objective_grad,
 //   1: cm_update_rate, info 3: cm_update_and_vjp                5: cm_evaluate(_rate)            cm_hessians
@@ -535,6 +535,38 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
     block_reduce_store<kRed>(red, partials, lds_buf);
 }
 
+// ---- cm_objective_grad_history: the whole K-step history of every point in one launch ------------------------------
+// (forward updates with the states stored, then the adjoint recursion; cm::history_point)
+struct SoaRowsIO {
+    int64_t B; unsigned b;
+    template <int N> __device__ __forceinline__ void load(const double* base, int64_t row0, double* out) const { load_soa<N>(base + row0 * B, B, b, out); }
+    template <int N> __device__ __forceinline__ void store(double* base, int64_t row0, const double* v) const { store_soa<N>(base + row0 * B, B, b, v); }
+    __device__ __forceinline__ void phase_barrier() const { __syncthreads(); }
+};
+
+template <int DEF, int YK, bool ROT, bool LS, int MK>
+__global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, int K,
+        const double* __restrict__ gradu_hist, const double* __restrict__ data_hist, Wsq wsq,
+        const double* __restrict__ xi0, double* xi_hist, double* __restrict__ partials) {
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
+    constexpr bool STAGED = LS && MK == CM_SMALL_ELASTIC_PLASTIC && has_structured<DEF, YK>();
+    constexpr int kLdsDoubles = (STAGED ? kLsSlots * kBlock : 0) > kRed * kRedStride ? kLsSlots * kBlock : kRed * kRedStride;
+    __shared__ double lds_buf[kLdsDoubles];
+    double red[kRed];
+#pragma unroll
+    for (int k = 0; k < kRed; ++k) red[k] = 0.0;
+    history_point<DEF, YK, ROT, LS, MK>(m, K, gradu_hist + blk0, data_hist + blk0, wsq.w, xi0 + blk0, xi_hist + blk0, valid,
+                                        LaneStage{lds_buf + (STAGED ? threadIdx.x : 0), kBlock}, SoaRowsIO{B, b}, red);
+    if (!valid) {
+#pragma unroll
+        for (int k = 0; k < kRed; ++k) red[k] = 0.0;
+    }
+    __syncthreads();             // the line search's LDS columns are done before the reduction reuses the buffer
+    block_reduce_store<kRed>(red, partials, lds_buf);
+}
+
 // ---- cm_evaluate: residual / Jacobian block / stress / stress-derivative block at given states ----------
 template <int DEF, int YK, bool ROT>
 __global__ __launch_bounds__(64) void k_evaluate(cm_model_desc m, int64_t B, int which,
@@ -771,6 +803,35 @@ int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, 
     double* stage = partials + nb * kRed;
     hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
     hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, accumulate);
+    return check_launch();
+}
+
+template <int MK>
+int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* data_hist,
+                   const double* wsq6, const double* xi0, double* xi_hist, double* out,
+                   void* workspace, int64_t wbytes, void* stream) {
+    if (!m || B < 0 || K < 1 || !out || !workspace || !wsq6) return CM_ERR_BAD_ARG;
+    if (B > 0 && (!gradu_hist || !data_hist || !xi0 || !xi_hist)) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind))) return CM_ERR_UNSUPPORTED;
+    if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = (double*)workspace;
+    const int64_t nb = nblocks_of(B);
+    Wsq w; for (int k = 0; k < 6; ++k) w.w[k] = wsq6[k];
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    if (B > 0) {
+        const dim3 grid((unsigned)nb), block(kBlock);
+        const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+                hipLaunchKernelGGL((k_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials);
+        });
+        if (!found) return CM_ERR_UNSUPPORTED;
+        if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
+    }
+    double* stage = partials + nb * kRed;
+    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
+    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, 0, 0);
     return check_launch();
 }
 
@@ -1029,6 +1090,32 @@ int cm_objective_grad_rate(const cm_model_desc* m, int64_t B, const double* grad
                            void* workspace, int64_t workspace_bytes, void* stream) {
     return launch_reverse_rate<1>(m, B, gradu, gradu_prev, xi_prev, nullptr, data, wsq6, nullptr, xi, nullptr, nullptr,
                                   nullptr, out, 0, 0, workspace, workspace_bytes, stream);
+}
+#endif
+
+#if CM_HAS_PART(7) || CM_HAS_PART(8)
+// the rate-form instantiations live in their own piece of the build (reached through cm_objective_grad_history)
+int cm_internal_history_rate(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* data_hist,
+                             const double* wsq6, const double* xi0, double* xi_hist, double* out,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+#endif
+
+#if CM_HAS_PART(8)
+int cm_internal_history_rate(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* data_hist,
+                             const double* wsq6, const double* xi0, double* xi_hist, double* out,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+    return launch_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream);
+}
+#endif
+
+#if CM_HAS_PART(7)
+int cm_objective_grad_history(const cm_model_desc* m, int64_t B, int32_t K,
+                              const double* gradu_hist, const double* data_hist, const double* wsq6, const double* xi0,
+                              double* xi_hist, double* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return cm_internal_history_rate(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream);
+    return launch_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream);
 }
 #endif
 

@@ -391,6 +391,31 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_objective_grad")
         return res, xi
 
+    def objective_grad_history(self, gradu_hist, data_hist, wsq6, xi0, xi_hist=None, out=None):
+        """`cm_objective_grad_history`: objective + gradient over a whole (K+1, n, B) load history in one launch.
+        Returns (out[1 + CM_NUM_PARAMS] on the device, xi_hist (K+1, n_xi, B))."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        if K < 1:
+            raise ValueError("a load history needs at least one step after the initial configuration")
+        for k in (0, K):
+            _check_soa(gradu_hist[k], self.nu, B, "gradu_hist"); _check_soa(data_hist[k], 6, B, "data_hist")
+        if not (gradu_hist.is_contiguous() and data_hist.is_contiguous() and data_hist.shape[0] == K + 1):
+            raise ValueError("gradu_hist (K+1, n_gradu, B) and data_hist (K+1, 6, B) must be contiguous")
+        _check_soa(xi0, self.nx, B, "xi0")
+        dev = gradu_hist.device
+        if xi_hist is None:
+            xi_hist = torch.empty((K + 1, self.nx, B), dtype=torch.float64, device=dev)
+        elif tuple(xi_hist.shape) != (K + 1, self.nx, B) or not xi_hist.is_contiguous() or xi_hist.dtype != torch.float64:
+            raise ValueError("xi_hist must be a contiguous float64 (K+1, n_xi, B) tensor")
+        res = out if out is not None else torch.empty(1 + _lib.CM_NUM_PARAMS, dtype=torch.float64, device=dev)
+        w = (C.c_double * 6)(*[float(v) for v in wsq6])
+        ws, need = self._workspace(B, dev)
+        rc = self.L.cm_objective_grad_history(C.byref(self.desc), B, K, _ptr(gradu_hist), _ptr(data_hist), w, _ptr(xi0),
+                                              _ptr(xi_hist), _ptr(res), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_objective_grad_history")
+        return res, xi_hist
+
     def adjoint_step(self, gradu, xi_prev, xi, data6, wsq6, hist_in, hist_out, out, accumulate=True, gradu_prev=None):
         B = gradu.shape[1]
         _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")

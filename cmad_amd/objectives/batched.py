@@ -5,8 +5,9 @@ for B independent Gauss points at once, sharded over ranks.
     J(p)    = sum_b sum_k 1/2 || w o (sigma_b,k(p) - data_b,k) ||^2
     grad(p) = dJ/dp in Parameters' flat active order, canonical (transform_grad applied) like the reference
 
-Per load step: one `cm_update` launch forward (all points), one `cm_adjoint_step` launch in reverse; a
-single-step history uses the fused `cm_objective_grad`.  Multi-GPU: each rank owns a contiguous shard of
+A K-step history is one `cm_objective_grad_history` launch (state in registers from step to step); with
+`fused_history=False` one `cm_update` launch per step forward and one `cm_adjoint_step` launch per step in reverse.
+A single-step history uses the fused `cm_objective_grad`.  Multi-GPU: each rank owns a contiguous shard of
 the points; the only exchange is one all-reduce of (1 + 12) doubles per evaluation (RCCL on GPUs).
 """
 from __future__ import annotations
@@ -43,7 +44,7 @@ class BatchedCalibrationObjective:
     xi0       : (n_xi, B_local) initial state (default: the model's init values)
     """
 
-    def __init__(self, model, gradu_hist, data_hist, weight, xi0=None, newton=None, group=None):
+    def __init__(self, model, gradu_hist, data_hist, weight, xi0=None, newton=None, group=None, fused_history=True):
         import torch
         self._model = model
         self._parameters = model.parameters
@@ -59,6 +60,9 @@ class BatchedCalibrationObjective:
             xi0 = torch.from_numpy(init).to(dev)[:, None].repeat(1, self._B).contiguous()
         self._xi0 = xi0
         self._out = torch.zeros(13, dtype=torch.float64, device=dev)
+        # K > 1: one `cm_objective_grad_history` launch per evaluation (False: one launch per step and direction)
+        self._fused_history = bool(fused_history)
+        self._xi_hist = None
 
     def evaluate(self, flat_active_values) -> GradientResult:
         self._parameters.set_active_values_from_flat(flat_active_values)
@@ -78,6 +82,8 @@ class BatchedCalibrationObjective:
         prev = (lambda k: {"gradu_prev": g[k - 1]}) if rate else (lambda k: {})
         if K == 1:
             ev.objective_grad(g[1], self._xi0, d[1], self._wsq6, out=out, **prev(1))
+        elif self._fused_history:
+            _, self._xi_hist = ev.objective_grad_history(g, d, self._wsq6, self._xi0, xi_hist=self._xi_hist, out=out)
         else:
             xs = [self._xi0]
             for k in range(1, K + 1):

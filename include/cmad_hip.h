@@ -294,6 +294,23 @@ int cm_hessians_rate(const cm_model_desc* m, int64_t B,
                      const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                      double* d2C, double* d2S, double* dC, double* dS, double* C0, double* sigma0, void* stream);
 
+/*
+ * cm_objective_grad_history: calibration objective and gradient over a whole K-step load history per point, one launch.
+ * Replaces, per point and summed over the batch, MPAdjointObjective._evaluate (cmad/objectives/mp_objective.py:95-147):
+ * the forward pass with storage (:62-89) and the adjoint recursion (:112-142) with QoI Calibration._qoi
+ * (cmad/qois/calibration.py:56-66).  Same numbers as K calls of cm_update (cm_update_rate) followed by K calls of
+ * cm_adjoint_step (cm_adjoint_step_rate), but the state stays in registers from step to step: per point and step the
+ * forward pass reads grad u and writes xi, the backward pass reads grad u, the previous xi and the data.
+ * Both model kinds (m->model_kind; the rate form takes grad u of step k-1 as its previous grad u).
+ *   in : gradu_hist[(K+1)][n_gradu][B] (step 0 = initial configuration), data_hist[(K+1)][6][B] (step 0 unused),
+ *        wsq6[6] (HOST, as cm_objective_grad), xi0[n_xi][B]
+ *   out: xi_hist[(K+1)][n_xi][B] (slot 0 = xi0, slot K = final state; also the kernel's own storage),
+ *        out[1 + CM_NUM_PARAMS] = {J, grad...}
+ */
+int cm_objective_grad_history(const cm_model_desc* m, int64_t B, int32_t K,
+                              const double* gradu_hist, const double* data_hist, const double* wsq6, const double* xi0,
+                              double* xi_hist, double* out, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

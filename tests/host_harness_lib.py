@@ -79,6 +79,18 @@ def vjp_rate(desc, gradu, gradu_prev, xi_prev, xi, sbar, xin=None):
     return g, xb, ub
 
 
+def history(desc, gradu_hist, data_hist, wsq6, xi0):
+    """cm::history_point over the batch: (out[13] = {J, grad KP}, xi_hist (K+1, nx, B))."""
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu_hist, data_hist, wsq6, xi0 = c(gradu_hist), c(data_hist), c(wsq6), c(xi0)
+    K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+    xi_hist = np.zeros((K + 1,) + xi0.shape); out = np.zeros(13)
+    rc = L.hh_history(C.byref(desc), C.c_int64(B), C.c_int(K), _p(gradu_hist), _p(data_hist), _p(wsq6), _p(xi0), _p(xi_hist), _p(out))
+    assert rc == 0
+    return out, xi_hist
+
+
 def evaluate(desc, which, gradu, xi_prev, xi, nx):
     """Explicit blocks at given states: C (nx,B), J (nx,ncols,B), sigma6 (6,B), S (6,ncols,B)."""
     L = lib()

@@ -220,6 +220,30 @@ static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu,
     }
 }
 
+// whole-history objective + gradient (cm::history_point, the body of k_history) with plain row indexing
+struct HostRowsIO {
+    int64_t B, b;
+    template <int N> void load(const double* base, int64_t row0, double* out) const { for (int k = 0; k < N; ++k) out[k] = base[(row0 + k) * B + b]; }
+    template <int N> void store(double* base, int64_t row0, const double* v) const { for (int k = 0; k < N; ++k) base[(row0 + k) * B + b] = v[k]; }
+    void phase_barrier() const {}
+};
+
+template <int DEF, int YK, bool ROT, int MK>
+static void run_history(const cm_model_desc& m, int64_t B, int K, const double* gradu_hist, const double* data_hist,
+                        const double* wsq6, const double* xi0, double* xi_hist, double* out) {
+    for (int k = 0; k < 1 + CM_NUM_PARAMS; ++k) out[k] = 0.0;
+    const bool ls = m.ls_max_evals > 0;
+    for (int64_t b = 0; b < B; ++b) {
+        double red[1 + CM_NUM_PARAMS] = {0.0};
+        double parked[2 * 9];
+        const LaneStage stage{parked, 1};
+        const HostRowsIO io{B, b};
+        if (ls) history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
+        else history_point<DEF, YK, ROT, false, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
+        for (int k = 0; k < 1 + CM_NUM_PARAMS; ++k) out[k] += red[k];
+    }
+}
+
 template <bool UNI = false, class F>
 static int dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity;
@@ -287,6 +311,14 @@ int hh_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, con
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_evaluate<D, Y, R>(*m, B, which, gradu, xi_prev, xi, C, J, s, S); });
+}
+int hh_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* data_hist,
+               const double* wsq6, const double* xi0, double* xi_hist, double* out) {
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch(m, [&]<int D, int Y, bool R>() {
+            if constexpr (!is_dense_yield(Y)) run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() {
+        run_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
 }
 void hh_set_dense(int d) { g_dense = d; }
 int hh_sizeof_desc(void) { return (int)sizeof(cm_model_desc); }

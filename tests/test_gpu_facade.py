@@ -149,6 +149,10 @@ def test_batched_objective_matches_pointwise_and_oracle():
     r = obj.evaluate(x)
     np.testing.assert_allclose(r.J, J_ref, rtol=1e-11)
     np.testing.assert_allclose(r.grad, g_ref, rtol=1e-8, atol=1e-10 * np.abs(g_ref).max())
+    # one launch per step and direction instead of cm_objective_grad_history: same numbers
+    r2 = BatchedCalibrationObjective(model, gh.contiguous(), dh.contiguous(), weight, fused_history=False).evaluate(x)
+    np.testing.assert_allclose(r2.J, r.J, rtol=1e-13)
+    np.testing.assert_allclose(r2.grad, r.grad, rtol=1e-10, atol=1e-12 * np.abs(r.grad).max())
 
 
 def test_calibration_recovers_truth():
@@ -466,6 +470,9 @@ def test_rate_model_batched_objective_matches_pointwise(def_type_name):
     r = BatchedCalibrationObjective(model, gh.contiguous(), dh.contiguous(), weight).evaluate(x)
     np.testing.assert_allclose(r.J, J_ref, rtol=1e-11)
     np.testing.assert_allclose(r.grad, g_ref, rtol=1e-8, atol=1e-10 * np.abs(g_ref).max())
+    r2 = BatchedCalibrationObjective(model, gh.contiguous(), dh.contiguous(), weight, fused_history=False).evaluate(x)
+    np.testing.assert_allclose(r2.J, r.J, rtol=1e-13)
+    np.testing.assert_allclose(r2.grad, r.grad, rtol=1e-10, atol=1e-12 * np.abs(r.grad).max())
 
 
 def _hessian_problem(active_elastic=False, K=10, rate=False):

@@ -55,6 +55,32 @@ def test_uniaxial_stress_tangent_and_vjp(yield_kind, kw, rot, uidx, solver_varia
     pc.check_vjp(BACKEND, sc, grad_atol=1e-9)
 
 
+def _host_history(desc, info, gh, d6, wsq6, xi0):
+    import host_harness_lib as hh
+    if "nn_packed" in info:
+        desc.nn_weights = info["nn_packed"].ctypes.data
+    return hh.history(desc, gh, d6, wsq6, xi0)
+
+
+@pytest.mark.parametrize("rate", [False, True])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_history_objective_grad(def_type, yield_kind, kw, rot, rate, solver_variant):
+    """cm::history_point (the body of cm_objective_grad_history): K updates forward with the state carried in
+    registers, K adjoint steps backward, both model kinds."""
+    if solver_variant == "dense":
+        pytest.skip("one variant: the history loop is the same code on both solver paths")
+    if rate and def_type == ol.UNIAXIAL_STRESS:
+        pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
+    pc.check_history(_host_history, def_type, yield_kind, kw, rot, rate=rate, B=96, uniaxial_idx=1)
+
+
+def test_history_objective_grad_with_line_search():
+    pc.check_history(_host_history, ol.FULL_3D, "J2", {}, False, ls=True, B=96)
+    pc.check_history(_host_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=96)
+
+
 @pytest.mark.parametrize("plastic", [True, False])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.SENS_YIELDS)
