@@ -10,7 +10,18 @@
 
 using namespace cm;
 
-static int g_dense = 0;   // 1: force the dense 7x7 path also for FULL_3D
+// The file compiles in independent pieces (-DHH_PART=0..6, tests/host_harness_lib.py) so the template instantiations
+// build in parallel; without HH_PART everything is one translation unit.
+#ifndef HH_PART
+#define HH_PART (-1)
+#endif
+#define HH_HAS(k) (HH_PART == -1 || HH_PART == (k))
+#define g_dense hh_g_dense
+#if HH_HAS(0)
+int hh_g_dense = 0;       // 1: force the dense 7x7 path also for FULL_3D
+#else
+extern int hh_g_dense;
+#endif
 
 template <int DEF, int YK, bool ROT>
 static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, const double* xi_prev,
@@ -274,44 +285,65 @@ static int dispatch(const cm_model_desc* m, F&& f) {
 }
 
 extern "C" {
+#if HH_HAS(0)
 double hh_quad_min(double phi0, double dphi0, double a, double phi) { return quad_min(phi0, dphi0, a, phi); }
+#endif
+#if HH_HAS(0)
 int hh_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
               double* xi, double* sigma, uint32_t* status, double* dsig) {
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_update<D, Y, R>(*m, B, gradu, xi_prev, xi, sigma, status, dsig); });
 }
+#endif
+#if HH_HAS(1)
 int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
            const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_vjp<D, Y, R>(*m, B, gradu, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
 }
+#endif
+#if HH_HAS(2)
 int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
 }
+#endif
+#if HH_HAS(2)
 int hh_vjp_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                 const double* xi, const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_vjp_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
 }
+#endif
+#if HH_HAS(2)
 int hh_tangent_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
                     const double* xi_prev, const double* xi, double* dsig) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_tangent_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, dsig); });
 }
+#endif
+#if HH_HAS(2)
 int hh_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                      const double* xi_prev, const double* xi, double* C, double* J, double* s, double* S) {
     return dispatch(m, [&]<int D, int Y, bool R>() { run_evaluate_rate<D, Y, R>(*m, B, which, gradu, gradu_prev, xi_prev, xi, C, J, s, S); });
 }
+#endif
+#if HH_HAS(4)
 int hh_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
                 double* d2C, double* d2S, double* dC, double* dS) {
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_hessians<D, Y, R>(*m, B, gradu, nullptr, xi_prev, xi, d2C, d2S, dC, dS); });
 }
+#endif
+#if HH_HAS(5)
 int hh_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                      const double* xi, double* d2C, double* d2S, double* dC, double* dS, double* C0, double* S0) {
     return dispatch<true>(m, [&]<int D, int Y, bool R>() {
         run_hessians<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, gradu, gradu_prev, xi_prev, xi, d2C, d2S, dC, dS, C0, S0); });
 }
+#endif
+#if HH_HAS(3)
 int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* xi_prev,
                 const double* xi, double* C, double* J, double* s, double* S) {
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_evaluate<D, Y, R>(*m, B, which, gradu, xi_prev, xi, C, J, s, S); });
 }
+#endif
+#if HH_HAS(6)
 int hh_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* data_hist,
                const double* wsq6, const double* xi0, double* xi_hist, double* out) {
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
@@ -320,6 +352,11 @@ int hh_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_his
     return dispatch<true>(m, [&]<int D, int Y, bool R>() {
         run_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
 }
+#endif
+#if HH_HAS(0)
 void hh_set_dense(int d) { g_dense = d; }
+#endif
+#if HH_HAS(0)
 int hh_sizeof_desc(void) { return (int)sizeof(cm_model_desc); }
+#endif
 }

@@ -17,6 +17,7 @@ run --workload j2_update_vjp --general-newton
 run --workload j2_update --general-newton
 run --workload j2_objective_grad --general-newton
 run --workload ps_calibration_history --steps 5
+run --workload ps_calibration_history --steps 5 --per-step-history
 run --workload j2_update_vjp --yield-surface hill
 run --workload j2_update_vjp --yield-surface hill --def-type plane_stress
 run --workload j2_update_vjp --yield-surface hosford8
