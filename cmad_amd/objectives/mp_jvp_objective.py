@@ -5,10 +5,10 @@ time loop through the local solver's implicit-function rule.  Host mirror of
 derivatives w.r.t. the canonical values out).
 
 The reference lets JAX trace `fori_loop(update_fun)` and transpose the solver's `custom_jvp`
-(`value_and_grad`, :31-33).  Here the forward loop is one `cm_update` launch per step with the settings of
-`update_fun = make_newton_solve(model._residual, ...)` and the reverse sweep is one `cm_adjoint_step` launch per
-step -- the same implicit-function transposition written as kernels (and usable with any batch size through
-`BatchedCalibrationObjective`, of which this is the one-point case).  The Hessian reuses the direct-adjoint
+(`value_and_grad`, :31-33) into one program.  Here the whole history is one `cm_objective_grad_history` launch with
+the settings of `update_fun = make_newton_solve(model._residual, ...)`: the forward loop with the states stored and
+the reverse sweep of the same implicit-function transposition, written as a kernel (and usable with any batch size
+through `BatchedCalibrationObjective`, of which this is the one-point case).  The Hessian reuses the direct-adjoint
 contraction of `MPDirectAdjointObjective`, which is the same quantity `jax.hessian` returns.
 """
 from __future__ import annotations
