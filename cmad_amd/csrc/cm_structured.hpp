@@ -673,6 +673,55 @@ CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z
 }
 
 
+// ---- forward pass over a whole load history of one point (state carried in registers) ------------------------------
+// cmad/objectives/mp_objective.py:62-89 (forward pass with storage) / cmad/cli/primal.py:129-176 without the QoI:
+// xi_hist[(K+1)][NX] rows (slot 0 = initial state), sigma_hist[(K+1)][6] rows (global Cauchy stress; slot 0 = stress of
+// the initial state under gradu_hist[0]) and status_hist[(K+1)] rows are optional (null = not stored).
+template <int DEF, int YK, bool ROT, bool LS, int MK, class IO>
+CM_D void primal_history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* xi0, double* xi_hist,
+                               double* sigma_hist, uint32_t* status_hist, bool valid, LaneStage stage, const IO& io) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    double x[NX], xp[NX], z[Dims<DEF>::NZ];
+    strain_z<DEF, ROT>(m, z);
+    io.template load<NX>(xi0, 0, x);
+    for (int k = 0; k <= K; ++k) {
+        double G[NU], eg[6];
+        io.template load<NU>(gradu_hist, (int64_t)k * NU, G);
+        uint32_t st = CM_STATUS_CONVERGED;
+        if (k > 0) {
+            if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) {
+                double Gp[NU], dG[NU], deg[6];
+                io.template load<NU>(gradu_hist, (int64_t)(k - 1) * NU, Gp);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) dG[i] = G[i] - Gp[i];
+                strain_from_gradu<DEF, ROT>(m, dG, deg);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xp[i] = x[i];
+                st = newton<DEF, YK, MK, LS>(m, deg, z, xp, x, valid);
+            } else {
+                strain_from_gradu<DEF, ROT>(m, G, eg);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xp[i] = x[i];
+                st = newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid, stage);
+            }
+        }
+        if (!valid) continue;
+        if (xi_hist) io.template store<NX>(xi_hist, (int64_t)k * NX, x);
+        if (sigma_hist) {
+            double sg[6];
+            if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) to_global<ROT>(m, x, sg);
+            else {
+                Eval<DEF> ev;
+                strain_from_gradu<DEF, ROT>(m, G, eg);
+                strain_stress<DEF>(m, eg, z, x, ev);
+                to_global<ROT>(m, ev.s, sg);
+            }
+            io.template store<6>(sigma_hist, (int64_t)k * 6, sg);
+        }
+        if (status_hist) io.store_status(status_hist, k, st);
+    }
+}
+
 // ---- a whole load history of one point: K updates forward, K adjoint steps backward ---------------------------------
 // cmad/objectives/mp_objective.py:62-89 (forward pass with storage) and :112-142 (adjoint recursion) with the QoI of
 // cmad/qois/calibration.py:56-66, for one Gauss point.  The state stays in registers from step to step: per step the

@@ -542,6 +542,7 @@ struct SoaRowsIO {
     template <int N> __device__ __forceinline__ void load(const double* base, int64_t row0, double* out) const { load_soa<N>(base + row0 * B, B, b, out); }
     template <int N> __device__ __forceinline__ void store(double* base, int64_t row0, const double* v) const { store_soa<N>(base + row0 * B, B, b, v); }
     __device__ __forceinline__ void phase_barrier() const { __syncthreads(); }
+    __device__ __forceinline__ void store_status(uint32_t* base, int64_t row, uint32_t v) const { (base + row * B)[b] = v; }
 };
 
 template <int DEF, int YK, bool ROT, bool LS, int MK>
@@ -565,6 +566,21 @@ __global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, 
     }
     __syncthreads();             // the line search's LDS columns are done before the reduction reuses the buffer
     block_reduce_store<kRed>(red, partials, lds_buf);
+}
+
+// ---- cm_update_history: K updates per point in one launch, states / stresses / statuses stored per step ------------
+template <int DEF, int YK, bool ROT, bool LS, int MK>
+__global__ __launch_bounds__(kBlock) void k_primal_history(cm_model_desc m, int64_t B, int K,
+        const double* __restrict__ gradu_hist, const double* __restrict__ xi0, double* __restrict__ xi_hist,
+        double* __restrict__ sigma_hist, uint32_t* __restrict__ status_hist) {
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
+    constexpr bool STAGED = LS && MK == CM_SMALL_ELASTIC_PLASTIC && has_structured<DEF, YK>();
+    __shared__ double ls_stage[STAGED ? kLsSlots * kBlock : 1];
+    primal_history_point<DEF, YK, ROT, LS, MK>(m, K, gradu_hist + blk0, xi0 + blk0, xi_hist ? xi_hist + blk0 : nullptr,
+                                               sigma_hist ? sigma_hist + blk0 : nullptr, status_hist ? status_hist + blk0 : nullptr,
+                                               valid, LaneStage{ls_stage + (STAGED ? threadIdx.x : 0), kBlock}, SoaRowsIO{B, b});
 }
 
 // ---- cm_evaluate: residual / Jacobian block / stress / stress-derivative block at given states ----------
@@ -835,6 +851,25 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
     return check_launch();
 }
 
+template <int MK>
+int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi0,
+                          double* xi_hist, double* sigma_hist, uint32_t* status_hist, void* stream) {
+    if (!m || B < 0 || K < 1) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind))) return CM_ERR_UNSUPPORTED;
+    if (B == 0) return CM_OK;
+    if (!gradu_hist || !xi0 || (!xi_hist && !sigma_hist)) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+            hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+
 #if CM_HAS_PART(6)
 template <int MK>
 int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
@@ -1098,6 +1133,28 @@ int cm_objective_grad_rate(const cm_model_desc* m, int64_t B, const double* grad
 int cm_internal_history_rate(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* data_hist,
                              const double* wsq6, const double* xi0, double* xi_hist, double* out,
                              void* workspace, int64_t workspace_bytes, void* stream);
+#endif
+
+#if CM_HAS_PART(7) || CM_HAS_PART(8)
+int cm_internal_primal_history_rate(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi0,
+                                    double* xi_hist, double* sigma_hist, uint32_t* status_hist, void* stream);
+#endif
+
+#if CM_HAS_PART(8)
+int cm_internal_primal_history_rate(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi0,
+                                    double* xi_hist, double* sigma_hist, uint32_t* status_hist, void* stream) {
+    return launch_primal_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, stream);
+}
+#endif
+
+#if CM_HAS_PART(7)
+int cm_update_history(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi0,
+                      double* xi_hist, double* sigma_hist, uint32_t* status_hist, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return cm_internal_primal_history_rate(m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, stream);
+    return launch_primal_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, stream);
+}
 #endif
 
 #if CM_HAS_PART(8)

@@ -391,6 +391,28 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_objective_grad")
         return res, xi
 
+    def update_history(self, gradu_hist, xi0, want_xi=True, want_sigma=True, want_status=True):
+        """`cm_update_history`: K updates per point in one launch.  Returns (xi_hist (K+1, n_xi, B),
+        sigma_hist (K+1, 6, B), status_hist (K+1, B) int32), None for the ones not requested."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        if K < 1:
+            raise ValueError("a load history needs at least one step after the initial configuration")
+        if not (want_xi or want_sigma):
+            raise ValueError("request the state history, the stress history or both")
+        _check_soa(gradu_hist[0], self.nu, B, "gradu_hist")
+        if not gradu_hist.is_contiguous():
+            raise ValueError("gradu_hist (K+1, n_gradu, B) must be contiguous")
+        _check_soa(xi0, self.nx, B, "xi0")
+        dev = gradu_hist.device
+        xi_hist = torch.empty((K + 1, self.nx, B), dtype=torch.float64, device=dev) if want_xi else None
+        sig_hist = torch.empty((K + 1, 6, B), dtype=torch.float64, device=dev) if want_sigma else None
+        st_hist = torch.empty((K + 1, B), dtype=torch.int32, device=dev) if want_status else None
+        rc = self.L.cm_update_history(C.byref(self.desc), B, K, _ptr(gradu_hist), _ptr(xi0), _ptr(xi_hist), _ptr(sig_hist),
+                                      _ptr(st_hist), self._stream())
+        _lib.check(rc, "cm_update_history")
+        return xi_hist, sig_hist, st_hist
+
     def objective_grad_history(self, gradu_hist, data_hist, wsq6, xi0, xi_hist=None, out=None):
         """`cm_objective_grad_history`: objective + gradient over a whole (K+1, n, B) load history in one launch.
         Returns (out[1 + CM_NUM_PARAMS] on the device, xi_hist (K+1, n_xi, B))."""

@@ -311,6 +311,20 @@ int cm_objective_grad_history(const cm_model_desc* m, int64_t B, int32_t K,
                               const double* gradu_hist, const double* data_hist, const double* wsq6, const double* xi0,
                               double* xi_hist, double* out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/*
+ * cm_update_history: K stress updates per point in one launch (the state is carried in registers from step to step).
+ * Replaces, per point, the forward pass with storage of the material-point drivers
+ * (cmad/objectives/mp_objective.py:62-89, cmad/cli/primal.py:129-176 without the QoI): the same numbers as K calls of
+ * cm_update (cm_update_rate for m->model_kind = CM_SMALL_RATE_ELASTIC_PLASTIC, previous grad u = step k-1).
+ *   in : gradu_hist[(K+1)][n_gradu][B] (step 0 = initial configuration), xi0[n_xi][B]
+ *   out (each may be NULL, not both xi_hist and sigma_hist): xi_hist[(K+1)][n_xi][B] (slot 0 = xi0),
+ *        sigma_hist[(K+1)][6][B] (global Cauchy stress; slot 0 = stress of xi0 under gradu_hist[0]),
+ *        status_hist[(K+1)][B] (iterations and CM_STATUS_CONVERGED / CM_STATUS_SINGULAR per step; the informational
+ *        CM_STATUS_PLASTIC bit is not evaluated here; slot 0 = CM_STATUS_CONVERGED)
+ */
+int cm_update_history(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi0,
+                      double* xi_hist, double* sigma_hist, uint32_t* status_hist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

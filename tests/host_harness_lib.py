@@ -104,6 +104,18 @@ def history(desc, gradu_hist, data_hist, wsq6, xi0):
     return out, xi_hist
 
 
+def primal_history(desc, gradu_hist, xi0):
+    """cm::primal_history_point over the batch: xi_hist (K+1, nx, B), sigma_hist (K+1, 6, B), status_hist (K+1, B)."""
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu_hist, xi0 = c(gradu_hist), c(xi0)
+    K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+    xi_hist = np.zeros((K + 1,) + xi0.shape); sig = np.zeros((K + 1, 6, B)); st = np.zeros((K + 1, B), dtype=np.uint32)
+    rc = L.hh_primal_history(C.byref(desc), C.c_int64(B), C.c_int(K), _p(gradu_hist), _p(xi0), _p(xi_hist), _p(sig), _p(st))
+    assert rc == 0
+    return xi_hist, sig, st
+
+
 def evaluate(desc, which, gradu, xi_prev, xi, nx):
     """Explicit blocks at given states: C (nx,B), J (nx,ncols,B), sigma6 (6,B), S (6,ncols,B)."""
     L = lib()

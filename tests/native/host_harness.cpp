@@ -237,6 +237,7 @@ struct HostRowsIO {
     template <int N> void load(const double* base, int64_t row0, double* out) const { for (int k = 0; k < N; ++k) out[k] = base[(row0 + k) * B + b]; }
     template <int N> void store(double* base, int64_t row0, const double* v) const { for (int k = 0; k < N; ++k) base[(row0 + k) * B + b] = v[k]; }
     void phase_barrier() const {}
+    void store_status(uint32_t* base, int64_t row, uint32_t v) const { base[row * B + b] = v; }
 };
 
 template <int DEF, int YK, bool ROT, int MK>
@@ -252,6 +253,19 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
         if (ls) history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
         else history_point<DEF, YK, ROT, false, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
         for (int k = 0; k < 1 + CM_NUM_PARAMS; ++k) out[k] += red[k];
+    }
+}
+
+template <int DEF, int YK, bool ROT, int MK>
+static void run_primal_history(const cm_model_desc& m, int64_t B, int K, const double* gradu_hist, const double* xi0,
+                               double* xi_hist, double* sigma_hist, uint32_t* status_hist) {
+    const bool ls = m.ls_max_evals > 0;
+    for (int64_t b = 0; b < B; ++b) {
+        double parked[2 * 9];
+        const LaneStage stage{parked, 1};
+        const HostRowsIO io{B, b};
+        if (ls) primal_history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
+        else primal_history_point<DEF, YK, ROT, false, MK>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
     }
 }
 
@@ -351,6 +365,16 @@ int hh_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_his
             if constexpr (!is_dense_yield(Y)) run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() {
         run_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
+}
+#endif
+#if HH_HAS(6)
+int hh_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi0,
+                      double* xi_hist, double* sigma_hist, uint32_t* status_hist) {
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch(m, [&]<int D, int Y, bool R>() {
+            if constexpr (!is_dense_yield(Y)) run_primal_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() {
+        run_primal_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
 }
 #endif
 #if HH_HAS(0)

@@ -332,10 +332,13 @@ def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
 
 
-def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, K=5, B=256, seed=22, uniaxial_idx=0):
+def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, K=5, B=256, seed=22, uniaxial_idx=0,
+                  primal=None):
     """Objective + gradient over a K-step history per point (forward updates, adjoint recursion) in one call vs the
     oracle's adjoint (cmad/objectives/mp_objective.py:95-147): J, gradient, every stored state.
-    `history(desc, info, gradu_hist, data6_hist, wsq6, xi0) -> (out[13], xi_hist)`."""
+    `history(desc, info, gradu_hist, data6_hist, wsq6, xi0) -> (out[13], xi_hist)`.
+    `primal(desc, info, gradu_hist, xi0) -> (xi_hist, sigma_hist, status_hist)`: the forward pass alone
+    (cm_update_history) on the same history -- states, stresses, iteration counts and convergence flags per step."""
     from cmad_amd.models.device import build_desc, fold_weight_and_data
     from cmad_amd.synthetic import gauss_point_batch
     rng = np.random.default_rng(seed)
@@ -355,13 +358,21 @@ def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, 
     gh = np.stack([c * g0 for c in path])
     xi0 = np.tile(mat.init_xi()[:, None], (1, B))
     xs, plastic = [xi0], 0.0
-    sig = [np.zeros((6, B))]
+    sig, its = [np.zeros((6, B))], [np.zeros(B, dtype=np.int32)]
     for k in range(1, K + 1):
         x, s, it, cv = mat.update_batch(st_o, gh[k], xs[-1], gradu_prev=gh[k - 1] if rate else None)
         assert cv.all()
         plastic = max(plastic, (it > 0).mean())
-        xs.append(x); sig.append(s)
+        xs.append(x); sig.append(s); its.append(it)
     assert plastic > 0.2
+    if primal is not None:
+        xh, sh, sth = primal(desc, info, gh, xi0)
+        sth = sth.astype(np.uint32)
+        assert ((sth >> 16) & 1).all() and ((sth >> 18) & 1).sum() == 0
+        for k in range(K + 1):
+            np.testing.assert_allclose(xh[k], xs[k], rtol=1e-10, atol=1e-7 if rate else XI_ATOL)
+            np.testing.assert_allclose(sh[k], sig[k], rtol=1e-10, atol=1e-7)
+            assert np.abs((sth[k] & 0xFFFF).astype(np.int32) - its[k]).max() <= 1
     data6 = np.stack([s + rng.normal(0., 5., size=s.shape) for s in sig])
     idx9 = [0, 1, 2, 1, 3, 4, 2, 4, 5]
     w = np.zeros((3, 3)); w[0, 0] = 1.; w[1, 1] = 1.; w[0, 1] = 0.5; w[1, 0] = 0.5

@@ -246,22 +246,31 @@ def _gpu_history(desc, info, gh, d6, wsq6, xi0):
     return out.cpu().numpy(), xi_hist.cpu().numpy()
 
 
+def _gpu_primal(desc, info, gh, xi0):
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return tuple(o.cpu().numpy() for o in DeviceEvaluator(desc, info).update_history(t(gh), t(xi0)))
+
+
 @pytest.mark.parametrize("rate", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_history_objective_grad(def_type, yield_kind, kw, rot, rate):
     """cm_objective_grad_history: the whole K-step history per point in one launch vs the oracle's adjoint
-    (cmad/objectives/mp_objective.py:95-147); block tail (B not a multiple of the block) included."""
+    (cmad/objectives/mp_objective.py:95-147), and cm_update_history (the forward pass alone: states, stresses, iteration
+    counts per step); block tail (B not a multiple of the block) included."""
     if rate and def_type == ol.UNIAXIAL_STRESS:
         pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
     # (the 7-step path ends with a large reversal that the rate form's plain Newton does not survive at every point)
-    pc.check_history(_gpu_history, def_type, yield_kind, kw, rot, rate=rate, B=1000, K=5 if rate else 7, uniaxial_idx=2)
+    pc.check_history(_gpu_history, def_type, yield_kind, kw, rot, rate=rate, B=1000, K=5 if rate else 7, uniaxial_idx=2,
+                     primal=_gpu_primal)
 
 
 def test_history_objective_grad_variants():
     """Line search variants, the hybrid network and Barlat surfaces, and the fused history against the per-step
     launches of BatchedCalibrationObjective."""
-    pc.check_history(_gpu_history, ol.FULL_3D, "J2", {}, False, ls=True, B=700)
-    pc.check_history(_gpu_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=700)
-    pc.check_history(_gpu_history, ol.PLANE_STRESS, "hosford", pc.YIELDS[2][1], True, rate=True, ls=True, B=700)
+    pc.check_history(_gpu_history, ol.FULL_3D, "J2", {}, False, ls=True, B=700, primal=_gpu_primal)
+    pc.check_history(_gpu_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=700, primal=_gpu_primal)
+    pc.check_history(_gpu_history, ol.PLANE_STRESS, "hosford", pc.YIELDS[2][1], True, rate=True, ls=True, B=700, primal=_gpu_primal)

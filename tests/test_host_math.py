@@ -62,6 +62,13 @@ def _host_history(desc, info, gh, d6, wsq6, xi0):
     return hh.history(desc, gh, d6, wsq6, xi0)
 
 
+def _host_primal(desc, info, gh, xi0):
+    import host_harness_lib as hh
+    if "nn_packed" in info:
+        desc.nn_weights = info["nn_packed"].ctypes.data
+    return hh.primal_history(desc, gh, xi0)
+
+
 @pytest.mark.parametrize("rate", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
@@ -73,12 +80,12 @@ def test_history_objective_grad(def_type, yield_kind, kw, rot, rate, solver_vari
         pytest.skip("one variant: the history loop is the same code on both solver paths")
     if rate and def_type == ol.UNIAXIAL_STRESS:
         pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
-    pc.check_history(_host_history, def_type, yield_kind, kw, rot, rate=rate, B=96, uniaxial_idx=1)
+    pc.check_history(_host_history, def_type, yield_kind, kw, rot, rate=rate, B=96, uniaxial_idx=1, primal=_host_primal)
 
 
 def test_history_objective_grad_with_line_search():
-    pc.check_history(_host_history, ol.FULL_3D, "J2", {}, False, ls=True, B=96)
-    pc.check_history(_host_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=96)
+    pc.check_history(_host_history, ol.FULL_3D, "J2", {}, False, ls=True, B=96, primal=_host_primal)
+    pc.check_history(_host_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=96, primal=_host_primal)
 
 
 @pytest.mark.parametrize("plastic", [True, False])
