@@ -400,9 +400,9 @@ class DeviceEvaluator:
             raise ValueError("a load history needs at least one step after the initial configuration")
         if not (want_xi or want_sigma):
             raise ValueError("request the state history, the stress history or both")
-        _check_soa(gradu_hist[0], self.nu, B, "gradu_hist")
-        if not gradu_hist.is_contiguous():
+        if not (gradu_hist.dim() == 3 and gradu_hist.is_contiguous()):
             raise ValueError("gradu_hist (K+1, n_gradu, B) must be contiguous")
+        _check_soa(gradu_hist[0], self.nu, B, "gradu_hist")
         _check_soa(xi0, self.nx, B, "xi0")
         dev = gradu_hist.device
         xi_hist = torch.empty((K + 1, self.nx, B), dtype=torch.float64, device=dev) if want_xi else None
@@ -420,10 +420,10 @@ class DeviceEvaluator:
         K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
         if K < 1:
             raise ValueError("a load history needs at least one step after the initial configuration")
-        for k in (0, K):
-            _check_soa(gradu_hist[k], self.nu, B, "gradu_hist"); _check_soa(data_hist[k], 6, B, "data_hist")
-        if not (gradu_hist.is_contiguous() and data_hist.is_contiguous() and data_hist.shape[0] == K + 1):
-            raise ValueError("gradu_hist (K+1, n_gradu, B) and data_hist (K+1, 6, B) must be contiguous")
+        if not (gradu_hist.dim() == 3 and data_hist.dim() == 3 and gradu_hist.is_contiguous() and data_hist.is_contiguous()
+                and data_hist.shape[0] == K + 1):
+            raise ValueError("gradu_hist (K+1, n_gradu, B) and data_hist (K+1, 6, B) must be contiguous with the same K")
+        _check_soa(gradu_hist[0], self.nu, B, "gradu_hist"); _check_soa(data_hist[0], 6, B, "data_hist")
         _check_soa(xi0, self.nx, B, "xi0")
         dev = gradu_hist.device
         if xi_hist is None:

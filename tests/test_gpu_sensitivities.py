@@ -274,3 +274,45 @@ def test_history_objective_grad_variants():
     pc.check_history(_gpu_history, ol.FULL_3D, "J2", {}, False, ls=True, B=700, primal=_gpu_primal)
     pc.check_history(_gpu_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=700, primal=_gpu_primal)
     pc.check_history(_gpu_history, ol.PLANE_STRESS, "hosford", pc.YIELDS[2][1], True, rate=True, ls=True, B=700, primal=_gpu_primal)
+
+
+def test_history_entries_edge_cases():
+    """Empty batch (J = 0, grad = 0, nothing read), operand checks before any launch, and an iteration cap that leaves
+    steps unconverged: like the reference (Newton failure is not an error) the history carries the last iterate on,
+    exactly as the same number of single-step calls does, and reports it in the per-step status."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, NewtonSettings, build_desc, fold_weight_and_data
+    from cmad_amd.synthetic import gauss_point_batch
+    values = ol.j2_voce_values()
+    desc, info = build_desc(values)
+    ev = DeviceEvaluator(desc, info)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    wsq6 = fold_weight_and_data(np.eye(3))
+    out, xh = ev.objective_grad_history(torch.empty((4, 9, 0), **f64), torch.empty((4, 6, 0), **f64), wsq6, torch.empty((7, 0), **f64))
+    assert xh.shape == (4, 7, 0) and not out.cpu().numpy().any()
+    xh, sh, st = ev.update_history(torch.empty((4, 9, 0), **f64), torch.empty((7, 0), **f64))
+    assert xh.shape == (4, 7, 0) and sh.shape == (4, 6, 0) and st.shape == (4, 0)
+    g = torch.zeros((3, 9, 8), **f64)
+    with pytest.raises(ValueError):
+        ev.update_history(g[:1], torch.zeros((7, 8), **f64))                       # no step after the initial one
+    with pytest.raises(ValueError):
+        ev.update_history(g, torch.zeros((8, 8), **f64))                           # wrong n_xi
+    with pytest.raises(ValueError):
+        ev.objective_grad_history(g, torch.zeros((2, 6, 8), **f64), wsq6, torch.zeros((7, 8), **f64))   # K mismatch
+    with pytest.raises(ValueError):
+        ev.objective_grad_history(g.transpose(1, 2), torch.zeros((3, 6, 8), **f64), wsq6, torch.zeros((7, 8), **f64))
+    # iteration cap 1: unconverged iterates are carried from step to step, identically to per-step calls
+    B, K = 300, 3
+    desc1, info1 = build_desc(values, newton=NewtonSettings(max_iters=1))
+    ev1 = DeviceEvaluator(desc1, info1)
+    g0 = gauss_point_batch(B, seed=9, dev_scale=8.0)
+    gh = torch.from_numpy(np.stack([c * g0 for c in (0., 0.6, 1.0, 1.3)])).cuda()
+    xh, sh, st = ev1.update_history(gh, torch.zeros((7, B), **f64))
+    x = torch.zeros((7, B), **f64)
+    for k in range(1, K + 1):
+        x, s, stk = ev1.update(gh[k], x)
+        np.testing.assert_allclose(xh[k].cpu().numpy(), x.cpu().numpy(), rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(sh[k].cpu().numpy(), s.cpu().numpy(), rtol=1e-10, atol=1e-9)
+        mask = 0xFFFF | (1 << 16) | (1 << 18)
+        assert torch.equal(st[k] & mask, stk & mask)
+    assert (((st[1:].cpu().numpy().astype(np.uint32) >> 16) & 1) == 0).any()
