@@ -677,7 +677,7 @@ CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z
 // cmad/objectives/mp_objective.py:62-89 (forward pass with storage) / cmad/cli/primal.py:129-176 without the QoI:
 // xi_hist[(K+1)][NX] rows (slot 0 = initial state), sigma_hist[(K+1)][6] rows (global Cauchy stress; slot 0 = stress of
 // the initial state under gradu_hist[0]) and status_hist[(K+1)] rows are optional (null = not stored).
-template <int DEF, int YK, bool ROT, bool LS, int MK, class IO>
+template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false, class IO>
 CM_D void primal_history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* xi0, double* xi_hist,
                                double* sigma_hist, uint32_t* status_hist, bool valid, LaneStage stage, const IO& io) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
@@ -702,7 +702,7 @@ CM_D void primal_history_point(const cm_model_desc& m, int K, const double* grad
                 strain_from_gradu<DEF, ROT>(m, G, eg);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) xp[i] = x[i];
-                st = newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid, stage);
+                st = newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, stage);
             }
         }
         if (!valid) continue;
@@ -731,7 +731,7 @@ CM_D void primal_history_point(const cm_model_desc& m, int K, const double* grad
 //   io.load<N>(base, step_row0, out) / io.store<N>(base, step_row0, v) / io.phase_barrier()
 // red[0] += J, red[1 + j] += dJ/dp_j (KP order).  MK selects the total-form or the rate-form model (the latter takes
 // grad u of the previous step as well).
-template <int DEF, int YK, bool ROT, bool LS, int MK, class IO>
+template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false, class IO>
 CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* data_hist, const double wsq[6],
                         const double* xi0, double* xi_hist, bool valid, LaneStage stage, const IO& io, double* red) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
@@ -756,7 +756,7 @@ CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist,
 #pragma unroll
         for (int i = 0; i < NX; ++i) xp[i] = x[i];
         if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) newton<DEF, YK, MK, LS>(m, eg, z, xp, x, valid);
-        else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid, stage);
+        else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, stage);
         if (valid) io.template store<NX>(xi_hist, (int64_t)k * NX, x);
     }
     io.phase_barrier();          // tail lanes shadow another lane's point: its stored states must be visible to them

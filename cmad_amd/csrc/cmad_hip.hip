@@ -545,7 +545,7 @@ struct SoaRowsIO {
     __device__ __forceinline__ void store_status(uint32_t* base, int64_t row, uint32_t v) const { (base + row * B)[b] = v; }
 };
 
-template <int DEF, int YK, bool ROT, bool LS, int MK>
+template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false>
 __global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, int K,
         const double* __restrict__ gradu_hist, const double* __restrict__ data_hist, Wsq wsq,
         const double* __restrict__ xi0, double* xi_hist, double* __restrict__ partials) {
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, 
     double red[kRed];
 #pragma unroll
     for (int k = 0; k < kRed; ++k) red[k] = 0.0;
-    history_point<DEF, YK, ROT, LS, MK>(m, K, gradu_hist + blk0, data_hist + blk0, wsq.w, xi0 + blk0, xi_hist + blk0, valid,
+    history_point<DEF, YK, ROT, LS, MK, RL>(m, K, gradu_hist + blk0, data_hist + blk0, wsq.w, xi0 + blk0, xi_hist + blk0, valid,
                                         LaneStage{lds_buf + (STAGED ? threadIdx.x : 0), kBlock}, SoaRowsIO{B, b}, red);
     if (!valid) {
 #pragma unroll
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, 
 }
 
 // ---- cm_update_history: K updates per point in one launch, states / stresses / statuses stored per step ------------
-template <int DEF, int YK, bool ROT, bool LS, int MK>
+template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false>
 __global__ __launch_bounds__(kBlock) void k_primal_history(cm_model_desc m, int64_t B, int K,
         const double* __restrict__ gradu_hist, const double* __restrict__ xi0, double* __restrict__ xi_hist,
         double* __restrict__ sigma_hist, uint32_t* __restrict__ status_hist) {
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void k_primal_history(cm_model_desc m, int6
     const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
     constexpr bool STAGED = LS && MK == CM_SMALL_ELASTIC_PLASTIC && has_structured<DEF, YK>();
     __shared__ double ls_stage[STAGED ? kLsSlots * kBlock : 1];
-    primal_history_point<DEF, YK, ROT, LS, MK>(m, K, gradu_hist + blk0, xi0 + blk0, xi_hist ? xi_hist + blk0 : nullptr,
+    primal_history_point<DEF, YK, ROT, LS, MK, RL>(m, K, gradu_hist + blk0, xi0 + blk0, xi_hist ? xi_hist + blk0 : nullptr,
                                                sigma_hist ? sigma_hist + blk0 : nullptr, status_hist ? status_hist + blk0 : nullptr,
                                                valid, LaneStage{ls_stage + (STAGED ? threadIdx.x : 0), kBlock}, SoaRowsIO{B, b});
 }
@@ -839,6 +839,12 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
         const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && D == CM_FULL_3D && Y == CM_YIELD_J2) {
+                if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                    hipLaunchKernelGGL((k_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials);
+                    return;
+                }
+            }
             if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
                 hipLaunchKernelGGL((k_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials);
         });
@@ -863,6 +869,12 @@ int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double
     const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && D == CM_FULL_3D && Y == CM_YIELD_J2) {
+            if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
+                return;
+            }
+        }
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
             hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
     });

@@ -250,7 +250,16 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
         double parked[2 * 9];
         const LaneStage stage{parked, 1};
         const HostRowsIO io{B, b};
-        if (ls) history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
+        bool done = false;
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && DEF == CM_FULL_3D && YK == CM_YIELD_J2) {   // same choice as launch_history
+            if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                if (ls) history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
+                else history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
+                done = true;
+            }
+        }
+        if (done) {}
+        else if (ls) history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
         else history_point<DEF, YK, ROT, false, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
         for (int k = 0; k < 1 + CM_NUM_PARAMS; ++k) out[k] += red[k];
     }
@@ -264,7 +273,16 @@ static void run_primal_history(const cm_model_desc& m, int64_t B, int K, const d
         double parked[2 * 9];
         const LaneStage stage{parked, 1};
         const HostRowsIO io{B, b};
-        if (ls) primal_history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
+        bool done = false;
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && DEF == CM_FULL_3D && YK == CM_YIELD_J2) {
+            if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                if (ls) primal_history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
+                else primal_history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
+                done = true;
+            }
+        }
+        if (done) {}
+        else if (ls) primal_history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
         else primal_history_point<DEF, YK, ROT, false, MK>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
     }
 }

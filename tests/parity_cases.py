@@ -333,7 +333,7 @@ def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
 
 
 def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, K=5, B=256, seed=22, uniaxial_idx=0,
-                  primal=None):
+                  primal=None, solver_flags=0):
     """Objective + gradient over a K-step history per point (forward updates, adjoint recursion) in one call vs the
     oracle's adjoint (cmad/objectives/mp_objective.py:95-147): J, gradient, every stored state.
     `history(desc, info, gradu_hist, data6_hist, wsq6, xi0) -> (out[13], xi_hist)`.
@@ -348,6 +348,7 @@ def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, 
     mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP if rate else 0, **extra)
     desc, info = build_desc(values, def_type=def_type, model_kind=1 if rate else 0, newton=st_d,
                             **({"uniaxial_stress_idx": uniaxial_idx} if extra else {}))
+    desc.solver_flags = solver_flags                    # 2 = CM_SOLVER_GENERAL_NEWTON (no J2 radial-line restriction)
     if def_type == ol.UNIAXIAL_STRESS:
         g0 = np.random.default_rng(seed + 2).uniform(-4e-3, 4e-3, size=(1, B))
     else:

@@ -272,6 +272,8 @@ def test_history_objective_grad_variants():
     """Line search variants, the hybrid network and Barlat surfaces, and the fused history against the per-step
     launches of BatchedCalibrationObjective."""
     pc.check_history(_gpu_history, ol.FULL_3D, "J2", {}, False, ls=True, B=700, primal=_gpu_primal)
+    pc.check_history(_gpu_history, ol.FULL_3D, "J2", {}, True, ls=True, B=700, primal=_gpu_primal, solver_flags=2)
+    pc.check_history(_gpu_history, ol.FULL_3D, "J2", {}, False, B=700, primal=_gpu_primal, solver_flags=2)
     pc.check_history(_gpu_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=700, primal=_gpu_primal)
     pc.check_history(_gpu_history, ol.PLANE_STRESS, "hosford", pc.YIELDS[2][1], True, rate=True, ls=True, B=700, primal=_gpu_primal)
 

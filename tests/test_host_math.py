@@ -85,6 +85,8 @@ def test_history_objective_grad(def_type, yield_kind, kw, rot, rate, solver_vari
 
 def test_history_objective_grad_with_line_search():
     pc.check_history(_host_history, ol.FULL_3D, "J2", {}, False, ls=True, B=96, primal=_host_primal)
+    pc.check_history(_host_history, ol.FULL_3D, "J2", {}, True, ls=True, B=96, primal=_host_primal, solver_flags=2)
+    pc.check_history(_host_history, ol.FULL_3D, "J2", {}, False, B=96, primal=_host_primal, solver_flags=2)
     pc.check_history(_host_history, ol.PLANE_STRESS, "hill", pc.YIELDS[1][1], True, ls=True, B=96, primal=_host_primal)
 
 
