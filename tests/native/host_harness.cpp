@@ -396,6 +396,9 @@ int hh_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gr
 }
 #endif
 #if HH_HAS(0)
+void hh_exp_s(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n; ++i) y[i] = exp_s(x[i]); }
+#endif
+#if HH_HAS(0)
 void hh_set_dense(int d) { g_dense = d; }
 #endif
 #if HH_HAS(0)

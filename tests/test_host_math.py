@@ -446,3 +446,24 @@ def test_rate_form_vjp(def_type, yield_kind, kw, rot, solver_variant):
     if solver_variant == "dense":
         pytest.skip("rate form always uses the dense path")
     pc.check_rate_vjp(lambda desc, info, g, gp, xp, x, sb: hh.vjp_rate(desc, g, gp, xp, x, sb), def_type, yield_kind, kw, rot, B=192)
+
+
+def test_exp_s():
+    """cm::exp_s (the exponential of the hardening laws, scalar-register coefficients on the device) against libm:
+    below 1 ulp on the working range, monotone limits outside."""
+    import ctypes as C
+    import numpy as np
+    import host_harness_lib as hh
+    L = hh.lib()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-40., 40., 200000), rng.uniform(-1., 1., 200000), -np.logspace(-18, 2.8, 2000),
+                        np.array([0., -0., 1e-300, -1e-300, 709.7, -745.1, -800., 800., 1e6, -1e6, np.inf, -np.inf])])
+    y = np.zeros_like(x)
+    L.hh_exp_s(C.c_int64(x.size), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+    with np.errstate(over="ignore"):
+        ref = np.exp(np.clip(x, -1100., 1100.))
+    fin = np.isfinite(ref) & (ref > 1e-300)
+    ulp = np.abs(y[fin] - ref[fin]) / np.spacing(ref[fin])
+    assert ulp.max() <= 1.0, ulp.max()
+    assert np.mean(ulp == 0) > 0.7
+    assert (y[x > 710.] == np.inf).all() and (y[x < -746.] == 0.).all()
