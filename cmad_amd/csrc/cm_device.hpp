@@ -195,12 +195,37 @@ CM_D QuadForm quad_form(const cm_model_desc& m) {
 // 1/2 (f(x) + f(-x)), so both signs share one pass over the hidden units (one dot product, one rank-1 Hessian
 // update per unit; the pass-through x . Wx1 cancels):
 //   F = f(x) + f(-x),  G = grad f(x) - grad f(-x) = d F / d x,  Hx = d2 F / d x2      (w.r.t. the SCALED input xs)
+// log(1 + t) for t in [0, 1] in ~28 VALU instructions (the math library's log1p takes ~65): with v = 1 + t, halved when
+// above sqrt(2), log v = 2 atanh(s), s = (v - 1) / (v + 1) within +-0.1716, by the odd series up to s^21 / 21 (truncation
+// 6e-19 relative); numerator and denominator are formed from t directly, so small t keeps full relative accuracy.
+// tests/test_host_math.py::test_softplus_pieces checks it against libm (<= 2 ulp).
+CM_D double log1p_01(double t) {
+    const bool hi = t > 0.41421356237309503;
+    const double num = hi ? t - 1.0 : t;
+    const double den = hi ? t + 3.0 : t + 2.0;
+    const double s = num * rcp(den);
+    const double s2 = s * s;
+    double p = CM_SCALAR(1.0 / 21.0);
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 19.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 17.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 15.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 13.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 11.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 9.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 7.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 5.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 3.0));
+    const double two_s = s + s;
+    const double r = __builtin_fma(two_s * s2, p, two_s);
+    return hi ? r + 0.6931471805599453 : r;
+}
+
 struct SoftUnit { double sp, sg; };
 CM_D SoftUnit soft_unit(double a) {
-    const double e = exp(-fabs(a));
-    const double inv = 1.0 / (1.0 + e);
+    const double e = exp_s(-fabs(a));                           // in (0, 1]
+    const double inv = rcp(1.0 + e);
     SoftUnit u;
-    u.sp = fmax(a, 0.0) + log1p(e);                             // jax.nn.softplus = logaddexp(a, 0)
+    u.sp = fmax(a, 0.0) + log1p_01(e);                          // jax.nn.softplus = logaddexp(a, 0)
     u.sg = (a >= 0.0) ? inv : e * inv;                          // sigmoid(a)
     return u;
 }

@@ -396,6 +396,12 @@ int hh_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gr
 }
 #endif
 #if HH_HAS(0)
+void hh_log1p_01(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n; ++i) y[i] = log1p_01(x[i]); }
+void hh_soft_unit(int64_t n, const double* x, double* sp, double* sg) {
+    for (int64_t i = 0; i < n; ++i) { const SoftUnit u = soft_unit(x[i]); sp[i] = u.sp; sg[i] = u.sg; }
+}
+#endif
+#if HH_HAS(0)
 void hh_exp_s(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n; ++i) y[i] = exp_s(x[i]); }
 #endif
 #if HH_HAS(0)

@@ -467,3 +467,30 @@ def test_exp_s():
     assert ulp.max() <= 1.0, ulp.max()
     assert np.mean(ulp == 0) > 0.7
     assert (y[x > 710.] == np.inf).all() and (y[x < -746.] == 0.).all()
+
+
+def test_softplus_pieces():
+    """cm::log1p_01 (log(1 + t), t in [0, 1]) and cm::soft_unit (softplus and sigmoid of the network surfaces) against
+    libm / the stable closed forms."""
+    import ctypes as C
+    import numpy as np
+    import host_harness_lib as hh
+    L = hh.lib()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(1)
+    t = np.concatenate([rng.uniform(0., 1., 300000), np.logspace(-320, 0, 3000), np.array([0., 1., 0.41421356237309503, 0.4142135623730951])])
+    y = np.zeros_like(t)
+    L.hh_log1p_01(C.c_int64(t.size), vp(t), vp(y))
+    ref = np.log1p(t)
+    nz = ref > 0
+    assert (y[~nz] == 0.).all()
+    ulp = np.abs(y[nz] - ref[nz]) / np.spacing(ref[nz])
+    assert ulp.max() <= 2.0, ulp.max()
+    a = np.concatenate([rng.uniform(-40., 40., 200000), rng.uniform(-2., 2., 100000), np.array([0., -0., 745., -745., 1e4, -1e4])])
+    sp, sg = np.zeros_like(a), np.zeros_like(a)
+    L.hh_soft_unit(C.c_int64(a.size), vp(a), vp(sp), vp(sg))
+    with np.errstate(over="ignore"):
+        sp_ref = np.logaddexp(a, 0.)
+        sg_ref = np.where(a >= 0, 1. / (1. + np.exp(-np.abs(a))), np.exp(-np.abs(a)) / (1. + np.exp(-np.abs(a))))
+    np.testing.assert_allclose(sp, sp_ref, rtol=1e-15, atol=1e-320)
+    np.testing.assert_allclose(sg, sg_ref, rtol=1e-15, atol=1e-320)
