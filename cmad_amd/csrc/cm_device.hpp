@@ -220,6 +220,15 @@ CM_D double log1p_01(double t) {
     return hi ? r + 0.6931471805599453 : r;
 }
 
+// log(S) for S in [1/2, 2] with an ABSOLUTE error of ~1e-16 (enough where the result is scaled down and exponentiated,
+// as in S^(1/a)): S or 2 S is brought into [1, 2] and handed to log1p_01.
+CM_D double log_near_one(double S) {
+    const bool lo = S < 1.0;
+    const double t = lo ? __builtin_fma(2.0, S, -1.0) : S - 1.0;
+    const double r = log1p_01(t);
+    return lo ? r - 0.6931471805599453 : r;
+}
+
 struct SoftUnit { double sp, sg; };
 CM_D SoftUnit soft_unit(double a) {
     const double e = exp_s(-fabs(a));                           // in (0, 1]
@@ -665,14 +674,15 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
         const double dd[3] = {s[0] - s[3], s[3] - s[5], s[5] - s[0]};
         const double t0 = fabs(dd[0]), t1 = fabs(dd[1]), t2 = fabs(dd[2]);
         const double mx = fmax(t0, fmax(t1, t2));
-        const double imx = (mx > 0.0) ? 1.0 / mx : 0.0;             // equal normal stresses: phi = 0, normal := 0
+        const double imx = (mx > 0.0) ? rcp(mx) : 0.0;              // equal normal stresses: phi = 0, normal := 0
         const double u[3] = {t0 * imx, t1 * imx, t2 * imx};
         // u_i^a (u_i in [0,1]); (|d_i|/phi)^(a-2) = u_i^a Sr^2 / (u_i^2 S) -- no further pow.
         // Integer exponents (the usual case: 6, 8, 100) by repeated squaring, ~log2(a) multiplications per term
         // and a few ulp; anything else as exp(a log u).  `a` is a kernel argument, so the branch is uniform.
         double ua[3];
         const int ai = (int)a;
-        if (a == (double)ai && ai >= 2 && ai <= 65536) {
+        const bool int_pow = (a == (double)ai && ai >= 2 && ai <= 65536);
+        if (int_pow) {
             double base[3] = {u[0], u[1], u[2]};
             ua[0] = ua[1] = ua[2] = 1.0;
             for (int e = ai; e != 0; e >>= 1) {
@@ -684,15 +694,27 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
             for (int i = 0; i < 3; ++i) ua[i] = (u[i] > 0.0) ? exp(a * log(u[i])) : 0.0;
         }
         const double S = 0.5 * (ua[0] + ua[1] + ua[2]);
-        const double Sr = (S > 0.0) ? exp(log(S) / a) : 0.0;
+        // S^(1/a): max u_i = 1 puts S in [1/2, 3/2] whenever it is non-zero, so the short logarithm applies; reciprocals by
+        // rcp (1 ulp) instead of the IEEE division sequence on the integer-exponent path (7 of them per evaluation)
+        double Sr, iSr, iS;
+        if (int_pow) {
+            Sr = (S > 0.0) ? exp_s(log_near_one(S) * rcp(a)) : 0.0;
+            iSr = (S > 0.0) ? rcp(Sr) : 0.0;
+            iS = (S > 0.0) ? rcp(S) : 0.0;
+        } else {
+            Sr = (S > 0.0) ? exp(log(S) / a) : 0.0;
+            iSr = (S > 0.0) ? 1.0 / Sr : 0.0;
+            iS = (S > 0.0) ? 1.0 / S : 0.0;
+        }
         phi = mx * Sr;
         double p[3], r[3], sg[3], ram2[3];
-        const double c2 = (S > 0.0) ? Sr * Sr / S : 0.0;
+        const double c2 = Sr * Sr * iS;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            r[i] = (S > 0.0) ? u[i] / Sr : 0.0;                 // |d_i| / phi
+            r[i] = u[i] * iSr;                                  // |d_i| / phi
             sg[i] = (dd[i] > 0.0) ? 1.0 : ((dd[i] < 0.0) ? -1.0 : 0.0);
-            ram2[i] = (u[i] > 0.0) ? ua[i] * c2 / (u[i] * u[i]) : ((a == 2.0) ? 1.0 : 0.0);
+            const double iu = (u[i] > 0.0) ? (int_pow ? rcp(u[i]) : 1.0 / u[i]) : 0.0;
+            ram2[i] = (u[i] > 0.0) ? ua[i] * c2 * iu * iu : ((a == 2.0) ? 1.0 : 0.0);
             p[i] = 0.5 * ram2[i] * r[i] * sg[i];               // d phi / d d_i
         }
 #pragma unroll
@@ -704,7 +726,7 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 #pragma unroll
                 for (int l = 0; l < 6; ++l) Ht[k][l] = 0.0;
             double Hd[3][3];
-            const double ip = (phi > 0.0) ? 1.0 / phi : 0.0;
+            const double ip = (phi > 0.0) ? rcp(phi) : 0.0;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
