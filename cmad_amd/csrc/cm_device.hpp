@@ -73,6 +73,9 @@ CM_D double exp_s(double x) {
     return __builtin_ldexp(p, (int)k);
 }
 
+// 1 / (2 mu), the residual's scale factor (elastic_stress.py:71-72); every other division by mu is a product with it
+CM_D double half_over_mu(const cm_model_desc& m) { return 0.5 / m.mu; }   // one expression everywhere: a single division per kernel
+
 constexpr double kIW[6] = {1.0, 0.5, 0.5, 1.0, 0.5, 1.0};   // 1 / w_k
 constexpr double kW[6] = {1.0, 2.0, 2.0, 1.0, 2.0, 1.0};
 constexpr bool kDiag[6] = {true, false, false, true, false, true};
@@ -821,7 +824,7 @@ CM_D void residual(const cm_model_desc& m, const double eg[6], const double z[6]
     strain_stress<DEF>(m, eg, z, x, ev);
     yield_eval<YK, HESS>(m, ev.s, ev.phi, ev.gt, Ht);
     ev.hd = hardening(m, x[6]);
-    const double i2mu = 0.5 / m.mu;
+    const double i2mu = half_over_mu(m);
     ev.f = (ev.phi - (m.Y + ev.hd.H)) * i2mu;
     ev.dgam = x[6] - xp[6];
     ev.plastic = (ev.f > m.yield_tol) || (fabs(ev.f) < m.yield_tol);
@@ -852,7 +855,7 @@ template <int DEF, bool TRANSPOSED>
 CM_D void jacobian_x(const cm_model_desc& m, const double z[6], const Eval<DEF>& ev, const double Ht[6][6],
                      double (&A)[Dims<DEF>::NX][Dims<DEF>::NX]) {
     constexpr int NX = Dims<DEF>::NX;
-    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
 #define CM_A(r, c) (TRANSPOSED ? A[c][r] : A[r][c])
 #pragma unroll
     for (int r = 0; r < NX; ++r)
@@ -985,7 +988,7 @@ CM_D void residual_rate(const cm_model_desc& m, const double deg[6], const doubl
     ev.tr = ev.e[0] + ev.e[3] + ev.e[5];
     yield_eval<YK, HESS>(m, ev.s, ev.phi, ev.gt, Ht);
     ev.hd = hardening(m, x[6]);
-    const double i2mu = 0.5 / m.mu, twomu = 2.0 * m.mu;
+    const double i2mu = half_over_mu(m), twomu = 2.0 * m.mu;
     ev.f = (ev.phi - (m.Y + ev.hd.H)) * i2mu;
     ev.dgam = x[6] - xp[6];
     ev.plastic = (ev.f > m.yield_tol) || (fabs(ev.f) < m.yield_tol);
@@ -1007,7 +1010,7 @@ template <int DEF, bool TRANSPOSED>
 CM_D void jacobian_rate(const cm_model_desc& m, const double z[6], const Eval<DEF>& ev, const double Ht[6][6],
                         double (&A)[Dims<DEF>::NX][Dims<DEF>::NX]) {
     constexpr int NX = Dims<DEF>::NX;
-    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
 #define CM_A(r, c) (TRANSPOSED ? A[c][r] : A[r][c])
 #pragma unroll
     for (int r = 0; r < NX; ++r)
@@ -1277,7 +1280,7 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
         for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
     lu_subst<NX>(At, lam);
-    const double i2mu = 0.5 / m.mu;
+    const double i2mu = half_over_mu(m);
     // ---- u_k = -dgam lam_k / w_k (plastic rows), hu = Ht u
     double u[6], hu[6];
 #pragma unroll
@@ -1296,14 +1299,14 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
         const double sbd = sbm[0] + sbm[3] + sbm[5], sbe = dot<6>(sbm, ev.e);
         // lam . dC/dp
         double cl = hud * ev.tr + lam6 * gd * ev.tr * i2mu;                        // lambda
-        double cm_ = 2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f / m.mu);           // mu
+        double cm_ = 2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f * 2.0 * i2mu);           // mu
         if constexpr (DEF == CM_PLANE_STRESS) {
             const double zt = z[0] + z[3] + z[5];
             double zwe = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) zwe += kW[k] * z[k] * ev.e[k];
             cl += lam[7] * zt * ev.tr * i2mu;
-            cm_ += lam[7] * (2.0 * zwe * i2mu - C[7] / m.mu);
+            cm_ += lam[7] * (2.0 * zwe * i2mu - C[7] * 2.0 * i2mu);
         }
         if constexpr (DEF == CM_UNIAXIAL_STRESS) {
 #pragma unroll
@@ -1314,7 +1317,7 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
 #pragma unroll
                 for (int k = 0; k < 6; ++k) zwe += kW[k] * Z[k] * ev.e[k];
                 cl += lam[7 + j] * zt * ev.tr * i2mu;
-                cm_ += lam[7 + j] * (2.0 * zwe * i2mu - C[7 + j] / m.mu);
+                cm_ += lam[7 + j] * (2.0 * zwe * i2mu - C[7 + j] * 2.0 * i2mu);
             }
         }
         pbar[CM_P_LAMBDA] = sbd * ev.tr - cl;
@@ -1388,7 +1391,7 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
     residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
     jacobian_x<DEF, false>(m, z, ev, Ht, A);
     const bool ok = lu_factor<NX>(A);
-    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
     const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
 #pragma unroll
     for (int l = 0; l < 6; ++l) {
@@ -1468,7 +1471,7 @@ CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const 
         for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
     lu_subst<NX>(At, lam);
-    const double i2mu = 0.5 / m.mu;
+    const double i2mu = half_over_mu(m);
     const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
     const double dgp = ev.plastic ? ev.dgam : 0.0;
     double n[6], cn[6];
@@ -1491,13 +1494,13 @@ CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const 
         for (int k = 0; k < 6; ++k) { le += lam[k] * ev.e[k]; ln += lam[k] * n[k]; lc += lam[k] * C[k]; }
         // lam . dC/dlambda , lam . dC/dmu
         double cl = ld * (-ev.tr + dgp * gd) * i2mu;
-        double cm_ = (-2.0 * le + dgp * 2.0 * ln) * i2mu - lc / m.mu + lam6 * (-ev.f / m.mu);
+        double cm_ = (-2.0 * le + dgp * 2.0 * ln) * i2mu - lc * 2.0 * i2mu + lam6 * (-ev.f * 2.0 * i2mu);
         if constexpr (PS) {
             double zwe = 0.0, zwn = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { zwe += zw[k] * ev.e[k]; zwn += zw[k] * n[k]; }
             cl += lam7 * zt * (ev.tr - dgp * gd) * i2mu;
-            cm_ += lam7 * ((2.0 * zwe - dgp * 2.0 * zwn) * i2mu - C[7] / m.mu);
+            cm_ += lam7 * ((2.0 * zwe - dgp * 2.0 * zwn) * i2mu - C[7] * 2.0 * i2mu);
         }
         pbar[CM_P_LAMBDA] = -cl;
         pbar[CM_P_MU] = -cm_;
@@ -1576,7 +1579,7 @@ CM_D bool tangent_point_rate(const cm_model_desc& m, const double deg[6], const 
     residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
     jacobian_rate<DEF, false>(m, z, ev, Ht, A);
     const bool ok = lu_factor<NX>(A);
-    const double i2mu = 0.5 / m.mu;
+    const double i2mu = half_over_mu(m);
     double czw[6];
     if constexpr (DEF == CM_PLANE_STRESS) {
         double zw[6];
@@ -1617,7 +1620,7 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
     strain_z<DEF, ROT>(m, z);
     residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
     to_global<ROT>(m, ev.s, sg);
-    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
     const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
     if (which == CM_W_NONE) return;
     // material-frame stress derivative columns ds[6] per column, then rotated
@@ -1672,7 +1675,7 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
                 J[k * NP_ + CM_P_MU] = -ev.dgam * kIW[k] * He[k];
             }
             J[6 * NP_ + CM_P_LAMBDA] = gd * ev.tr * i2mu;
-            J[6 * NP_ + CM_P_MU] = ge2 * i2mu - ev.f / m.mu;
+            J[6 * NP_ + CM_P_MU] = ge2 * i2mu - ev.f * 2.0 * i2mu;
             J[6 * NP_ + CM_P_Y] = -i2mu;
             if (m.has_voce) {
                 J[6 * NP_ + CM_P_VOCE_S] = -(1.0 - ev.hd.expo) * i2mu;
@@ -1704,7 +1707,7 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
                 double zwe = 0.0;
                 for (int k = 0; k < 6; ++k) zwe += kW[k] * z[k] * ev.e[k];
                 J[7 * NP_ + CM_P_LAMBDA] = zt * ev.tr * i2mu;
-                J[7 * NP_ + CM_P_MU] = 2.0 * zwe * i2mu - C[7] / m.mu;
+                J[7 * NP_ + CM_P_MU] = 2.0 * zwe * i2mu - C[7] * 2.0 * i2mu;
             }
         }
         if constexpr (DEF == CM_UNIAXIAL_STRESS) {
@@ -1715,7 +1718,7 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
                     double zwe = 0.0;
                     for (int k = 0; k < 6; ++k) zwe += kW[k] * Z[k] * ev.e[k];
                     J[(7 + j) * NP_ + CM_P_LAMBDA] = zt * ev.tr * i2mu;
-                    J[(7 + j) * NP_ + CM_P_MU] = 2.0 * zwe * i2mu - C[7 + j] / m.mu;
+                    J[(7 + j) * NP_ + CM_P_MU] = 2.0 * zwe * i2mu - C[7 + j] * 2.0 * i2mu;
                 }
             }
         }
@@ -1772,7 +1775,7 @@ CM_D void evaluate_blocks_rate(const cm_model_desc& m, const double* G, const do
     residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
     to_global<ROT>(m, x, sg);
     if (which == CM_W_NONE) return;
-    const double twomu = 2.0 * m.mu, i2mu = 0.5 / m.mu, lam = m.lambda;
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
     const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? NP_ : NU);
     if (S) for (int i = 0; i < 6 * ncols; ++i) S[i] = 0.0;
     if (J) for (int i = 0; i < NX * ncols; ++i) J[i] = 0.0;
@@ -1812,10 +1815,10 @@ CM_D void evaluate_blocks_rate(const cm_model_desc& m, const double* G, const do
             for (int k = 0; k < 6; ++k) {
                 const double nk = ev.plastic ? n[k] : 0.0;
                 J[k * NP_ + CM_P_LAMBDA] = (kDiag[k] ? (-ev.tr + dgp * trn) : 0.0) * i2mu;
-                J[k * NP_ + CM_P_MU] = (-2.0 * ev.e[k] + dgp * 2.0 * nk) * i2mu - C[k] / m.mu;
+                J[k * NP_ + CM_P_MU] = (-2.0 * ev.e[k] + dgp * 2.0 * nk) * i2mu - C[k] * 2.0 * i2mu;
             }
             if (ev.plastic) {
-                J[6 * NP_ + CM_P_MU] = -ev.f / m.mu;
+                J[6 * NP_ + CM_P_MU] = -ev.f * 2.0 * i2mu;
                 J[6 * NP_ + CM_P_Y] = -i2mu;
                 if (m.has_voce) {
                     J[6 * NP_ + CM_P_VOCE_S] = -(1.0 - ev.hd.expo) * i2mu;
@@ -1847,7 +1850,7 @@ CM_D void evaluate_blocks_rate(const cm_model_desc& m, const double* G, const do
                 double zwe = 0.0, zwn = 0.0;
                 for (int k = 0; k < 6; ++k) { zwe += kW[k] * z[k] * ev.e[k]; zwn += kW[k] * z[k] * n[k]; }
                 J[7 * NP_ + CM_P_LAMBDA] = zt * (ev.tr - dgp * trn) * i2mu;
-                J[7 * NP_ + CM_P_MU] = (2.0 * zwe - dgp * 2.0 * zwn) * i2mu - C[7] / m.mu;
+                J[7 * NP_ + CM_P_MU] = (2.0 * zwe - dgp * 2.0 * zwn) * i2mu - C[7] * 2.0 * i2mu;
                 if constexpr (YK == CM_YIELD_HILL) {
                     if (ev.plastic) for (int j = 0; j < 6; ++j) {
                         double cdn[6], r = 0.0;

@@ -121,7 +121,7 @@ CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* z
     for (int k = 0; k < 6; ++k) ev.s[k] = twomu * ev.e[k] + (kDiag[k] ? lt : 0.0);
     yield_eval_s<YK>(m, ev.s, ev.y);
     if constexpr (!KNOWN_HD) ev.hd = hardening(m, x[6]);
-    const double i2mu = 0.5 / m.mu;
+    const double i2mu = half_over_mu(m);
     ev.f = (ev.y.phi - (m.Y + ev.hd.H)) * i2mu;
     ev.dgam = x[6] - xp[6];
     ev.plastic = (ev.f > m.yield_tol) || (fabs(ev.f) < m.yield_tol);
@@ -172,7 +172,7 @@ CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOp& op) {
         op.ok = fabs(a) > 1e-300;
         op.inv3[0] = rcp(a); op.inv3[1] = 0.5 * br;
         op.eta = br;
-        op.j66 = -ev.hd.dH * 0.5 / m.mu;
+        op.j66 = -ev.hd.dH * half_over_mu(m);
         op.k = 1.0 + op.j66 * op.eta;
         return;
     }
@@ -190,7 +190,7 @@ CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOp& op) {
     op.inv3[3] = c33 * id; op.inv3[4] = c35 * id; op.inv3[5] = c55 * id;
     op.ib[0] = rcp(b1); op.ib[1] = rcp(b2); op.ib[2] = rcp(b4);
     op.eta = b * y.rho;
-    op.j66 = -ev.hd.dH * 0.5 / m.mu;
+    op.j66 = -ev.hd.dH * half_over_mu(m);
     op.k = 1.0 + op.j66 * op.eta;
 }
 
@@ -264,7 +264,7 @@ struct Border {
 };
 template <int YK>
 CM_D void border_build(const cm_model_desc& m, const PlasticOp& op, const EvalS<YK>& ev, const double z[6], Border& bd) {
-    const double l2m = m.lambda * 0.5 / m.mu, zt = z[0] + z[3] + z[5];
+    const double l2m = m.lambda * half_over_mu(m), zt = z[0] + z[3] + z[5];
     double dd = l2m * zt * zt;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -447,7 +447,7 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
     residual_s<CM_YIELD_J2>(m, eg, x, xp, ev, C);              // trial state: phi_trial, normal, f0
     const double n0sq = dot<7>(C, C);
     const double rel2 = m.rel_tol * m.rel_tol * n0sq, abs2 = m.abs_tol * m.abs_tol;
-    const double phi_tr = ev.y.phi, i2mu = 0.5 / m.mu, three_mu = 3.0 * m.mu, alpha_p = xp[6];
+    const double phi_tr = ev.y.phi, i2mu = half_over_mu(m), three_mu = 3.0 * m.mu, alpha_p = xp[6];
     double alpha = alpha_p, f = C[6], dH = ev.hd.dH;
     int it = 0;
     bool running = lane_valid, fallback = false;
@@ -530,7 +530,7 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
         for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
     const bool ok = solve_s<DEF, true>(m, op, ev, z, lam, lam);
-    const double i2mu = 0.5 / m.mu;
+    const double i2mu = half_over_mu(m);
     const YieldS<YK>& y = ev.y;
     double u[6], hu[6];
 #pragma unroll
@@ -541,14 +541,14 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
         const double ge = dot<6>(y.gt, ee), hue = dot<6>(hu, ee);
         const double sbd = sbm[0] + sbm[3] + sbm[5], sbe = dot<6>(sbm, ee);
         // lam[0:7] . dC/dlambda = 0 for a pressure-independent surface (Ht d = 0, gt . d = 0)
-        double cl = 0.0, cm_ = 2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f / m.mu);
+        double cl = 0.0, cm_ = 2.0 * hue + lam6 * (2.0 * ge * i2mu - ev.f * 2.0 * i2mu);
         if constexpr (PS) {
             const double zt = z[0] + z[3] + z[5];
             double zwe = 0.0, zws = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { zwe += kW[k] * z[k] * ee[k]; zws += kW[k] * z[k] * ss[k]; }
             cl = lam[7] * zt * etr * i2mu;
-            cm_ += lam[7] * (2.0 * zwe * i2mu - zws * i2mu / m.mu);      // C7 = (w o z) . s / 2mu
+            cm_ += lam[7] * (2.0 * zwe * i2mu - zws * i2mu * 2.0 * i2mu);      // C7 = (w o z) . s / 2mu
         }
         pbar[CM_P_LAMBDA] = sbd * etr - cl;
         pbar[CM_P_MU] = 2.0 * sbe - cm_;
@@ -621,7 +621,7 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
         b[6] = ev.plastic ? -y.gt[l] : 0.0;
         if constexpr (PS) {                                           // -dC7/deg_l = -(Cel (w o z))_l / 2mu
             const double zt = z[0] + z[3] + z[5];
-            b[7] = -(kW[l] * z[l] + (kDiag[l] ? m.lambda * 0.5 / m.mu * zt : 0.0));
+            b[7] = -(kW[l] * z[l] + (kDiag[l] ? m.lambda * half_over_mu(m) * zt : 0.0));
         }
         ok = solve_s<DEF, false>(m, op, ev, z, b, b) && ok;
         double de[6], ds[6];
