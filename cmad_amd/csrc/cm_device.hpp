@@ -1878,4 +1878,43 @@ CM_D void evaluate_blocks_rate(const cm_model_desc& m, const double* G, const do
     }
 }
 
+// ---- forward (direct) parameter sensitivities of one converged step -------------------------------------------------
+// cmad/objectives/mp_objective.py:158-215 (MPDirectObjective): with A = dC/dxi at the converged state,
+//   dxi/dp = -A^-1 (dC/dp + dC/dxi_prev dxi_prev/dp) ,  dsigma/dp = dsigma/dp|_xi + dsigma/dxi dxi/dp
+// for the CM_NUM_PARAMS native parameters (KP order).  Built on the explicit blocks of evaluate_blocks[_rate] (the same
+// ones the stateful evaluate() surface returns), one LU factorisation and CM_NUM_PARAMS substitutions per point.
+//   dxp_dp [NX][NP] row-major or null (= 0: first step of a history) -> dx_dp [NX][NP], ds_dp [6][NP] (global stress; may be null)
+template <int MK, int DEF, int YK, bool ROT>
+CM_D bool direct_point(const cm_model_desc& m, const double* G, const double* Gp, const double* x, const double* xp,
+                       const double* dxp_dp, double* dx_dp, double* ds_dp) {
+    constexpr int NX = Dims<DEF>::NX, NP_ = CM_NUM_PARAMS;
+    double C[NX], sg[6], Ax[NX * NX], Sx[6 * NX], Cp[NX * NP_], Sp[6 * NP_], Axp[NX * NX];
+    auto blocks = [&](int which, double* J, double* S) {
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, which, C, J, sg, S);
+        else evaluate_blocks<DEF, YK, ROT>(m, G, x, xp, which, C, J, sg, S);
+    };
+    blocks(CM_W_XI, Ax, Sx);
+    blocks(CM_W_PARAMS, Cp, Sp);
+    double A[NX][NX];
+    for (int i = 0; i < NX; ++i) for (int j = 0; j < NX; ++j) A[i][j] = Ax[i * NX + j];
+    const bool ok = lu_factor<NX>(A);
+    if (dxp_dp) blocks(CM_W_XI_PREV, Axp, nullptr);
+    for (int j = 0; j < NP_; ++j) {
+        double rhs[NX];
+        for (int i = 0; i < NX; ++i) {
+            double t = Cp[i * NP_ + j];
+            if (dxp_dp) for (int k = 0; k < NX; ++k) t += Axp[i * NX + k] * dxp_dp[k * NP_ + j];
+            rhs[i] = -t;
+        }
+        lu_subst<NX>(A, rhs);
+        for (int i = 0; i < NX; ++i) dx_dp[i * NP_ + j] = rhs[i];
+        if (ds_dp) for (int r = 0; r < 6; ++r) {
+            double t = Sp[r * NP_ + j];
+            for (int k = 0; k < NX; ++k) t += Sx[r * NX + k] * rhs[k];
+            ds_dp[r * NP_ + j] = t;
+        }
+    }
+    return ok;
+}
+
 }  // namespace cm

@@ -635,6 +635,23 @@ __global__ __launch_bounds__(64) void k_evaluate_rate(cm_model_desc m, int64_t B
     }
 }
 
+// ---- cm_direct_step: forward parameter sensitivities of one converged step (cm::direct_point) ------------------------
+template <int DEF, int YK, bool ROT, int MK>
+__global__ __launch_bounds__(64) void k_direct_step(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
+        const double* __restrict__ xi, const double* __restrict__ dxp_dp, double* __restrict__ dx_dp, double* __restrict__ ds_dp) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double G[NU], Gp[NU], xp[NX], x[NX], din[NX * NP_], dout[NX * NP_], dsig[6 * NP_];
+    for (int k = 0; k < NU; ++k) { G[k] = gradu[(int64_t)k * B + b]; Gp[k] = gradu_prev ? gradu_prev[(int64_t)k * B + b] : 0.0; }
+    for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + b]; x[k] = xi[(int64_t)k * B + b]; }
+    if (dxp_dp) for (int i = 0; i < NX * NP_; ++i) din[i] = dxp_dp[(int64_t)i * B + b];
+    direct_point<MK, DEF, YK, ROT>(m, G, Gp, x, xp, dxp_dp ? din : nullptr, dout, ds_dp ? dsig : nullptr);
+    for (int i = 0; i < NX * NP_; ++i) dx_dp[(int64_t)i * B + b] = dout[i];
+    if (ds_dp) for (int i = 0; i < 6 * NP_; ++i) ds_dp[(int64_t)i * B + b] = dsig[i];
+}
+
 // ---- cm_hessians: one thread per (point, pair of differentiation variables) -----------------------------------
 template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 __global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
@@ -890,6 +907,25 @@ int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double
     return check_launch();
 }
 
+template <int MK>
+int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
+                       const double* xi, const double* dxp_dp, double* dx_dp, double* ds_dp, void* stream) {
+    if (!m || B < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS)) return CM_ERR_UNSUPPORTED;
+    if (B == 0) return CM_OK;
+    if (!gradu || !xi_prev || !xi || !dx_dp || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+            hipLaunchKernelGGL((k_direct_step<D, Y, R, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+
 #if CM_HAS_PART(6)
 template <int MK>
 int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
@@ -1034,6 +1070,16 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
 
 #if CM_HAS_PART(1)
 int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
+#endif
+
+#if CM_HAS_PART(5)
+int cm_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
+                   const double* xi, const double* dxi_prev_dp, double* dxi_dp, double* dsigma_dp, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return launch_direct_step<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, gradu, gradu_prev, xi_prev, xi, dxi_prev_dp, dxi_dp, dsigma_dp, stream);
+    return launch_direct_step<CM_SMALL_ELASTIC_PLASTIC>(m, B, gradu, nullptr, xi_prev, xi, dxi_prev_dp, dxi_dp, dsigma_dp, stream);
+}
 #endif
 
 #if CM_HAS_PART(5)

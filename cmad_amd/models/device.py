@@ -391,6 +391,27 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_objective_grad")
         return res, xi
 
+    def direct_step(self, gradu, xi_prev, xi, dxi_prev_dp=None, want_dsigma=True, gradu_prev=None):
+        """`cm_direct_step`: forward parameter sensitivities of one converged step.  Returns (dxi_dp (n_xi, 12, B),
+        dsigma_dp (6, 12, B) or None), native parameters in KP order; chain the columns to the caller's parameters with
+        `kp_to_leaf_grad` / `Model.active_grad_from_kp`."""
+        torch = _torch()
+        B = gradu.shape[1]
+        NP = _lib.CM_NUM_PARAMS
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev"); _check_soa(xi, self.nx, B, "xi")
+        gp = self._rate_prev(gradu_prev, B)
+        if dxi_prev_dp is not None:
+            if not (dxi_prev_dp.is_cuda and dxi_prev_dp.dtype == torch.float64 and dxi_prev_dp.is_contiguous()
+                    and tuple(dxi_prev_dp.shape) == (self.nx, NP, B)):
+                raise ValueError(f"dxi_prev_dp: expected a contiguous float64 CUDA tensor of shape ({self.nx}, {NP}, {B})")
+        dev = gradu.device
+        dx = torch.empty((self.nx, NP, B), dtype=torch.float64, device=dev)
+        ds = torch.empty((6, NP, B), dtype=torch.float64, device=dev) if want_dsigma else None
+        rc = self.L.cm_direct_step(C.byref(self.desc), B, _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(xi), _ptr(dxi_prev_dp),
+                                   _ptr(dx), _ptr(ds), self._stream())
+        _lib.check(rc, "cm_direct_step")
+        return dx, ds
+
     def update_history(self, gradu_hist, xi0, want_xi=True, want_sigma=True, want_status=True):
         """`cm_update_history`: K updates per point in one launch.  Returns (xi_hist (K+1, n_xi, B),
         sigma_hist (K+1, 6, B), status_hist (K+1, B) int32), None for the ones not requested."""

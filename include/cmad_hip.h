@@ -325,6 +325,20 @@ int cm_objective_grad_history(const cm_model_desc* m, int64_t B, int32_t K,
 int cm_update_history(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi0,
                       double* xi_hist, double* sigma_hist, uint32_t* status_hist, void* stream);
 
+/*
+ * cm_direct_step: forward (direct) parameter sensitivities of one converged step, per point.
+ * Replaces the per-step body of MPDirectObjective._evaluate (cmad/objectives/mp_objective.py:158-215):
+ *   dxi/dp = -(dC/dxi)^-1 (dC/dp + dC/dxi_prev dxi_prev/dp) ,  dsigma/dp = dsigma/dp|_xi + dsigma/dxi dxi/dp
+ * for the CM_NUM_PARAMS native parameters (KP order; columns of coefficients the model does not use are zero).
+ * Both model kinds (gradu_prev: rate form only, NULL otherwise); FULL_3D, PLANE_STRESS, UNIAXIAL_STRESS (total form).
+ *   in : gradu, [gradu_prev,] xi_prev, xi (converged), dxi_prev_dp[n_xi*CM_NUM_PARAMS][B] (NULL = zeros: first step)
+ *   out: dxi_dp[n_xi*CM_NUM_PARAMS][B], entry (k, j) at [(k*CM_NUM_PARAMS + j)*B + b];
+ *        dsigma_dp[6*CM_NUM_PARAMS][B] (global Cauchy stress rows xx,xy,xz,yy,yz,zz; may be NULL)
+ */
+int cm_direct_step(const cm_model_desc* m, int64_t B,
+                   const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
+                   const double* dxi_prev_dp, double* dxi_dp, double* dsigma_dp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

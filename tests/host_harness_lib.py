@@ -104,6 +104,18 @@ def history(desc, gradu_hist, data_hist, wsq6, xi0):
     return out, xi_hist
 
 
+def direct_step(desc, gradu, xi_prev, xi, dxp_dp=None, gradu_prev=None):
+    """cm::direct_point over the batch: dxi_dp (nx, 12, B), dsigma_dp (6, 12, B)."""
+    L = lib()
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    gradu, xi_prev, xi, dxp_dp, gradu_prev = c(gradu), c(xi_prev), c(xi), c(dxp_dp), c(gradu_prev)
+    B, nx = gradu.shape[1], xi.shape[0]
+    dx = np.zeros((nx, 12, B)); ds = np.zeros((6, 12, B))
+    rc = L.hh_direct_step(C.byref(desc), C.c_int64(B), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi), _p(dxp_dp), _p(dx), _p(ds))
+    assert rc == 0
+    return dx, ds
+
+
 def primal_history(desc, gradu_hist, xi0):
     """cm::primal_history_point over the batch: xi_hist (K+1, nx, B), sigma_hist (K+1, 6, B), status_hist (K+1, B)."""
     L = lib()

@@ -395,6 +395,26 @@ int hh_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gr
         run_primal_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
 }
 #endif
+#if HH_HAS(3)
+int hh_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
+                   const double* xi, const double* dxp_dp, double* dx_dp, double* ds_dp) {
+    auto body = [&]<int D, int Y, bool R, int MK>() {
+        constexpr int NX = Dims<D>::NX, NU = Dims<D>::NU, NP_ = CM_NUM_PARAMS;
+        for (int64_t b = 0; b < B; ++b) {
+            double G[NU], Gp[NU], xp[NX], x[NX], din[NX * NP_], dout[NX * NP_], dsig[6 * NP_];
+            for (int k = 0; k < NU; ++k) { G[k] = gradu[k * B + b]; Gp[k] = gradu_prev ? gradu_prev[k * B + b] : 0.0; }
+            for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; }
+            if (dxp_dp) for (int i = 0; i < NX * NP_; ++i) din[i] = dxp_dp[(int64_t)i * B + b];
+            direct_point<MK, D, Y, R>(*m, G, Gp, x, xp, dxp_dp ? din : nullptr, dout, dsig);
+            for (int i = 0; i < NX * NP_; ++i) dx_dp[(int64_t)i * B + b] = dout[i];
+            for (int i = 0; i < 6 * NP_; ++i) ds_dp[(int64_t)i * B + b] = dsig[i];
+        }
+    };
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+}
+#endif
 #if HH_HAS(0)
 void hh_log1p_01(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n; ++i) y[i] = log1p_01(x[i]); }
 void hh_soft_unit(int64_t n, const double* x, double* sp, double* sg) {

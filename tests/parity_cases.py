@@ -391,6 +391,76 @@ def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, 
                                atol=(1e-9 if def_type == ol.UNIAXIAL_STRESS else 1e-11) * np.abs(ref).max())
 
 
+def check_direct(direct, def_type, yield_kind, kw, rot, rate=False, K=3, B=128, seed=22, uniaxial_idx=0, npts=5):
+    """Forward (direct) parameter sensitivities over a K-step history (cmad/objectives/mp_objective.py:158-215):
+    dxi/dp and dsigma/dp per point and step against the recursion written with the oracle's dual-number Jacobians (a few
+    points), and the gradient they give for the calibration objective against the oracle's adjoint (whole batch).
+    `direct(desc, info, gradu, gradu_prev, xi_prev, xi, dxi_prev_dp) -> (dxi_dp (nx, 12, B), dsigma_dp (6, 12, B))`."""
+    from cmad_amd.models.device import build_desc, fold_weight_and_data, kp_to_leaf_grad
+    from cmad_amd.synthetic import gauss_point_batch
+    rng = np.random.default_rng(seed)
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+    st_o, st_d = settings_pair(False)
+    extra = {"uniaxial_idx": uniaxial_idx} if def_type == ol.UNIAXIAL_STRESS else {}
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP if rate else 0, **extra)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1 if rate else 0, newton=st_d,
+                            **({"uniaxial_stress_idx": uniaxial_idx} if extra else {}))
+    if def_type == ol.UNIAXIAL_STRESS:
+        g0 = np.random.default_rng(seed + 2).uniform(-4e-3, 4e-3, size=(1, B))
+    else:
+        g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=3 if def_type == ol.FULL_3D else 2)
+    path = np.array([0., 0.6, 1.1, 1.5, 1.7])[:K + 1]
+    gh = np.stack([c * g0 for c in path])
+    xi0 = np.tile(mat.init_xi()[:, None], (1, B))
+    xs, sig, plastic = [xi0], [np.zeros((6, B))], 0.0
+    for k in range(1, K + 1):
+        x, s_, it, cv = mat.update_batch(st_o, gh[k], xs[-1], gradu_prev=gh[k - 1] if rate else None)
+        assert cv.all()
+        plastic = max(plastic, (it > 0).mean())
+        xs.append(x); sig.append(s_)
+    assert plastic > 0.2
+    paths = param_paths(yield_kind)
+    idx9 = [0, 1, 2, 1, 3, 4, 2, 4, 5]
+    v6 = [0, 1, 2, 4, 5, 8]
+    pts = np.unique(np.linspace(0, B - 1, npts).astype(int))
+    dx_o = {b: np.zeros((mat.nx, ol.NP)) for b in pts}
+    dxp_d = None
+    ds_hist = []
+    for k in range(1, K + 1):
+        dx_d, ds_d = direct(desc, info, gh[k], gh[k - 1] if rate else None, xs[k - 1], xs[k], dxp_d)
+        for b in pts:
+            U, Up = gh[k][:, b], gh[k - 1][:, b]
+            A = mat.jacobian(ol.W_XI, xs[k][:, b], xs[k - 1][:, b], U, Up)
+            Cp = mat.jacobian(ol.W_PARAMS, xs[k][:, b], xs[k - 1][:, b], U, Up)
+            Axp = mat.jacobian(ol.W_XI_PREV, xs[k][:, b], xs[k - 1][:, b], U, Up)
+            dx = -np.linalg.solve(A, Cp + Axp @ dx_o[b])
+            dsg = (mat.dcauchy(ol.W_PARAMS, xs[k][:, b], xs[k - 1][:, b], U, Up)
+                   + mat.dcauchy(ol.W_XI, xs[k][:, b], xs[k - 1][:, b], U, Up) @ dx)[v6]
+            dx_o[b] = dx
+            for pth in paths:
+                got_x = np.array([kp_to_leaf_grad(pth, dx_d[i, :, b], info) for i in range(mat.nx)])
+                got_s = np.array([kp_to_leaf_grad(pth, ds_d[r, :, b], info) for r in range(6)])
+                j = mat.param_index(pth)
+                # (columns that vanish analytically carry round-off of the other columns' size in one of the two)
+                np.testing.assert_allclose(got_x, dx[:, j], rtol=1e-8, atol=1e-9 * np.abs(dx[:, j]).max() + 1e-12 * np.abs(dx).max())
+                np.testing.assert_allclose(got_s, dsg[:, j], rtol=1e-8, atol=1e-9 * np.abs(dsg[:, j]).max() + 1e-12 * np.abs(dsg).max())
+        dxp_d = dx_d
+        ds_hist.append(ds_d)
+    # objective gradient assembled from the direct sensitivities == the adjoint's
+    data6 = [s_ + rng.normal(0., 5., size=s_.shape) for s_ in sig]
+    w = np.zeros((3, 3)); w[0, 0] = 1.; w[1, 1] = 1.; w[0, 1] = 0.5; w[1, 0] = 0.5
+    if def_type == ol.UNIAXIAL_STRESS:
+        w = np.zeros((3, 3)); w[uniaxial_idx, uniaxial_idx] = 1.
+    dh = np.stack([d[idx9, :] for d in data6])
+    _, g_o, _, _ = mat.objective_grad_batch(st_o, gh, dh, w, xi0)
+    wsq6 = np.asarray(fold_weight_and_data(w))
+    g_kp = np.zeros(12)
+    for k in range(1, K + 1):
+        g_kp += np.einsum("r,rb,rjb->j", wsq6, sig[k] - data6[k], ds_hist[k - 1])
+    got, ref = leaf_grads(g_kp, info, mat, yield_kind, g_o)
+    np.testing.assert_allclose(got, ref, rtol=1e-7, atol=(1e-9 if def_type == ol.UNIAXIAL_STRESS else 1e-10) * np.abs(ref).max())
+
+
 def check_j2_radial_line(backend, B=4096, rot=False):
     """J2 / FULL_3D (plain Newton, and the traced Newton whose full steps pass the Armijo test): the default kernels
     restrict the iteration to the radial line it never leaves;

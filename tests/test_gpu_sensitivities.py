@@ -318,3 +318,23 @@ def test_history_entries_edge_cases():
         mask = 0xFFFF | (1 << 16) | (1 << 18)
         assert torch.equal(st[k] & mask, stk & mask)
     assert (((st[1:].cpu().numpy().astype(np.uint32) >> 16) & 1) == 0).any()
+
+
+@pytest.mark.parametrize("rate", [False, True])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_direct_sensitivities(def_type, yield_kind, kw, rot, rate):
+    """cm_direct_step: forward parameter sensitivities dxi/dp, dsigma/dp propagated over a history
+    (cmad/objectives/mp_objective.py:158-215) vs the oracle's Jacobians, and the objective gradient they give vs the
+    oracle's adjoint."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator
+    if rate and def_type == ol.UNIAXIAL_STRESS:
+        pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def direct(desc, info, g, gp, xp, x, dxp):
+        dx, ds = DeviceEvaluator(desc, info).direct_step(t(g), t(xp), t(x), dxi_prev_dp=t(dxp), gradu_prev=t(gp))
+        return dx.cpu().numpy(), ds.cpu().numpy()
+    pc.check_direct(direct, def_type, yield_kind, kw, rot, rate=rate, B=300, uniaxial_idx=0)

@@ -83,6 +83,21 @@ def test_history_objective_grad(def_type, yield_kind, kw, rot, rate, solver_vari
     pc.check_history(_host_history, def_type, yield_kind, kw, rot, rate=rate, B=96, uniaxial_idx=1, primal=_host_primal)
 
 
+@pytest.mark.parametrize("rate", [False, True])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_direct_sensitivities(def_type, yield_kind, kw, rot, rate, solver_variant):
+    """cm::direct_point (the body of cm_direct_step): forward parameter sensitivities propagated over a history."""
+    import host_harness_lib as hh
+    if solver_variant == "dense":
+        pytest.skip("one variant: built on the explicit blocks")
+    if rate and def_type == ol.UNIAXIAL_STRESS:
+        pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
+    pc.check_direct(lambda desc, info, g, gp, xp, x, dxp: hh.direct_step(desc, g, xp, x, dxp, gradu_prev=gp),
+                    def_type, yield_kind, kw, rot, rate=rate, B=64, uniaxial_idx=1)
+
+
 def test_history_objective_grad_with_line_search():
     pc.check_history(_host_history, ol.FULL_3D, "J2", {}, False, ls=True, B=96, primal=_host_primal)
     pc.check_history(_host_history, ol.FULL_3D, "J2", {}, True, ls=True, B=96, primal=_host_primal, solver_flags=2)
