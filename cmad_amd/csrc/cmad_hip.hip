@@ -22,8 +22,10 @@ int g_cm_last_hip_error = 0;
 
 namespace {
 
+// 128 lanes (two wavefronts) per workgroup: measured against 64 and 256 on the same box (tools/ab_multi.sh): -3 % on the
+// fused update + vjp kernel against 256 (finer-grained release of wave slots and LDS), within +-1.5 % elsewhere; 64 is slower.
 #ifndef CM_BLOCK
-#define CM_BLOCK 256
+#define CM_BLOCK 128
 #endif
 constexpr int kBlock = CM_BLOCK;      // threads per workgroup of the per-point kernels
 constexpr int kRBlock = 256;          // threads per workgroup of the reduction kernels
@@ -242,19 +244,22 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
 constexpr int kRedStride = kBlock + 16;      // rows start 32 banks apart: the four 16-lane groups of a wave do not collide
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(const double* v, double* __restrict__ partials, double* sh) {
-    static_assert(kBlock == 256 && NV * 16 <= kBlock, "thread (k, j) layout assumes 256 lanes and NV <= 16");
+    // kGroup lanes share a row: each adds kBlock / kGroup = 16 entries, then log2(kGroup) shuffle steps (256 lanes: 16 x 16
+    // and four steps; 64 lanes: 4 x 16 and two)
+    constexpr int kGroup = kBlock / 16;
+    static_assert((kBlock == 256 || kBlock == 128 || kBlock == 64) && NV <= 16, "thread (k, j) layout: 16 rows of kBlock / 16 lanes");
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NV; ++k) sh[k * kRedStride + threadIdx.x] = v[k];
     __syncthreads();
-    const int k = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int k = threadIdx.x / kGroup, j = threadIdx.x % kGroup;
     double a = 0.0;
     if (k < NV) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a += sh[k * kRedStride + i * 16 + j];
+        for (int i = 0; i < 16; ++i) a += sh[k * kRedStride + i * kGroup + j];
     }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) a += __shfl_xor(a, off, 16);
+    for (int off = kGroup / 2; off > 0; off >>= 1) a += __shfl_xor(a, off, kGroup);
     if (k < NV && j == 0) partials[(int64_t)blockIdx.x * NV + k] = a;
 }
 
