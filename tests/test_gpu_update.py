@@ -343,3 +343,65 @@ def test_full_size_hybrid_network_surface():
     xi2, sig2, st2 = ev.update(gradu[:, sel].contiguous(), xi[:, sel].contiguous())
     it2 = st2.to(torch.int64) & 0xFFFF
     assert float((it2[ok[sel]] == 0).double().mean()) > 0.999              # re-applying the strain: elastic, no iterations
+
+
+def test_full_size_history_consistency():
+    """configs[4] with a K-step history at 4 x 10^6 points per GPU: the one-launch history entries against one launch per
+    step -- every stored state and stress (cm_update_history vs K x cm_update), the objective and gradient
+    (cm_objective_grad_history vs K x cm_update + K x cm_adjoint_step), a random sample against the oracle's adjoint, and
+    additivity over shards."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc, fold_weight_and_data
+    from cmad_amd.synthetic import gauss_point_batch
+    B, K = 4_000_000, 4
+    values = ol.j2_voce_values()
+    desc, info = build_desc(values)
+    ev = DeviceEvaluator(desc, info)
+    g0 = gauss_point_batch(B, seed=31)
+    path = [0.0, 0.5, 0.9, 1.3, 1.1]
+    f64 = dict(dtype=torch.float64, device="cuda")
+    gh = torch.stack([c * torch.from_numpy(g0).cuda() for c in path]).contiguous()
+    xi0 = torch.zeros((7, B), **f64)
+    xh, sh, st = ev.update_history(gh, xi0)
+    assert bool((((st.to(torch.int64) >> 16) & 1) == 1).all())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(12)
+    dh = (sh + 20.0 * torch.randn(sh.shape, generator=gen, **f64)).contiguous()
+    w = np.zeros((3, 3)); w[0, 0] = 1.; w[1, 1] = 1.; w[2, 2] = 0.5; w[0, 1] = w[1, 0] = 0.5
+    wsq6 = fold_weight_and_data(w)
+    out, xh2 = ev.objective_grad_history(gh, dh, wsq6, xi0)
+    assert torch.equal(xh2, xh)
+    x = xi0
+    acc = torch.zeros(13, **f64)
+    hist = torch.zeros((7, B), **f64)
+    xs = [xi0]
+    for k in range(1, K + 1):
+        x, s, _ = ev.update(gh[k], x)
+        np.testing.assert_allclose(xh[k].cpu().numpy(), x.cpu().numpy(), rtol=1e-10, atol=1e-14)
+        assert float((sh[k] - s).abs().max()) < 1e-8
+        xs.append(x)
+    for k in range(K, 0, -1):
+        ev.adjoint_step(gh[k], xs[k - 1], xs[k], dh[k], wsq6, hist, hist, acc, accumulate=True)
+    np.testing.assert_allclose(float(out[0]), float(acc[0]), rtol=1e-12)
+    np.testing.assert_allclose(out[1:].cpu().numpy(), acc[1:].cpu().numpy(), rtol=1e-9, atol=1e-11 * float(acc[1:].abs().max()))
+    # additivity over uneven shards, and bit-for-bit repeatability
+    tot = torch.zeros(13, **f64)
+    bounds = [0, 1_000_001, 2_999_999, B]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        o, _ = ev.objective_grad_history(gh[:, :, a:b].contiguous(), dh[:, :, a:b].contiguous(), wsq6, xi0[:, a:b].contiguous())
+        tot += o
+    np.testing.assert_allclose(tot.cpu().numpy(), out.cpu().numpy(), rtol=1e-11, atol=1e-11 * float(out.abs().max()))
+    out2, _ = ev.objective_grad_history(gh, dh, wsq6, xi0)
+    assert torch.equal(out, out2)
+    # a random sample against the oracle's adjoint
+    idx = np.sort(np.random.default_rng(8).choice(B, 2048, replace=False))
+    tidx = torch.from_numpy(idx).cuda()
+    mat = ol.Material(values)
+    gh_s = gh[:, :, tidx].cpu().numpy()
+    dh_s = dh[:, :, tidx].cpu().numpy()
+    idx9 = [0, 1, 2, 1, 3, 4, 2, 4, 5]
+    J_o, g_o, _, xk = mat.objective_grad_batch(ol.newton_settings(), gh_s, dh_s[:, idx9, :], w, np.zeros((7, idx.size)))
+    o_s, xh_s = ev.objective_grad_history(gh[:, :, tidx].contiguous(), dh[:, :, tidx].contiguous(), wsq6, xi0[:, tidx].contiguous())
+    np.testing.assert_allclose(xh_s[K].cpu().numpy(), xk, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(float(o_s[0]), J_o, rtol=1e-10)
+    got, ref = pc.leaf_grads(o_s[1:].cpu().numpy(), info, mat, "J2", g_o)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-11 * np.abs(ref).max())
