@@ -405,3 +405,53 @@ def test_full_size_history_consistency():
     np.testing.assert_allclose(float(o_s[0]), J_o, rtol=1e-10)
     got, ref = pc.leaf_grads(o_s[1:].cpu().numpy(), info, mat, "J2", g_o)
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-11 * np.abs(ref).max())
+
+
+def test_entry_points_are_graph_capture_safe():
+    """include/cmad_hip.h promises that nothing is allocated or synchronised inside the entry points: a per-step
+    calibration sequence (cm_update, cm_adjoint_step, cm_update_and_vjp with the two reduction launches each) is captured
+    into a HIP graph on a side stream and replayed on new input values; the results equal the eager calls."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc, fold_weight_and_data
+    from cmad_amd.synthetic import gauss_point_batch
+    B = 5000
+    desc, info = build_desc(ol.j2_voce_values())
+    ev = DeviceEvaluator(desc, info)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    g_a = torch.from_numpy(gauss_point_batch(B, seed=41)).cuda()
+    g_b = torch.from_numpy(gauss_point_batch(B, seed=42, dev_scale=5.0)).cuda()
+    gradu = g_a.clone()
+    xi0 = torch.zeros((7, B), **f64)
+    data = torch.zeros((6, B), **f64)
+    sbar = torch.ones((6, B), **f64)
+    wsq6 = fold_weight_and_data(np.eye(3))
+    out13 = torch.zeros(13, **f64)
+    hist = torch.zeros((7, B), **f64)
+    res = {"xi": torch.empty((7, B), **f64), "sigma": torch.empty((6, B), **f64), "grad": torch.empty(12, **f64)}
+    bufs = {"xi": torch.empty((7, B), **f64), "sigma": torch.empty((6, B), **f64)}
+
+    def sequence():
+        ev.update(gradu, xi0, want_status=False, out=bufs)
+        ev.adjoint_step(gradu, xi0, bufs["xi"], data, wsq6, None, hist, out13, accumulate=False)
+        ev.update_and_vjp(gradu, xi0, sbar, out=res)
+
+    ev._workspace(B, gradu.device)                      # allocated before the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sequence()                                      # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        sequence()
+    for g_new in (g_b, g_a):
+        gradu.copy_(g_new)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (bufs["xi"].clone(), out13.clone(), hist.clone(), res["grad"].clone(), res["sigma"].clone())
+        sequence()
+        torch.cuda.synchronize()
+        for a, b in zip(got, (bufs["xi"], out13, hist, res["grad"], res["sigma"])):
+            assert torch.equal(a, b)
+    assert float(out13[0]) > 0.0
