@@ -1,5 +1,7 @@
 """GPU parity of the HIP stress update against the CPU oracle, through the C-ABI (`-m gpu`).
 Scenarios and tolerances: tests/parity_cases.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -455,3 +457,44 @@ def test_entry_points_are_graph_capture_safe():
         for a, b in zip(got, (bufs["xi"], out13, hist, res["grad"], res["sigma"])):
             assert torch.equal(a, b)
     assert float(out13[0]) > 0.0
+
+
+@pytest.mark.parametrize("model_kind", [0, 1])
+def test_hill_material_rotations_golden(golden_dir, model_kind):
+    """The reference's own known-answer test for anisotropy (tests/models/test_hill_material_rotations.py:40-158: Al7079
+    Hill coefficients, 12 material orientations, 200 load steps, tolerance 1e-8 on the yy stress history) run directly on
+    the GPU path: each history is one cm_update_history launch, once with the rotation applied to the deformation and the
+    stress outside the model (Q = I) and once with params["rotation matrix"] = R."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    g = np.load(os.path.join(golden_dir, "hill_rotations.npz"))
+    hill, el, Y, voce = g["hill"], g["elastic"], float(g["Y"]), g["voce"]
+    V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+
+    def history(values, F):
+        desc, info = build_desc(values, model_kind=model_kind)
+        ev = DeviceEvaluator(desc, info)
+        K = F.shape[2] - 1
+        gh = torch.from_numpy(np.stack([(F[:, :, k] - np.eye(3)).reshape(9, 1) for k in range(K + 1)])).cuda().contiguous()
+        xi0 = torch.zeros((7, 1), dtype=torch.float64, device="cuda")
+        _, sh, st = ev.update_history(gh, xi0)
+        assert bool((((st.to(torch.int64) >> 16) & 1) == 1).all())
+        s6 = sh.cpu().numpy()[:, :, 0]
+        S = np.zeros((3, 3, K + 1))
+        for r, (i, j) in enumerate(V6):
+            S[i, j] = S[j, i] = s6[:, r]
+        return S
+
+    for R, stress, strain in zip(g["R"], g["stress"], g["strain"]):
+        num_steps = 200
+        F = np.repeat(np.eye(3)[:, :, None], num_steps + 1, axis=2)
+        F[:, :, 1:] += strain
+        ref_yy = stress[1, 1, :]
+        vals = ol.j2_voce_values(E=el[0], nu=el[1], Y=Y, S=voce[0], D=voce[1], yield_kind="hill", hill=hill)
+        Fr = np.stack([R.T @ F[:, :, k] @ R for k in range(num_steps + 1)], axis=2)
+        cauchy = history(vals, Fr)
+        num_yy = np.array([(R @ cauchy[:, :, k] @ R.T)[1, 1] for k in range(1, num_steps + 1)])
+        assert np.linalg.norm(ref_yy - num_yy) < 1e-8
+        vals = ol.j2_voce_values(E=el[0], nu=el[1], Y=Y, S=voce[0], D=voce[1], yield_kind="hill", hill=hill, Q=R)
+        cauchy = history(vals, F)
+        assert np.linalg.norm(ref_yy - cauchy[1, 1, 1:]) < 1e-8
