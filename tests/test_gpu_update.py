@@ -498,3 +498,38 @@ def test_hill_material_rotations_golden(golden_dir, model_kind):
         vals = ol.j2_voce_values(E=el[0], nu=el[1], Y=Y, S=voce[0], D=voce[1], yield_kind="hill", hill=hill, Q=R)
         cauchy = history(vals, F)
         assert np.linalg.norm(ref_yy - cauchy[1, 1, 1:]) < 1e-8
+
+
+@pytest.mark.parametrize("model_kind", [0, 1])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+@pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
+def test_j2_voce_analytical_golden(golden_dir, model_kind, def_type, yield_kind):
+    """The reference's analytical J2 + Voce known-answer test (tests/models/test_elastic_plastic_models.py:15-125 with
+    cmad/verification/solutions.py:30-58: uniaxial and biaxial stress histories, 100 steps, tolerance 1e-6 in norm on the
+    stress and the hardening variable) run directly on the GPU path, one cm_update_history launch per history; the
+    J2-equivalent Hill and Hosford (a = 2 equivalent settings of tests/support/test_problems.py) reproduce the same fields."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    if model_kind == 1 and def_type == ol.UNIAXIAL_STRESS:
+        pytest.skip("rate form under UNIAXIAL_STRESS: dual-number blocks + host Newton (test_gpu_facade.py)")
+    g = np.load(os.path.join(golden_dir, "j2_voce_analytical.npz"))
+    nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
+    V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    desc, info = build_desc(ol.j2_voce_values(yield_kind=yield_kind), def_type=def_type, model_kind=model_kind)
+    ev = DeviceEvaluator(desc, info)
+    mat = ol.Material(ol.j2_voce_values(yield_kind=yield_kind), def_type=def_type, model_kind=model_kind)
+    for name in (["uniaxial", "biaxial"] if def_type != ol.UNIAXIAL_STRESS else ["uniaxial"]):
+        stress, strain, alpha = g[f"{name}_stress"], g[f"{name}_strain"], g[f"{name}_alpha"]
+        K = 100
+        gh = np.zeros((K + 1, nd * nd, 1))
+        gh[1:, :, 0] = strain[:nd, :nd, :].reshape(nd * nd, K).T
+        xi0 = torch.from_numpy(mat.init_xi()[:, None].copy()).cuda()
+        xh, sh, st = ev.update_history(torch.from_numpy(gh).cuda().contiguous(), xi0)
+        st = st.to(torch.int64)
+        assert bool((((st >> 16) & 1) == 1).all()) and int((st & 0xFFFF).max()) <= 10
+        s6 = sh.cpu().numpy()[:, :, 0]
+        cauchy = np.zeros((3, 3, K + 1))
+        for r, (i, j) in enumerate(V6):
+            cauchy[i, j] = cauchy[j, i] = s6[:, r]
+        assert np.linalg.norm(xh.cpu().numpy()[1:, 6, 0] - alpha) < 1e-6
+        assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6
