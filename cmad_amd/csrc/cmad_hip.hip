@@ -916,7 +916,8 @@ template <int MK>
 int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                        const double* xi, const double* dxp_dp, double* dx_dp, double* ds_dp, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (m->def_type == CM_UNIAXIAL_STRESS || is_dense_yield(m->yield_kind))))
+        return CM_ERR_UNSUPPORTED;                  // never a silent no-op: the dispatch below has no such specialisation
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi || !dx_dp || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     const cm_model_desc md = *m;

@@ -303,6 +303,20 @@ def test_history_entries_edge_cases():
         ev.objective_grad_history(g, torch.zeros((2, 6, 8), **f64), wsq6, torch.zeros((7, 8), **f64))   # K mismatch
     with pytest.raises(ValueError):
         ev.objective_grad_history(g.transpose(1, 2), torch.zeros((3, 6, 8), **f64), wsq6, torch.zeros((7, 8), **f64))
+    # combinations without a kernel are refused (CM_ERR_UNSUPPORTED -> NotImplementedError), never a silent no-op:
+    # the rate form with the Barlat surface has the update and the explicit blocks only
+    yk, kw = pc.BARLAT
+    desc_rb, info_rb = build_desc(ol.j2_voce_values(yield_kind=yk, **kw), model_kind=1)
+    ev_rb = DeviceEvaluator(desc_rb, info_rb)
+    z7, z6 = torch.zeros((7, 8), **f64), torch.zeros((3, 6, 8), **f64)
+    with pytest.raises(NotImplementedError):
+        ev_rb.objective_grad_history(g, z6, wsq6, z7)
+    with pytest.raises(NotImplementedError):
+        ev_rb.update_history(g, z7)
+    with pytest.raises(NotImplementedError):
+        ev_rb.direct_step(g[1], z7, z7, gradu_prev=g[0])
+    with pytest.raises(NotImplementedError):
+        ev_rb.update_vjp(g[1], z7, z7, torch.zeros((6, 8), **f64), gradu_prev=g[0])
     # iteration cap 1: unconverged iterates are carried from step to step, identically to per-step calls
     B, K = 300, 3
     desc1, info1 = build_desc(values, newton=NewtonSettings(max_iters=1))
