@@ -27,35 +27,75 @@ BYTES_PER_UPDATE = 280           # read gradu 72 + xi_prev 56 + 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(values, seconds_target=15.0):
-    """The CPU oracle (oracle/cmad_oracle.cpp: nested-dual AD restatement of the reference algorithm,
-    OpenMP over points) on a bounded sample of the same workload, all host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import oracle_lib as ol
-    from cmad_amd.synthetic import gauss_point_batch
+def effective_cores():
+    """Host cores this process can really use: the affinity mask, capped by the cgroup CPU quota (a GPU box exposes
+    all of the host's hardware threads in the mask but grants the job only a share of them)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
+    return cores
+
+
+def cpu_baseline(values, budget_s=12.0):
+    """the CPU restatement of the CMAD path (oracle/cmad_oracle.cpp: 7-dof Newton on the reference's
+    residual, Jacobians by nested forward-mode AD like jacfwd(residual) o grad(effective_stress), OpenMP over points)
+    on the same synthetic batch -- update + vjp per point -- on ONE core and on ALL usable cores, median of 5 timed
+    runs after a warm-up run.  The sample is sized from a probe so each leg costs about `budget_s` seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    from cmad_amd.synthetic import gauss_point_batch
+    cores = effective_cores()
     mat = ol.Material(values)
     st = ol.newton_settings()
 
-    def run(B):
-        g = gauss_point_batch(B); xp = np.zeros((7, B)); sb = np.random.default_rng(0).normal(size=(6, B))
+    def run(B, nthreads, g, xp, sb):
         t0 = time.perf_counter()
-        xi, sig, it, cv = mat.update_batch(st, g, xp, nthreads=cores)
-        mat.update_vjp_batch(g, xp, xi, sb, nthreads=cores, want_bars=False)
+        xi, sig, it, cv = mat.update_batch(st, g, xp, nthreads=nthreads)
+        mat.update_vjp_batch(g, xp, xi, sb, nthreads=nthreads, want_bars=False)
         return time.perf_counter() - t0
 
-    probe = 4096 * max(1, cores // 4)
-    t = run(probe)
-    B = int(max(probe, min(4_000_000, probe * seconds_target / max(t, 1e-6))))
-    t = run(B)
-    return {"value": B / t, "unit": "updates/s", "cores": cores, "kind": "port",
-            "sample": f"{B} points of the same synthetic batch (seed 22), oracle update + vjp, {t:.1f} s wall, "
-                      f"OpenMP {cores} threads; CPU restatement of the CMAD path (nested-dual AD), not JAX"}
+    def leg(nthreads):
+        probe = 2048 * nthreads
+        g = gauss_point_batch(probe); xp = np.zeros((7, probe)); sb = np.random.default_rng(0).normal(size=(6, probe))
+        run(probe, nthreads, g, xp, sb)                                   # thread pool + page warm-up
+        t = run(probe, nthreads, g, xp, sb)
+        B = int(max(probe, min(1_000_000, probe * (budget_s / 6.0) / max(t, 1e-6))))    # 1 warm-up + 5 timed runs
+        g = gauss_point_batch(B); xp = np.zeros((7, B)); sb = np.random.default_rng(0).normal(size=(6, B))
+        run(B, nthreads, g, xp, sb)
+        ts = sorted(run(B, nthreads, g, xp, sb) for _ in range(5))
+        return B, ts[2], ts
+
+    B_all, t_all, ts_all = leg(cores)
+    B_one, t_one, _ = leg(1)
+    return {"value": B_all / t_all, "unit": "updates/s", "cores": cores, "kind": "port",
+            "one_core": {"value": B_one / t_one, "unit": "updates/s", "cores": 1, "sample_points": B_one},
+            "hardware_threads_visible": os.cpu_count(),
+            "sample": f"{B_all} points of the same synthetic batch (seed 22), update + vjp per point, median of 5 runs "
+                      f"after warm-up ({t_all:.2f} s, min {ts_all[0]:.2f} / max {ts_all[-1]:.2f}), OpenMP {cores} threads = "
+                      f"the cores the job may use (affinity mask capped by the cgroup CPU quota; {os.cpu_count()} hardware "
+                      "threads visible); CPU restatement of the CMAD path (oracle: 7-dof Newton, Jacobians by nested "
+                      "forward-mode AD as jacfwd o grad does), g++ -O3, not JAX"}
 
 
 def load_traffic(points):
@@ -143,6 +183,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000, help="Gauss points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch each step through the C-ABI from Python instead of replaying the captured HIP graph")
     ap.add_argument("--coherent", action="store_true",
                     help="side measurement: order the synthetic points by deviatoric strain magnitude, so that the lanes of a "
                          "wavefront sit in similar states (as neighbouring Gauss points of a mesh do) instead of the default "
@@ -286,22 +328,58 @@ def main():
         if distributed and r is not None:
             pending[k & 1] = dist.all_reduce(r, async_op=True)
 
+    # The step is replayed from a captured HIP graph (one per result buffer): the entry points allocate and synchronise
+    # nothing (include/cmad_hip.h), so a replay is the main kernel + the two reduction kernels with one host call and
+    # no Python between the launches.  --no-graph launches through the C-ABI each step instead (A/B).
+    use_graph = not args.no_graph
+    graphs = [None, None]
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(2):
+                launch(i)                              # warm-up on the capture stream (workspace allocated here)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for i in range(2):
+            graphs[i] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graphs[i], stream=side):
+                launch(i)
+    result_of = {"j2_update_vjp": grads, "j2_objective_grad": res13}.get(wl, [None, None])   # what each graph writes
+
+    def step(k):
+        i = k & 1
+        if not use_graph:
+            return launch(k)
+        if pending[i] is not None:
+            pending[i].wait()
+            pending[i] = None
+        graphs[i].replay()
+        return result_of[i]
+
+    # every timing event is created AND recorded once before the timed region: hipEventCreate / the first record of an
+    # event must not land between two timed launches
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    for e in starts + ends:
+        e.record()
     for k in range(args.warmup):
-        reduce_async(k, launch(k))
+        reduce_async(k, step(k))
     for i in range(2):
         if pending[i] is not None:
             pending[i].wait(); pending[i] = None
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    host_t = [0.0] * (args.steps + 1)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        host_t[k] = time.perf_counter()
         starts[k].record()                         # events on the stream the kernels are launched on
-        r = launch(k)
+        r = step(k)
         ends[k].record()
         reduce_async(k, r)
+    host_t[args.steps] = time.perf_counter()
     for i in range(2):
         if pending[i] is not None:
             pending[i].wait()
@@ -309,11 +387,21 @@ def main():
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    per_step_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    kernel_ms = float(np.mean(per_step_ms))
+    device_span_ms = float(starts[0].elapsed_time(ends[-1]))           # first launch start -> last launch end, device clock
+    start_gaps_ms = [starts[k].elapsed_time(starts[k + 1]) for k in range(args.steps - 1)]
+    host_issue_ms = [(host_t[k + 1] - host_t[k]) * 1e3 for k in range(args.steps)]
+    local_elapsed = elapsed
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    per_rank_kernel_ms = [kernel_ms]
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(kms) for _ in range(world)]
+        dist.all_gather(gathered, kms)
+        per_rank_kernel_ms = [float(t.item()) for t in gathered]
     elapsed = float(tmax.item())
 
     # a cheap self-check so a broken run cannot report a number: all points converged, finite gradient
@@ -328,10 +416,15 @@ def main():
     if rank == 0:
         n = world
         value = n * B * args.steps / elapsed
-        achieved = bytes_per_update * B / (kernel_ms * 1e-3) / 1e9
+        ms_per_step = elapsed / args.steps * 1e3
+        # roofline.achieved comes from the SAME interval as `value` (barrier-to-barrier wall clock, max over ranks), per GPU:
+        # algorithmic bytes per launch / ms_per_step.  The kernel-only figure (HIP events around each step on the launch
+        # stream: main kernel + the two reduction kernels) is kept beside it under roofline.kernel_only.
+        achieved = bytes_per_update * B / (ms_per_step * 1e-3) / 1e9
+        achieved_kernel = bytes_per_update * B / (kernel_ms * 1e-3) / 1e9
         res = {
             "metric": METRIC, "value": value, "unit": "updates/s", "n_gpus": n, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": {"j2_update_vjp": "J2 isotropic-hardening (Voce) stress update + vjp w.r.t. parameters, FULL_3D, "
@@ -357,7 +450,22 @@ def main():
                                     if not (args.general_newton or args.ls_evals > 0 or ps) else
                                     "k_reverse<J2,noROT,fused update+vjp>",
                                     "j2_objective_grad": "k_reverse<FULL_3D,J2,noROT,fused objective+grad>"}.get(wl, "k_update"),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_update": bytes_per_update},
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_update": bytes_per_update,
+                         "interval": "ms_per_step (same wall-clock interval as value)",
+                         "kernel_only": {"ms": kernel_ms, "achieved": achieved_kernel, "frac": achieved_kernel / HBM_PEAK_GBS,
+                                         "how": "mean HIP-event duration of one step on the launch stream"}},
+            # where the time of the timed region went (rank 0): a host stall, a launch-bound loop and a slow kernel look
+            # different here.  device_span = first launch start -> last launch end on the device clock;
+            # start_gap = distance between consecutive launch starts; host_issue = host time spent issuing one step.
+            "timeline": {"launch": "hip graph replay" if use_graph else "eager C-ABI calls",
+                         "wall_ms": local_elapsed * 1e3, "device_span_ms": device_span_ms,
+                         "device_span_per_step_ms": device_span_ms / args.steps,
+                         "step_kernel_ms": {"min": min(per_step_ms), "max": max(per_step_ms), "mean": kernel_ms},
+                         "start_gap_ms": ({"min": min(start_gaps_ms), "max": max(start_gaps_ms),
+                                           "mean": float(np.mean(start_gaps_ms))} if start_gaps_ms else None),
+                         "host_issue_ms": {"min": min(host_issue_ms), "max": max(host_issue_ms),
+                                           "mean": float(np.mean(host_issue_ms))},
+                         "per_rank_kernel_ms": per_rank_kernel_ms},
         }
         if (n == 1 and wl == "j2_update_vjp" and not ps and args.ls_evals == 0 and not args.general_newton
                 and args.yield_surface == "j2"):

@@ -1254,7 +1254,7 @@ CM_D void cotangent_to_material(const cm_model_desc& m, const double sb[6], doub
 template <int DEF, int YK>
 CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double z[6],
                         const double* x, const double* xp, const double sbm[6], const double* xin,
-                        double* pbar, double* xpbar, double* egbar) {
+                        double* pbar, double* xpbar, double* egbar, double* lam_out = nullptr) {
     constexpr int NX = Dims<DEF>::NX;
     Eval<DEF> ev;
     double C[NX], Ht[6][6], At[NX][NX], lam[NX];
@@ -1280,6 +1280,10 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
         for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
     lu_subst<NX>(At, lam);
+    if (lam_out) {                                           // the adjoint vector of this step (phi = -lam in the reference)
+#pragma unroll
+        for (int k = 0; k < NX; ++k) lam_out[k] = lam[k];
+    }
     const double i2mu = half_over_mu(m);
     // ---- u_k = -dgam lam_k / w_k (plastic rows), hu = Ht u
     double u[6], hu[6];
@@ -1453,7 +1457,7 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
 template <int DEF, int YK>
 CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const double z[6],
                              const double* x, const double* xp, const double sbm[6], const double* xin,
-                             double* pbar, double* xpbar, double* degbar) {
+                             double* pbar, double* xpbar, double* degbar, double* lam_out = nullptr) {
     static_assert(DEF != CM_UNIAXIAL_STRESS, "batched rate-form reverse sweep: FULL_3D and PLANE_STRESS");
     constexpr int NX = Dims<DEF>::NX;
     constexpr bool PS = (DEF == CM_PLANE_STRESS);
@@ -1471,6 +1475,10 @@ CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const 
         for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
     lu_subst<NX>(At, lam);
+    if (lam_out) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) lam_out[k] = lam[k];
+    }
     const double i2mu = half_over_mu(m);
     const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];
     const double dgp = ev.plastic ? ev.dgam : 0.0;

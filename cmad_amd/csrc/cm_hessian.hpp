@@ -257,7 +257,7 @@ CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, dou
 template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv, const double* xpv, int a, int b,
                        double* out_C, double* out_S, double* out_Ca, double* out_Sa,
-                       double* out_C0 = nullptr, double* out_S0 = nullptr) {
+                       double* out_C0 = nullptr, double* out_S0 = nullptr, double* out_Sb = nullptr) {
     constexpr int NX = nx_of<DEF, MK>();
     constexpr bool RATE_UNI = (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS);
     double eg[6], z[Dims<DEF>::NZ];
@@ -286,8 +286,31 @@ CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv
     to_global<ROT>(m, s2, g2);
     to_global<ROT>(m, s1, g1);
     for (int k = 0; k < 6; ++k) { out_S[k] = g2[k]; out_Sa[k] = g1[k]; }
+    if (out_Sb) {                                         // first derivative of the global stress w.r.t. q_b
+        double sb1[6], gb1[6];
+        for (int k = 0; k < 6; ++k) sb1[k] = s[k].b;
+        to_global<ROT>(m, sb1, gb1);
+        for (int k = 0; k < 6; ++k) out_Sb[k] = gb1[k];
+    }
     if (out_C0) for (int k = 0; k < NX; ++k) out_C0[k] = C[k].v;
     if (out_S0) { to_global<ROT>(m, s0, g0); for (int k = 0; k < 6; ++k) out_S0[k] = g0[k]; }
+}
+
+// ---- one entry of the second-order weight matrix of a history step (cm_hessian_history) ---------------------------------
+// W[a][b] = sbar . d2 sigma / dq_a dq_b + sum_r hss_r d sigma_r / dq_a  d sigma_r / dq_b - lam . d2 C / dq_a dq_b,
+// q = [xi, xi_prev, p]: the Hessian in q of the step's Lagrangian J_k(sigma) - lam . C_k for a QoI whose curvature in the six
+// stored stress entries is diagonal (cmad/qois/calibration.py:56-66: hss = folded squared weights), with lam = -phi of
+// cmad/objectives/mp_objective.py:255-281.  G: grad u (rate form: grad u - grad u_prev).
+template <int DEF, int YK, bool ROT, int MK>
+CM_D double hessian_weight(const cm_model_desc& m, const double* G, const double* x, const double* xp, const double* lam,
+                           const double sbar[6], const double hss[6], int a, int b) {
+    constexpr int NX = nx_of<DEF, MK>();
+    double oC[NX], oS[6], oCa[NX], oSa[6], oSb[6];
+    hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa, nullptr, nullptr, oSb);
+    double w = 0.0;
+    for (int k = 0; k < NX; ++k) w -= lam[k] * oC[k];
+    for (int r = 0; r < 6; ++r) w += sbar[r] * oS[r] + hss[r] * oSa[r] * oSb[r];
+    return w;
 }
 
 }  // namespace cm

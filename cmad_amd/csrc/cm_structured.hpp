@@ -499,7 +499,7 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
 template <int YK, bool HAVE_EV = false, int DEF = CM_FULL_3D>
 CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const double* x, const double* xp,
                           const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar,
-                          EvalS<YK>* evp = nullptr, const double* z = nullptr) {
+                          EvalS<YK>* evp = nullptr, const double* z = nullptr, double* lam_out = nullptr) {
     constexpr int NX = Dims<DEF>::NX;
     constexpr bool PS = (DEF == CM_PLANE_STRESS);
     EvalS<YK> evl;
@@ -530,6 +530,10 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
         for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
     const bool ok = solve_s<DEF, true>(m, op, ev, z, lam, lam);
+    if (lam_out) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) lam_out[k] = lam[k];
+    }
     const double i2mu = half_over_mu(m);
     const YieldS<YK>& y = ev.y;
     double u[6], hu[6];
@@ -660,10 +664,11 @@ CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const doubl
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
-                      const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar) {
+                      const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar,
+                      double* lam_out = nullptr) {
     if constexpr (STRUCT && has_structured<DEF, YK>())
-        return reverse_point_s<YK, false, DEF>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar, nullptr, z);
-    else return reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, egbar);
+        return reverse_point_s<YK, false, DEF>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar, nullptr, z, lam_out);
+    else return reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, egbar, lam_out);
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
@@ -731,9 +736,20 @@ CM_D void primal_history_point(const cm_model_desc& m, int K, const double* grad
 //   io.load<N>(base, step_row0, out) / io.store<N>(base, step_row0, v) / io.phase_barrier()
 // red[0] += J, red[1 + j] += dJ/dp_j (KP order).  MK selects the total-form or the rate-form model (the latter takes
 // grad u of the previous step as well).
+// HistoryCotangents (cm_adjoint_history): instead of the calibration QoI the caller may hand in the QoI's cotangents per
+// step -- sbar_hist[(K+1)][6] = dJ/d sigma (the 6 stored global entries) replaces wsq o (sigma - data) (red[0] stays 0),
+// xibar_hist[(K+1)][NX] = explicit dJ/d xi is added to the incoming state cotangent -- and ask for the adjoint vector of
+// every step, lam_hist[(K+1)][NX] (slot 0 unused; phi = -lam in cmad/objectives/mp_objective.py:112-142).
+struct HistoryCotangents {
+    const double* sbar_hist;
+    const double* xibar_hist;
+    double* lam_hist;
+};
+
 template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false, class IO>
 CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* data_hist, const double wsq[6],
-                        const double* xi0, double* xi_hist, bool valid, LaneStage stage, const IO& io, double* red) {
+                        const double* xi0, double* xi_hist, bool valid, LaneStage stage, const IO& io, double* red,
+                        HistoryCotangents hc = HistoryCotangents{nullptr, nullptr, nullptr}) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
     double x[NX], xp[NX], z[Dims<DEF>::NZ];
     strain_z<DEF, ROT>(m, z);
@@ -764,31 +780,83 @@ CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist,
 #pragma unroll
     for (int i = 0; i < NX; ++i) xin[i] = 0.0;
     for (int k = K; k >= 1; --k) {
-        double eg[6], sd[6], sg[6], sb[6], sbm[6], pbar[CM_NUM_PARAMS], xpbar[NX];
+        double eg[6], sd[6], sg[6], sb[6], sbm[6], pbar[CM_NUM_PARAMS], xpbar[NX], lam[NX];
         strain_at(k, eg);
         io.template load<NX>(xi_hist, (int64_t)(k - 1) * NX, xp);
-        io.template load<6>(data_hist, (int64_t)k * 6, sd);
-        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) to_global<ROT>(m, x, sg);
-        else {
-            Eval<DEF> ev;
-            strain_stress<DEF>(m, eg, z, x, ev);
-            to_global<ROT>(m, ev.s, sg);
-        }
         double J = 0.0;
+        if (hc.sbar_hist) {                                     // the caller's QoI: cotangents given, objective on its side
+            io.template load<6>(hc.sbar_hist, (int64_t)k * 6, sb);
+        } else {
+            io.template load<6>(data_hist, (int64_t)k * 6, sd);
+            if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) to_global<ROT>(m, x, sg);
+            else {
+                Eval<DEF> ev;
+                strain_stress<DEF>(m, eg, z, x, ev);
+                to_global<ROT>(m, ev.s, sg);
+            }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double mm = sg[i] - sd[i];
-            sb[i] = wsq[i] * mm;
-            J += 0.5 * sb[i] * mm;
+            for (int i = 0; i < 6; ++i) {
+                const double mm = sg[i] - sd[i];
+                sb[i] = wsq[i] * mm;
+                J += 0.5 * sb[i] * mm;
+            }
+        }
+        if (hc.xibar_hist) {
+            double xb[NX];
+            io.template load<NX>(hc.xibar_hist, (int64_t)k * NX, xb);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xin[i] += xb[i];
         }
         cotangent_to_material<ROT>(m, sb, sbm);
-        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) reverse_point_rate<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr);
-        else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr);
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) reverse_point_rate<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
+        else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
+        if (hc.lam_hist && valid) io.template store<NX>(hc.lam_hist, (int64_t)k * NX, lam);
         red[0] += J;
 #pragma unroll
         for (int j = 0; j < CM_NUM_PARAMS; ++j) red[1 + j] += pbar[j];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xin[i] = xpbar[i]; x[i] = xp[i]; }
+    }
+}
+
+// ---- forward (direct) sensitivities over a stored history of one point (cm_direct_history) ---------------------------------
+// cmad/objectives/mp_objective.py:158-215: dxi_k/dp = -A_k^-1 (dC_k/dp + dC_k/dxi_prev dxi_{k-1}/dp), dsigma_k/dp by the chain
+// rule (cm::direct_point per step, the sensitivity block carried from step to step), and the gradient contraction
+//   g_j = sum_k sbar_k . dsigma_k/dp_j + xibar_k . dxi_k/dp_j     (sbar_hist / xibar_hist may be null: no contraction).
+// IO: io.get(base, row) / io.put(base, row, v) address row `row` of this point.  Row layouts as include/cmad_hip.h.
+template <int DEF, int YK, bool ROT, int MK, class IO>
+CM_D void direct_history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* xi_hist,
+                               const double* sbar_hist, const double* xibar_hist, double* dx_dp_hist, double* ds_dp_hist,
+                               const IO& io, double* g) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    double G[NU], Gp[NU], xp[NX], x[NX], din[NX * NP_], dout[NX * NP_], dsig[6 * NP_];
+    for (int j = 0; j < NP_; ++j) g[j] = 0.0;
+    for (int i = 0; i < NX * NP_; ++i) din[i] = 0.0;
+    if (dx_dp_hist) for (int i = 0; i < NX * NP_; ++i) io.put(dx_dp_hist, i, 0.0);                   // slot 0
+    if (ds_dp_hist) for (int i = 0; i < 6 * NP_; ++i) io.put(ds_dp_hist, i, 0.0);
+    for (int k = 0; k < NU; ++k) Gp[k] = io.get(gradu_hist, k);
+    for (int k = 0; k < NX; ++k) xp[k] = io.get(xi_hist, k);
+    for (int step = 1; step <= K; ++step) {
+        for (int k = 0; k < NU; ++k) G[k] = io.get(gradu_hist, (int64_t)step * NU + k);
+        for (int k = 0; k < NX; ++k) x[k] = io.get(xi_hist, (int64_t)step * NX + k);
+        direct_point<MK, DEF, YK, ROT>(m, G, Gp, x, xp, step > 1 ? din : nullptr, dout, dsig);
+        if (dx_dp_hist) for (int i = 0; i < NX * NP_; ++i) io.put(dx_dp_hist, (int64_t)step * NX * NP_ + i, dout[i]);
+        if (ds_dp_hist) for (int i = 0; i < 6 * NP_; ++i) io.put(ds_dp_hist, (int64_t)step * 6 * NP_ + i, dsig[i]);
+        if (sbar_hist) {
+            for (int r = 0; r < 6; ++r) {
+                const double sb = io.get(sbar_hist, (int64_t)step * 6 + r);
+                for (int j = 0; j < NP_; ++j) g[j] += sb * dsig[r * NP_ + j];
+            }
+        }
+        if (xibar_hist) {
+            for (int i = 0; i < NX; ++i) {
+                const double xb = io.get(xibar_hist, (int64_t)step * NX + i);
+                for (int j = 0; j < NP_; ++j) g[j] += xb * dout[i * NP_ + j];
+            }
+        }
+        for (int i = 0; i < NX * NP_; ++i) din[i] = dout[i];
+        for (int k = 0; k < NU; ++k) Gp[k] = G[k];
+        for (int k = 0; k < NX; ++k) xp[k] = x[k];
     }
 }
 

@@ -344,9 +344,11 @@ constexpr int min_waves() {
 template <int DEF, int YK, bool ROT, bool LS, int MODE, bool RL = false>
 __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_reverse(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi_in,
-        const double* __restrict__ sbar_or_data, Wsq wsq, const double* __restrict__ hist_in,
-        double* __restrict__ xi_out, double* __restrict__ sigma_out, double* __restrict__ xpbar_out,
+        const double* __restrict__ sbar_or_data, Wsq wsq, const double* hist_in,
+        double* __restrict__ xi_out, double* __restrict__ sigma_out, double* xpbar_out,
         double* __restrict__ gbar_out, double* __restrict__ partials) {
+    // hist_in and xpbar_out carry no __restrict__: cm_adjoint_step documents that hist_out may alias hist_in (the history
+    // vector is updated in place; each lane reads its own column before it writes it)
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
@@ -461,8 +463,8 @@ template <int DEF, int YK, bool ROT, bool LS, int MODE>
 __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
         const double* __restrict__ xi_in, const double* __restrict__ sbar_or_data, Wsq wsq,
-        const double* __restrict__ hist_in, double* __restrict__ xi_out, double* __restrict__ sigma_out,
-        double* __restrict__ xpbar_out, double* __restrict__ gbar_out, double* __restrict__ partials) {
+        const double* hist_in /* may alias xpbar_out */, double* __restrict__ xi_out, double* __restrict__ sigma_out,
+        double* xpbar_out, double* __restrict__ gbar_out, double* __restrict__ partials) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
@@ -558,10 +560,17 @@ struct SoaRowsIO {
     __device__ __forceinline__ void store_status(uint32_t* base, int64_t row, uint32_t v) const { (base + row * B)[b] = v; }
 };
 
+// plain per-point row access for the one-thread-per-point kernels (point b of row r at base[r * B + b])
+struct PointRowsIO {
+    int64_t B, b;
+    __device__ __forceinline__ double get(const double* base, int64_t row) const { return base[row * B + b]; }
+    __device__ __forceinline__ void put(double* base, int64_t row, double v) const { base[row * B + b] = v; }
+};
+
 template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false>
 __global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, int K,
         const double* __restrict__ gradu_hist, const double* __restrict__ data_hist, Wsq wsq,
-        const double* __restrict__ xi0, double* xi_hist, double* __restrict__ partials) {
+        const double* __restrict__ xi0, double* xi_hist, double* __restrict__ partials, HistoryCotangents hc) {
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
     const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
@@ -571,8 +580,12 @@ __global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, 
     double red[kRed];
 #pragma unroll
     for (int k = 0; k < kRed; ++k) red[k] = 0.0;
-    history_point<DEF, YK, ROT, LS, MK, RL>(m, K, gradu_hist + blk0, data_hist + blk0, wsq.w, xi0 + blk0, xi_hist + blk0, valid,
-                                        LaneStage{lds_buf + (STAGED ? threadIdx.x : 0), kBlock}, SoaRowsIO{B, b}, red);
+    if (hc.sbar_hist) hc.sbar_hist += blk0;
+    if (hc.xibar_hist) hc.xibar_hist += blk0;
+    if (hc.lam_hist) hc.lam_hist += blk0;
+    history_point<DEF, YK, ROT, LS, MK, RL>(m, K, gradu_hist + blk0, data_hist ? data_hist + blk0 : nullptr, wsq.w, xi0 + blk0,
+                                        xi_hist + blk0, valid, LaneStage{lds_buf + (STAGED ? threadIdx.x : 0), kBlock},
+                                        SoaRowsIO{B, b}, red, hc);
     if (!valid) {
 #pragma unroll
         for (int k = 0; k < kRed; ++k) red[k] = 0.0;
@@ -697,6 +710,104 @@ __global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
     }
 }
 
+// ---- cm_direct_history: the forward-sensitivity recursion of a whole load history in one launch ------------------------
+// (cmad/objectives/mp_objective.py:158-215, MPDirectObjective: dxi_k/dp = -A_k^-1 (dC_k/dp + dC_k/dxi_prev dxi_{k-1}/dp),
+//  dsigma_k/dp = dsigma/dp|_xi + dsigma/dxi dxi_k/dp; one thread per point, the 7..9 x 12 sensitivity block carried from
+//  step to step).  Optional per-step outputs dxi_dp_hist[(K+1)][NX*12][B], dsigma_dp_hist[(K+1)][6*12][B]; with the QoI
+//  cotangents sbar_hist[(K+1)][6][B] (and xibar_hist[(K+1)][NX][B]) the gradient contraction
+//  g_j = sum_k sbar_k . dsigma_k/dp_j + xibar_k . dxi_k/dp_j happens here and rows[b][1 + j] receives point b's share.
+template <int DEF, int YK, bool ROT, int MK>
+__global__ __launch_bounds__(64) void k_direct_history(cm_model_desc m, int64_t B, int K,
+        const double* __restrict__ gradu_hist, const double* __restrict__ xi_hist,
+        const double* __restrict__ sbar_hist, const double* __restrict__ xibar_hist,
+        double* __restrict__ dx_dp_hist, double* __restrict__ ds_dp_hist, double* __restrict__ rows) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double g[CM_NUM_PARAMS];
+    direct_history_point<DEF, YK, ROT, MK>(m, K, gradu_hist, xi_hist, sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist,
+                                           PointRowsIO{B, b}, g);
+    if (rows) {
+        rows[b * kRed] = 0.0;
+        for (int j = 0; j < CM_NUM_PARAMS; ++j) rows[b * kRed + 1 + j] = g[j];
+    }
+}
+
+// ---- cm_hessian_history: second-order (direct-adjoint) contraction of a stored history ---------------------------------
+// cmad/objectives/mp_objective.py:218-345 (MPDirectAdjointObjective).  With q = [xi_k, xi_{k-1}, p] (NQ entries), the
+// Lagrangian of step k is  J_k(sigma(xi_k, p)) - lam_k . C_k(q)  (lam = -phi, cm_adjoint_history) and the total
+// derivative of q w.r.t. the parameters is  D_k = [dxi_k/dp ; dxi_{k-1}/dp ; I]  (cm_direct_history), so that
+//     d2J/dp2 = sum_k D_k^T W_k D_k ,   W_k[a][b] = sbar . d2sigma/dq_a dq_b + sum_r hss_r dsigma_r/dq_a dsigma_r/dq_b
+//                                                  - lam . d2C/dq_a dq_b
+// which is the reference's 13-term sum written as one quadratic form.  Stage 1: one thread per (point, step, pair a <= b)
+// evaluates the residual in hyper-dual arithmetic (cm::hessian_pair) and writes W; stage 2: one block per (point, step)
+// forms the 12 x 12 quadratic form; stage 3: a fixed-order sum over (point, step).
+template <int DEF, int YK, bool ROT, int MK>
+__global__ __launch_bounds__(64) void k_hessian_weights(cm_model_desc m, int64_t B, int K,
+        const double* __restrict__ gradu_hist, const double* __restrict__ xi_hist, const double* __restrict__ lam_hist,
+        const double* __restrict__ sbar_hist, Wsq hss, double* __restrict__ W) {
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS, NPAIR = NQ * (NQ + 1) / 2;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * K * NPAIR) return;
+    const int64_t ps = tid / NPAIR;                       // (step - 1) * B + point
+    const int64_t pt = ps % B;
+    const int step = (int)(ps / B) + 1;
+    int rem = (int)(tid % NPAIR), a = 0;
+    while (rem >= NQ - a) { rem -= NQ - a; ++a; }
+    const int b = a + rem;
+    double G[NU], xp[NX], x[NX], lam[NX], sbar[6];
+    for (int k = 0; k < NU; ++k) {
+        G[k] = gradu_hist[((int64_t)step * NU + k) * B + pt];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_hist[((int64_t)(step - 1) * NU + k) * B + pt];
+    }
+    for (int k = 0; k < NX; ++k) {
+        xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + pt];
+        x[k] = xi_hist[((int64_t)step * NX + k) * B + pt];
+        lam[k] = lam_hist[((int64_t)step * NX + k) * B + pt];
+    }
+    for (int r = 0; r < 6; ++r) sbar[r] = sbar_hist[((int64_t)step * 6 + r) * B + pt];
+    const double w = hessian_weight<DEF, YK, ROT, MK>(m, G, x, xp, lam, sbar, hss.w, a, b);
+    W[(ps * NQ + a) * NQ + b] = w;
+    W[(ps * NQ + b) * NQ + a] = w;
+}
+
+template <int NX>
+__global__ __launch_bounds__(192) void k_hessian_quadform(int64_t B, int K, const double* __restrict__ W,
+        const double* __restrict__ dx_dp_hist, double* __restrict__ part) {
+    constexpr int NP_ = CM_NUM_PARAMS, NQ = 2 * NX + NP_;
+    __shared__ double sW[NQ * NQ], sD[NQ * NP_];
+    const int64_t ps = blockIdx.x, pt = ps % B;
+    const int step = (int)(ps / B) + 1;
+    for (int i = threadIdx.x; i < NQ * NQ; i += 192) sW[i] = W[ps * NQ * NQ + i];
+    for (int i = threadIdx.x; i < NQ * NP_; i += 192) {
+        const int r = i / NP_, j = i % NP_;
+        double v;
+        if (r < NX) v = dx_dp_hist[(((int64_t)step * NX + r) * NP_ + j) * B + pt];
+        else if (r < 2 * NX) v = dx_dp_hist[(((int64_t)(step - 1) * NX + (r - NX)) * NP_ + j) * B + pt];
+        else v = (r - 2 * NX == j) ? 1.0 : 0.0;
+        sD[i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NP_ * NP_) {
+        const int i = threadIdx.x / NP_, j = threadIdx.x % NP_;
+        double acc = 0.0;
+        for (int a = 0; a < NQ; ++a) {
+            double t = 0.0;
+            for (int b = 0; b < NQ; ++b) t += sW[a * NQ + b] * sD[b * NP_ + j];
+            acc += sD[a * NP_ + i] * t;
+        }
+        part[ps * (NP_ * NP_) + threadIdx.x] = acc;
+    }
+}
+
+// out[j] = sum over rows of part[row][ncols] in a fixed order (one thread per column)
+__global__ __launch_bounds__(256) void k_sum_rows(const double* __restrict__ part, int64_t nrows, int ncols, double* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    double acc = 0.0;
+    for (int64_t r = 0; r < nrows; ++r) acc += part[r * ncols + j];
+    out[j] = acc;
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 
@@ -747,6 +858,11 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
 #undef CM_CASE
     return false;
 }
+
+// The point-wise entry points (cm_evaluate*, cm_hessians*, cm_direct_step: B = 1 in the reference's use, latency-bound)
+// always run the rotation products: with Q = I they reproduce the unrotated result exactly (products with 1 and sums
+// with 0), and one instantiation per (def_type, yield) instead of two keeps the library small.
+constexpr bool kColdRot = true;
 
 inline int check_launch() {
     const hipError_t e = hipGetLastError();
@@ -855,15 +971,16 @@ int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, 
 template <int MK>
 int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* data_hist,
                    const double* wsq6, const double* xi0, double* xi_hist, double* out,
-                   void* workspace, int64_t wbytes, void* stream) {
-    if (!m || B < 0 || K < 1 || !out || !workspace || !wsq6) return CM_ERR_BAD_ARG;
-    if (B > 0 && (!gradu_hist || !data_hist || !xi0 || !xi_hist)) return CM_ERR_BAD_ARG;
+                   void* workspace, int64_t wbytes, void* stream, HistoryCotangents hc = HistoryCotangents{nullptr, nullptr, nullptr},
+                   int out_offset = 0) {
+    if (!m || B < 0 || K < 1 || !out || !workspace || (!wsq6 && !hc.sbar_hist)) return CM_ERR_BAD_ARG;
+    if (B > 0 && (!gradu_hist || (!data_hist && !hc.sbar_hist) || !xi0 || !xi_hist)) return CM_ERR_BAD_ARG;
     if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind))) return CM_ERR_UNSUPPORTED;
     if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* partials = (double*)workspace;
     const int64_t nb = nblocks_of(B);
-    Wsq w; for (int k = 0; k < 6; ++k) w.w[k] = wsq6[k];
+    Wsq w; for (int k = 0; k < 6; ++k) w.w[k] = wsq6 ? wsq6[k] : 0.0;
     const cm_model_desc md = *m;
     (void)hipGetLastError();
     if (B > 0) {
@@ -871,19 +988,19 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
         const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && D == CM_FULL_3D && Y == CM_YIELD_J2) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
-                    hipLaunchKernelGGL((k_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials);
+                    hipLaunchKernelGGL((k_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
                     return;
                 }
             }
             if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
-                hipLaunchKernelGGL((k_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials);
+                hipLaunchKernelGGL((k_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
         });
         if (!found) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     double* stage = partials + nb * kRed;
     hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
-    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, 0, 0);
+    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, 0);
     return check_launch();
 }
 
@@ -926,9 +1043,42 @@ int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, c
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
-            hipLaunchKernelGGL((k_direct_step<D, Y, R, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
+            hipLaunchKernelGGL((k_direct_step<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+
+template <int MK>
+int launch_direct_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi_hist,
+                          const double* sbar_hist, const double* xibar_hist, double* dx_dp_hist, double* ds_dp_hist,
+                          double* grad_p, void* workspace, int64_t wbytes, void* stream) {
+    if (!m || B < 0 || K < 1) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (m->def_type == CM_UNIAXIAL_STRESS || is_dense_yield(m->yield_kind))))
+        return CM_ERR_UNSUPPORTED;
+    if (grad_p && (!sbar_hist || !workspace)) return CM_ERR_BAD_ARG;
+    if (grad_p && wbytes < cm_direct_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (!grad_p && !dx_dp_hist && !ds_dp_hist) return CM_ERR_BAD_ARG;
+    if (B > 0 && (!gradu_hist || !xi_hist)) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    hipStream_t s = (hipStream_t)stream;
+    double* rows = grad_p ? (double*)workspace : nullptr;
+    if (B > 0) {
+        const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+        const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+                hipLaunchKernelGGL((k_direct_history<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist,
+                                   sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist, rows);
+        });
+        if (!found) return CM_ERR_UNSUPPORTED;
+        if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
+    }
+    if (grad_p) {
+        double* stage = rows + (B > 0 ? B : 1) * kRed;
+        hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, rows, B, stage);
+        hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, grad_p, 1, 0);
+    }
     return check_launch();
 }
 
@@ -949,10 +1099,45 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (!is_dense_yield(Y))
-            hipLaunchKernelGGL((k_hessians<D, Y, R, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi,
+            hipLaunchKernelGGL((k_hessians<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi,
                                d2C, d2S, dC, dS, C0, S0);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+
+template <int MK>
+int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi_hist,
+                           const double* lam_hist, const double* dx_dp_hist, const double* sbar_hist, const double* hss6,
+                           double* out, void* workspace, int64_t wbytes, void* stream) {
+    if (!m || B < 0 || K < 1 || !out || !workspace || !hss6) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || is_dense_yield(m->yield_kind) ||
+        (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS)) return CM_ERR_UNSUPPORTED;
+    if (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !dx_dp_hist || !sbar_hist)) return CM_ERR_BAD_ARG;
+    if (wbytes < cm_hessian_workspace_bytes(m, B, K)) return CM_ERR_WORKSPACE;
+    const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
+    constexpr int NPP = CM_NUM_PARAMS * CM_NUM_PARAMS;
+    const int64_t nps = B * (int64_t)K;
+    double* W = (double*)workspace;
+    double* part = W + nps * nq * nq;
+    Wsq h; for (int k = 0; k < 6; ++k) h.w[k] = hss6[k];
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    hipStream_t s = (hipStream_t)stream;
+    if (nps > 0) {
+        const int64_t nthreads = nps * (int64_t)(nq * (nq + 1) / 2);
+        const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
+        const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (!is_dense_yield(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS)) {
+                hipLaunchKernelGGL((k_hessian_weights<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist, lam_hist,
+                                   sbar_hist, h, W);
+                hipLaunchKernelGGL((k_hessian_quadform<Dims<D>::NX>), dim3((unsigned)nps), dim3(192), 0, s, B, K, W, dx_dp_hist, part);
+            }
+        });
+        if (!found) return CM_ERR_UNSUPPORTED;
+        if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, s, part, nps, NPP, out);
     return check_launch();
 }
 #endif
@@ -963,7 +1148,7 @@ extern "C" {
 
 
 #if CM_HAS_PART(1)
-int cm_abi_version(void) { return 3; }
+int cm_abi_version(void) { return 4; }
 #endif
 
 #if CM_HAS_PART(1)
@@ -1078,6 +1263,46 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
 int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
 #endif
 
+#if CM_HAS_PART(1)
+int64_t cm_direct_workspace_bytes(int64_t B) {
+    if (B < 0) return CM_ERR_BAD_ARG;
+    return ((B > 0 ? B : 1) + kRedBlocks + 1) * kRed * (int64_t)sizeof(double);      // one row per point + stage rows
+}
+int64_t cm_hessian_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K) {
+    if (!m || B < 0 || K < 1) return CM_ERR_BAD_ARG;
+    const int nx = cm_num_xi(m);
+    if (nx < 0) return CM_ERR_UNSUPPORTED;
+    const int64_t nq = 2 * nx + CM_NUM_PARAMS, nps = (B > 0 ? B : 1) * (int64_t)K;
+    return nps * (nq * nq + CM_NUM_PARAMS * CM_NUM_PARAMS) * (int64_t)sizeof(double);
+}
+#endif
+
+#if CM_HAS_PART(5)
+int cm_direct_history(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi_hist,
+                      const double* sigma_bar_hist, const double* xi_bar_hist, double* dxi_dp_hist, double* dsigma_dp_hist,
+                      double* grad_p, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return launch_direct_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi_hist, sigma_bar_hist, xi_bar_hist,
+                                                                    dxi_dp_hist, dsigma_dp_hist, grad_p, workspace, workspace_bytes, stream);
+    return launch_direct_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi_hist, sigma_bar_hist, xi_bar_hist,
+                                                           dxi_dp_hist, dsigma_dp_hist, grad_p, workspace, workspace_bytes, stream);
+}
+#endif
+
+#if CM_HAS_PART(6)
+int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi_hist,
+                       const double* lam_hist, const double* dxi_dp_hist, const double* sigma_bar_hist, const double* hss6,
+                       double* hess_pp, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return launch_hessian_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi_hist, lam_hist, dxi_dp_hist,
+                                                                     sigma_bar_hist, hss6, hess_pp, workspace, workspace_bytes, stream);
+    return launch_hessian_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sigma_bar_hist,
+                                                            hss6, hess_pp, workspace, workspace_bytes, stream);
+}
+#endif
+
 #if CM_HAS_PART(5)
 int cm_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    const double* xi, const double* dxi_prev_dp, double* dxi_dp, double* dsigma_dp, void* stream) {
@@ -1102,7 +1327,7 @@ int cm_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        hipLaunchKernelGGL((k_evaluate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, xi_prev, xi, C, jac, sigma, dsigma);
+        hipLaunchKernelGGL((k_evaluate<D, Y, kColdRot>), grid, block, 0, s, md, B, which, gradu, xi_prev, xi, C, jac, sigma, dsigma);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
@@ -1124,7 +1349,7 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
-        hipLaunchKernelGGL((k_evaluate_rate<D, Y, R>), grid, block, 0, s, md, B, which, gradu, gradu_prev, xi_prev, xi,
+        hipLaunchKernelGGL((k_evaluate_rate<D, Y, kColdRot>), grid, block, 0, s, md, B, which, gradu, gradu_prev, xi_prev, xi,
                            C, jac, sigma, dsigma);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1204,7 +1429,8 @@ int cm_objective_grad_rate(const cm_model_desc* m, int64_t B, const double* grad
 // the rate-form instantiations live in their own piece of the build (reached through cm_objective_grad_history)
 int cm_internal_history_rate(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* data_hist,
                              const double* wsq6, const double* xi0, double* xi_hist, double* out,
-                             void* workspace, int64_t workspace_bytes, void* stream);
+                             void* workspace, int64_t workspace_bytes, void* stream,
+                             const double* sbar_hist, const double* xibar_hist, double* lam_hist, int out_offset);
 #endif
 
 #if CM_HAS_PART(7) || CM_HAS_PART(8)
@@ -1232,8 +1458,10 @@ int cm_update_history(const cm_model_desc* m, int64_t B, int32_t K, const double
 #if CM_HAS_PART(8)
 int cm_internal_history_rate(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* data_hist,
                              const double* wsq6, const double* xi0, double* xi_hist, double* out,
-                             void* workspace, int64_t workspace_bytes, void* stream) {
-    return launch_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream);
+                             void* workspace, int64_t workspace_bytes, void* stream,
+                             const double* sbar_hist, const double* xibar_hist, double* lam_hist, int out_offset) {
+    return launch_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream,
+                                                         HistoryCotangents{sbar_hist, xibar_hist, lam_hist}, out_offset);
 }
 #endif
 
@@ -1243,8 +1471,20 @@ int cm_objective_grad_history(const cm_model_desc* m, int64_t B, int32_t K,
                               double* xi_hist, double* out, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!m) return CM_ERR_BAD_ARG;
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return cm_internal_history_rate(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream);
+        return cm_internal_history_rate(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream,
+                                        nullptr, nullptr, nullptr, 0);
     return launch_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out, workspace, workspace_bytes, stream);
+}
+
+int cm_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* sigma_bar_hist,
+                       const double* xi_bar_hist, const double* xi0, double* xi_hist, double* lam_hist, double* grad_p,
+                       void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!m || !grad_p || (B > 0 && !sigma_bar_hist)) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return cm_internal_history_rate(m, B, K, gradu_hist, nullptr, nullptr, xi0, xi_hist, grad_p, workspace, workspace_bytes, stream,
+                                        sigma_bar_hist, xi_bar_hist, lam_hist, 1);
+    return launch_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, nullptr, nullptr, xi0, xi_hist, grad_p, workspace, workspace_bytes,
+                                                    stream, HistoryCotangents{sigma_bar_hist, xi_bar_hist, lam_hist}, 1);
 }
 #endif
 

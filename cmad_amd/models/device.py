@@ -459,6 +459,86 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_objective_grad_history")
         return res, xi_hist
 
+    def _check_hist(self, t, rows, K, B, name):
+        torch = _torch()
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+                and tuple(t.shape) == (K + 1, rows, B)):
+            raise ValueError(f"{name}: expected a contiguous float64 CUDA tensor of shape ({K + 1}, {rows}, {B})")
+
+    def adjoint_history(self, gradu_hist, sigma_bar_hist, xi0, xi_bar_hist=None, want_lam=False, xi_hist=None):
+        """`cm_adjoint_history`: the adjoint recursion of a whole history for caller-supplied QoI cotangents.
+        Returns (grad_kp (12,) device, xi_hist (K+1, n_xi, B), lam_hist (K+1, n_xi, B) or None)."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        if K < 1:
+            raise ValueError("a load history needs at least one step after the initial configuration")
+        self._check_hist(gradu_hist, self.nu, K, B, "gradu_hist")
+        self._check_hist(sigma_bar_hist, 6, K, B, "sigma_bar_hist")
+        if xi_bar_hist is not None:
+            self._check_hist(xi_bar_hist, self.nx, K, B, "xi_bar_hist")
+        _check_soa(xi0, self.nx, B, "xi0")
+        dev = gradu_hist.device
+        if xi_hist is None:
+            xi_hist = torch.empty((K + 1, self.nx, B), dtype=torch.float64, device=dev)
+        lam = torch.zeros((K + 1, self.nx, B), dtype=torch.float64, device=dev) if want_lam else None
+        g = torch.empty(_lib.CM_NUM_PARAMS, dtype=torch.float64, device=dev)
+        ws, need = self._workspace(B, dev)
+        rc = self.L.cm_adjoint_history(C.byref(self.desc), B, K, _ptr(gradu_hist), _ptr(sigma_bar_hist), _ptr(xi_bar_hist), _ptr(xi0),
+                                       _ptr(xi_hist), _ptr(lam), _ptr(g), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_adjoint_history")
+        return g, xi_hist, lam
+
+    def direct_history(self, gradu_hist, xi_hist, sigma_bar_hist=None, xi_bar_hist=None, want_blocks=False):
+        """`cm_direct_history`: forward sensitivities over a stored history in one launch.  Returns (grad_kp (12,) device
+        or None, dxi_dp_hist (K+1, n_xi, 12, B) or None, dsigma_dp_hist (K+1, 6, 12, B) or None)."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        NP = _lib.CM_NUM_PARAMS
+        self._check_hist(gradu_hist, self.nu, K, B, "gradu_hist")
+        self._check_hist(xi_hist, self.nx, K, B, "xi_hist")
+        if sigma_bar_hist is None and not want_blocks:
+            raise ValueError("request the gradient (pass the QoI cotangents), the sensitivity blocks, or both")
+        if sigma_bar_hist is not None:
+            self._check_hist(sigma_bar_hist, 6, K, B, "sigma_bar_hist")
+        if xi_bar_hist is not None:
+            self._check_hist(xi_bar_hist, self.nx, K, B, "xi_bar_hist")
+        dev = gradu_hist.device
+        dx = torch.empty((K + 1, self.nx, NP, B), dtype=torch.float64, device=dev) if want_blocks else None
+        ds = torch.empty((K + 1, 6, NP, B), dtype=torch.float64, device=dev) if want_blocks else None
+        g = ws = None
+        need = 0
+        if sigma_bar_hist is not None:
+            g = torch.empty(NP, dtype=torch.float64, device=dev)
+            need = self.L.cm_direct_workspace_bytes(B)
+            ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
+        rc = self.L.cm_direct_history(C.byref(self.desc), B, K, _ptr(gradu_hist), _ptr(xi_hist), _ptr(sigma_bar_hist),
+                                      _ptr(xi_bar_hist), _ptr(dx), _ptr(ds), _ptr(g), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_direct_history")
+        return g, dx, ds
+
+    def hessian_history(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sigma_bar_hist, hss6):
+        """`cm_hessian_history`: d2J/dp2 (12, 12) device tensor, KP order, summed over the batch and the steps."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        NP = _lib.CM_NUM_PARAMS
+        self._check_hist(gradu_hist, self.nu, K, B, "gradu_hist")
+        self._check_hist(xi_hist, self.nx, K, B, "xi_hist")
+        self._check_hist(lam_hist, self.nx, K, B, "lam_hist")
+        self._check_hist(sigma_bar_hist, 6, K, B, "sigma_bar_hist")
+        if not (dxi_dp_hist.is_cuda and dxi_dp_hist.is_contiguous() and tuple(dxi_dp_hist.shape) == (K + 1, self.nx, NP, B)):
+            raise ValueError(f"dxi_dp_hist: expected a contiguous float64 CUDA tensor of shape ({K + 1}, {self.nx}, {NP}, {B})")
+        dev = gradu_hist.device
+        H = torch.empty((NP, NP), dtype=torch.float64, device=dev)
+        need = self.L.cm_hessian_workspace_bytes(C.byref(self.desc), B, K)
+        if need < 0:
+            _lib.check(int(need), "cm_hessian_workspace_bytes")
+        ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
+        h = (C.c_double * 6)(*[float(v) for v in hss6])
+        rc = self.L.cm_hessian_history(C.byref(self.desc), B, K, _ptr(gradu_hist), _ptr(xi_hist), _ptr(lam_hist), _ptr(dxi_dp_hist),
+                                       _ptr(sigma_bar_hist), h, _ptr(H), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_hessian_history")
+        return H
+
     def adjoint_step(self, gradu, xi_prev, xi, data6, wsq6, hist_in, hist_out, out, accumulate=True, gradu_prev=None):
         B = gradu.shape[1]
         _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev")

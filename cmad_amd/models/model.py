@@ -83,6 +83,24 @@ class Model(ABC):
         objective evaluations, and the description is a few hundred bytes)."""
         return DeviceEvaluator(*self._desc(newton=newton))
 
+    def history_engine(self, newton: NewtonSettings | None = None):
+        """Whole-history launches (cm_update_history, cm_objective_grad_history, cm_adjoint_history, cm_direct_history,
+        cm_hessian_history) for the CURRENT parameter values: what `cmad_amd.objectives` is built from."""
+        from .history_engine import HistoryEngine
+        return HistoryEngine(self.device_evaluator(newton))
+
+    def init_state(self, B: int = 1) -> np.ndarray:
+        """(n_xi, B) initial local state (reference `set_xi_to_init_vals`, :296-299)."""
+        x0 = np.concatenate([np.atleast_1d(np.asarray(b, dtype=np.float64)) for b in self._init_xi])
+        return np.repeat(x0[:, None], B, axis=1)
+
+    def active_hessian_from_kp(self, H_kp, g_kp, info=None):
+        """Kernel-order Hessian (12, 12) + gradient (12,) -> Hessian w.r.t. the NATIVE active parameters: the chain rule
+        through the elastic-constant map (lambda, mu)(E, nu, ...) adds sum_kp g_kp d2 kp / dp_i dp_j."""
+        info = info or self._desc()[1]
+        T1, T2 = self._param_chain(info)
+        return T1.T @ np.asarray(H_kp) @ T1 + np.einsum("k,kij->ij", np.asarray(g_kp), T2)
+
     @staticmethod
     def _flat(blocks) -> np.ndarray:
         return np.concatenate([np.atleast_1d(np.asarray(b, dtype=np.float64)).ravel() for b in blocks])

@@ -1,187 +1,113 @@
-"""Sensitivity-providing objectives for material-point calibration -- host mirror of
-/root/reference/cmad/objectives/mp_objective.py:23-215 (`MPObjective`, `MPAdjointObjective`,
-`MPDirectObjective`; same constructor, `evaluate(flat_active_values) -> GradientResult`, same loops).
-Every `model.evaluate*()` / `newton_solve` inside is a launch of the HIP library with B = 1; this is the
-reference's one-point-per-call shape kept for drop-in use.  For many points use
-`cmad_amd.objectives.batched.BatchedCalibrationObjective`, which runs the same mathematics as batched
-kernels (one launch per load step for the whole batch)."""
+"""Material-point calibration objectives with first- and second-order sensitivities, built on whole-history kernels.
+
+Public surface as the reference's (/root/reference/cmad/objectives/mp_objective.py:23-345): `MPObjective(qoi, global_state)`
+with `evaluate(flat_active_values)` (canonical values in) returning `GradientResult(J, grad)` -- `HessianResult(J, grad,
+hessian)` for `MPDirectAdjointObjective` -- in canonical parameters.  The construction is different: where the
+reference steps through the load history in Python and assembles every step from `model.evaluate()` blocks, each
+objective here is a fixed, small number of launches over the WHOLE history (`Model.history_engine()`):
+
+    MPAdjointObjective        Calibration QoI : 1 launch   cm_objective_grad_history (forward + adjoint, QoI fused)
+                              any other QoI   : 2 launches cm_update_history -> qoi.history_cotangents -> cm_adjoint_history
+    MPDirectObjective         2 launches      cm_update_history -> qoi.history_cotangents -> cm_direct_history
+    MPDirectAdjointObjective  4 launches      cm_update_history, cm_adjoint_history (keeps lam_k), cm_direct_history
+                                              (keeps dxi_k/dp), cm_hessian_history (sum_k D_k^T W_k D_k)
+
+The QoI differentiates only its own formula (dJ/dsigma, explicit dJ/dxi, diagonal curvature in sigma); the model
+derivatives, the recursions over the steps and the reductions happen in the kernels.  Sensitivities leave the kernels
+w.r.t. the 12 native kernel parameters (KP order, include/cmad_hip.h) and are chained to the active parameters of
+`cmad_amd.parameters.Parameters` by the model (`active_grad_from_kp`, `active_hessian_from_kp`), then to canonical ones.
+"""
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
 
 import numpy as np
 
-from ..models.global_fields import mp_U_from_F
-from ..models.nonlinear_solver import newton_solve
-from ..typing import GradientResult
+from ..typing import GradientResult, HessianResult
 
 
 class MPObjective(ABC):
+    """A QoI over the load history `global_state` = F (ndims, ndims, num_steps + 1) of one material point."""
+
     def __init__(self, qoi, global_state) -> None:
         self._qoi = qoi
         self._model = qoi.model()
-        self._parameters = qoi.model().parameters
-        self._global_state = global_state
-        self._num_steps = qoi.data().shape[-1] - 1
-        self._xi_at_step = [[None] * self._model.num_residuals for _ in range(self._num_steps + 1)]
-        self._model.store_xi(self._xi_at_step, self._model.xi(), 0)
+        self._parameters = self._model.parameters
+        F = np.asarray(global_state, dtype=np.float64)
+        nd, nsnap = F.shape[0], F.shape[2]
+        if qoi.data().shape[-1] != nsnap:
+            raise ValueError("the QoI data and the deformation history must have the same number of steps")
+        # grad u = F - I per snapshot as one SoA history of a single point: (K+1, ndims^2, 1)
+        self._gradu_hist = np.ascontiguousarray((np.moveaxis(F, 2, 0) - np.eye(nd)).reshape(nsnap, nd * nd, 1))
+        self._num_steps = nsnap - 1
 
     def evaluate(self, flat_active_values):
         self._parameters.set_active_values_from_flat(flat_active_values)
-        return self._evaluate()
+        return self._evaluate(self._model.history_engine())
 
     @abstractmethod
-    def _evaluate(self): ...
+    def _evaluate(self, engine): ...
 
-    def _forward_pass_with_storage(self) -> float:            # reference :62-89
-        qoi, model, F = self._qoi, self._model, self._global_state
-        model.set_xi_to_init_vals()
-        # the reference stores step 0 once, at construction (:51); re-storing it here keeps the adjoint
-        # right when the model was left in another state between construction and evaluation
-        model.store_xi(self._xi_at_step, model.xi(), 0)
-        J = 0.
-        for step in range(1, self._num_steps + 1):
-            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
-            newton_solve(model)
-            model.store_xi(self._xi_at_step, model.xi(), step)
-            model.seed_none()
-            qoi.evaluate(step)
-            J += qoi.J()
-            model.advance_xi()
-        return float(J)
+    # shared pieces -------------------------------------------------------------------------------------------------
+    def _primal_and_cotangents(self, engine):
+        """Forward pass with storage, then the QoI on the stored history: (xi0, xi_hist, J, sigma_bar_hist, xi_bar_hist)."""
+        xi0 = self._model.init_state(1)
+        xi_hist, sigma_hist = engine.primal(self._gradu_hist, xi0)
+        J, sbar, xibar = self._qoi.history_cotangents(sigma_hist, xi_hist)
+        return xi0, xi_hist, J, sbar, xibar
+
+    def _canonical_gradient(self, g_kp, info):
+        grad = self._model.active_grad_from_kp(g_kp, info)
+        native = grad.copy()
+        self._parameters.transform_grad(grad)
+        return grad, native
 
 
 class MPAdjointObjective(MPObjective):
-    """Gradient via reverse-time adjoint pass after a forward pass (reference :92-147)."""
+    """Gradient by the adjoint recursion: one solve with A_k^T per step, backwards in time."""
 
-    def _evaluate(self) -> GradientResult:
-        qoi, model, F = self._qoi, self._model, self._global_state
-        xi_at_step, num_steps = self._xi_at_step, self._num_steps
-        J = self._forward_pass_with_storage()
-        grad = np.zeros((1, model.parameters.num_active_params))
-        history_vec = np.zeros((model.num_dofs, 1))
-        for step in range(num_steps, 0, -1):
-            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
-            model.gather_xi(xi_at_step[step], xi_at_step[step - 1])
-            model.seed_xi()
-            model.evaluate()
-            dC_dxi = model.Jac()
-            qoi.evaluate(step)
-            dJ_dxi = qoi.dJ()
-            phi = np.linalg.solve(dC_dxi.T, -dJ_dxi.T + history_vec)
-            model.seed_xi_prev()
-            model.evaluate()
-            history_vec = -model.Jac().T @ phi
-            model.seed_params()
-            model.evaluate()
-            dC_dp = model.Jac()
-            qoi.evaluate(step)
-            grad += phi.T @ dC_dp + qoi.dJ()
-        grad = grad.squeeze()
-        model.parameters.transform_grad(grad)
-        return GradientResult(J=J, grad=grad)
+    def _evaluate(self, engine) -> GradientResult:
+        fused = self._qoi.fused_calibration()
+        if fused is not None:
+            wsq6, data6_hist, const = fused
+            J, g_kp = engine.calibration(self._gradu_hist, data6_hist, wsq6, self._model.init_state(1))
+            J += const
+        else:
+            xi0, _, J, sbar, xibar = self._primal_and_cotangents(engine)
+            g_kp, _ = engine.adjoint(self._gradu_hist, sbar, xi0, xibar)
+        grad, _ = self._canonical_gradient(g_kp, engine.info)
+        return GradientResult(J=float(J), grad=grad)
 
 
 class MPDirectObjective(MPObjective):
-    """Gradient via forward sensitivity (tangent) pass (reference :150-215)."""
+    """Gradient by forward sensitivities: dxi_k/dp carried through the history, contracted with the QoI cotangents."""
 
-    def _evaluate(self) -> GradientResult:
-        qoi, model, F = self._qoi, self._model, self._global_state
-        model.set_xi_to_init_vals()
-        nap = model.parameters.num_active_params
-        J = 0.
-        grad = np.zeros((1, nap))
-        dxi_dp = np.zeros((model.num_dofs, nap))
-        for step in range(1, self._num_steps + 1):
-            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
-            newton_solve(model)
-            model.seed_none()
-            qoi.evaluate(step)
-            J += qoi.J()
-            model.seed_xi()
-            model.evaluate()
-            dC_dxi = model.Jac()
-            qoi.evaluate(step)
-            dJ_dxi = qoi.dJ()
-            model.seed_xi_prev()
-            model.evaluate()
-            dC_dxi_prev = model.Jac()
-            model.seed_params()
-            model.evaluate()
-            dC_dp = model.Jac()
-            qoi.evaluate(step)
-            dJ_dp = qoi.dJ()
-            dxi_dp = np.linalg.solve(dC_dxi, -dC_dp - dC_dxi_prev @ dxi_dp)
-            grad += dJ_dxi @ dxi_dp + dJ_dp
-            model.advance_xi()
-        grad = grad.squeeze()
-        model.parameters.transform_grad(grad)
+    def _evaluate(self, engine) -> GradientResult:
+        _, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
+        g_kp, _ = engine.direct(self._gradu_hist, xi_hist, sbar, xibar)
+        grad, _ = self._canonical_gradient(g_kp, engine.info)
         return GradientResult(J=float(J), grad=grad)
 
 
 class MPDirectAdjointObjective(MPObjective):
-    """Gradient + Hessian via the direct-adjoint method (reference :218-345, arXiv:2501.04584): adjoint pass
-    storing phi per step, then a forward sensitivity pass contracting the second derivatives of the residual
-    (`model.evaluate_hessians()`, cm_hessians) and of the QoI with dxi/dp -- the reference's 13 einsum terms."""
+    """Gradient and Hessian by the direct-adjoint method (arXiv:2501.04584): with q_k = [xi_k, xi_{k-1}, p],
+    D_k = dq_k/dp from the forward sensitivities and lam_k from the adjoint pass,
 
-    def _evaluate(self):
-        from ..typing import HessianResult
-        qoi, model, F = self._qoi, self._model, self._global_state
-        xi_at_step, num_steps = self._xi_at_step, self._num_steps
-        J = self._forward_pass_with_storage()
-        nap = model.parameters.num_active_params
-        grad = np.zeros((1, nap))
-        num_dofs = model.num_dofs
-        history_vec = np.zeros((num_dofs, 1))
-        phi_at_step = [np.zeros(num_dofs)] * (num_steps + 1)
-        for step in range(num_steps, 0, -1):
-            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
-            model.gather_xi(xi_at_step[step], xi_at_step[step - 1])
-            model.seed_xi(); model.evaluate()
-            dC_dxi = model.Jac()
-            qoi.evaluate(step)
-            phi = np.linalg.solve(dC_dxi.T, -qoi.dJ().T + history_vec)
-            phi_at_step[step] = phi.squeeze()
-            model.seed_xi_prev(); model.evaluate()
-            history_vec = -model.Jac().T @ phi
-            model.seed_params(); model.evaluate()
-            dC_dp = model.Jac()
-            qoi.evaluate(step)
-            grad += phi.T @ dC_dp + qoi.dJ()
-        grad = grad.squeeze()
-        untransformed_grad = grad.copy()
-        model.parameters.transform_grad(grad)
+        d2J/dp2 = sum_k D_k^T ( d2J_k/dq2 - sum_r lam_k[r] d2C_k[r]/dq2 ) D_k
 
-        hessian = np.zeros((nap, nap))
-        dxi_dp_prev = np.zeros((num_dofs, nap))
-        for step in range(1, num_steps + 1):
-            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
-            model.gather_xi(xi_at_step[step], xi_at_step[step - 1])
-            model.seed_xi(); model.evaluate(); dC_dxi = model.Jac()
-            model.seed_xi_prev(); model.evaluate(); dC_dxi_prev = model.Jac()
-            model.seed_params(); model.evaluate(); dC_dp = model.Jac()
-            dxi_dp = np.linalg.solve(dC_dxi, -dC_dp - dC_dxi_prev @ dxi_dp_prev)
-            model.evaluate_hessians()
-            d2C_dxi2, d2C_dxi_dxi_prev, d2C_dxi_prev2 = model.d2C_dxi2, model.d2C_dxi_dxi_prev, model.d2C_dxi_prev2
-            d2C_dp2 = model.d2C_dparams2
-            d2C_dp_dxi = model.d2C_dxi_dparams.transpose((0, 2, 1))
-            d2C_dp_dxi_prev = model.d2C_dxi_prev_dparams.transpose((0, 2, 1))
-            qoi.evaluate_hessians(step)
-            d2J_dxi2, d2J_dp2, d2J_dp_dxi = qoi.d2J_dxi2, qoi.d2J_dparams2, qoi.d2J_dxi_dparams.T
-            phi = phi_at_step[step]
-            hessian += d2J_dp2 \
-                + np.einsum("q,qij->ij", phi, d2C_dp2) \
-                + np.einsum("ik,kj->ij", d2J_dp_dxi, dxi_dp) \
-                + np.einsum("q,qik,kj->ij", phi, d2C_dp_dxi, dxi_dp) \
-                + np.einsum("jk,ki->ij", d2J_dp_dxi, dxi_dp) \
-                + np.einsum("q,qjk,ki->ij", phi, d2C_dp_dxi, dxi_dp) \
-                + np.einsum("km,ki,mj->ij", d2J_dxi2, dxi_dp, dxi_dp) \
-                + np.einsum("q,qkm,ki,mj->ij", phi, d2C_dxi2, dxi_dp, dxi_dp) \
-                + np.einsum("q,qik,kj->ij", phi, d2C_dp_dxi_prev, dxi_dp_prev) \
-                + np.einsum("q,qkm,ki,mj->ij", phi, d2C_dxi_dxi_prev, dxi_dp, dxi_dp_prev) \
-                + np.einsum("q,qmk,ki,mj->ij", phi, d2C_dxi_dxi_prev, dxi_dp_prev, dxi_dp) \
-                + np.einsum("q,qkm,ki,mj->ij", phi, d2C_dxi_prev2, dxi_dp_prev, dxi_dp_prev) \
-                + np.einsum("q,qjk,ki->ij", phi, d2C_dp_dxi_prev, dxi_dp_prev)
-            dxi_dp_prev = dxi_dp
-        model.parameters.transform_hessian(hessian, untransformed_grad)
-        return HessianResult(J=J, grad=grad, hessian=hessian)
+    evaluated per step on the device (`cm_hessian_history`)."""
+
+    def _evaluate(self, engine) -> HessianResult:
+        qoi, model = self._qoi, self._model
+        hss6 = qoi.stress_curvature()
+        xi0, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
+        if xibar is not None:
+            raise NotImplementedError("the second-order pass takes QoIs of the stress only")
+        g_kp, lam_hist = engine.adjoint(self._gradu_hist, sbar, xi0, want_lam=True)
+        _, dxi_dp_hist = engine.direct(self._gradu_hist, xi_hist, sbar, want_blocks=True)
+        H_kp = engine.hessian(self._gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar, hss6)
+        grad, native_grad = self._canonical_gradient(g_kp, engine.info)
+        hessian = model.active_hessian_from_kp(H_kp, g_kp, engine.info)
+        hessian = 0.5 * (hessian + hessian.T)
+        self._parameters.transform_hessian(hessian, native_grad)
+        return HessianResult(J=float(J), grad=grad, hessian=hessian)

@@ -54,6 +54,28 @@ class Calibration(QoI):
             self._dJ = np.atleast_2d(np.einsum("ij,ijk->k", w * mismatch, ds))
         model._deriv_mode = saved[0]
 
+    def _folded(self):
+        """Squared weights of the 6 stored entries, the equivalent symmetric data and the constant the folding leaves
+        (models/device.py `fold_weight_and_data`)."""
+        from ..models.device import fold_weight_and_data
+        wsq6, data6, const = fold_weight_and_data(self._weight, np.asarray(self._data))       # (6,), (6, K+1), (K+1,)
+        return wsq6, data6, const
+
+    def fused_calibration(self):
+        wsq6, data6, const = self._folded()
+        return wsq6, np.ascontiguousarray(data6.T[:, :, None]), float(np.sum(const[1:]))
+
+    def stress_curvature(self):
+        return self._folded()[0]
+
+    def history_cotangents(self, sigma_hist, xi_hist):
+        wsq6, data6, const = self._folded()
+        mism = sigma_hist - data6.T[:, :, None]                       # (K+1, 6, B)
+        sbar = wsq6[None, :, None] * mism
+        sbar[0] = 0.0
+        J = 0.5 * float(np.sum(sbar[1:] * mism[1:])) + float(np.sum(const[1:])) * sigma_hist.shape[2]
+        return J, sbar, None
+
     def evaluate_hessians(self, step) -> None:
         """d2J_dxi2 (n_xi, n_xi), d2J_dxi_dparams (n_xi, P), d2J_dparams2 (P, P) of qoi.py:160-188.
         The mixed block is the true d2J/dxi dparams; the reference builds it from jacfwd(..., DXI_PREV)

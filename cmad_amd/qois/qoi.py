@@ -36,6 +36,22 @@ class QoI(ABC):
     def weight(self):
         return self._weight
 
+    # ---- whole-history protocol used by cmad_amd.objectives (the kernels differentiate the model, the QoI its own formula)
+    def history_cotangents(self, sigma_hist, xi_hist):
+        """Evaluate the QoI on a whole history: sigma_hist (K+1, 6, B) stored global stress entries [xx,xy,xz,yy,yz,zz],
+        xi_hist (K+1, n_xi, B).  Returns (J, sigma_bar_hist (K+1, 6, B) = dJ/dsigma, xi_bar_hist (K+1, n_xi, B) = explicit
+        dJ/dxi or None); slot 0 is the initial configuration and carries no contribution."""
+        raise NotImplementedError
+
+    def stress_curvature(self):
+        """Diagonal d2J_k/dsigma_r^2 over the 6 stored entries (constant in time), for the second-order pass."""
+        raise NotImplementedError("this QoI has no second-order pass")
+
+    def fused_calibration(self):
+        """(wsq6, data6_hist (K+1, 6, 1), constant) when the QoI is the weighted stress mismatch the kernels fuse
+        (cm_objective_grad_history), else None."""
+        return None
+
     def data_at_step(self, step):
         raise NotImplementedError
 

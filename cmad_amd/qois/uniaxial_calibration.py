@@ -34,6 +34,26 @@ class UniaxialCalibration(QoI):
     def weight_at_step(self, step):
         return self._weight[:, step]
 
+    def history_cotangents(self, sigma_hist, xi_hist):
+        """J = 1/2 sum_k || w_k o ([sigma_aa, stretch_1 - 1, stretch_2 - 1]_k - data_k) ||^2 (uniaxial_calibration.py:70-85):
+        the stress term contributes dJ/dsigma_aa, the stretches are state variables and contribute dJ/dxi directly."""
+        a = self._idx
+        r_aa = (0, 3, 5)[a]                                            # slot of (a, a) in [xx,xy,xz,yy,yz,zz]
+        off = self._model.delta_xi_offset(self._svar, 0)
+        K1, _, B = sigma_hist.shape
+        d, w = np.asarray(self._data), np.asarray(self._weight)       # (3, K+1)
+        pred = np.stack([sigma_hist[:, r_aa, :], xi_hist[:, off, :] - 1.0, xi_hist[:, off + 1, :] - 1.0], axis=1)   # (K+1, 3, B)
+        wm = (pred - d.T[:, :, None]) * w.T[:, :, None]
+        wm[0] = 0.0
+        J = 0.5 * float(np.sum(wm * wm))
+        cot = wm * w.T[:, :, None]
+        sbar = np.zeros_like(sigma_hist)
+        sbar[:, r_aa, :] = cot[:, 0, :]
+        xibar = np.zeros_like(xi_hist)
+        xibar[:, off, :] = cot[:, 1, :]
+        xibar[:, off + 1, :] = cot[:, 2, :]
+        return J, sbar, xibar
+
     def evaluate(self, step) -> None:
         """reference qoi.py:80-110 with `_qoi` of uniaxial_calibration.py:70-85."""
         model = self._model

@@ -108,7 +108,7 @@ typedef struct cm_model_desc {
 } cm_model_desc;
 
 /* library / build info */
-int  cm_abi_version(void);                       /* 3: cm_model_desc.yc holds 19 entries (Barlat), beta_* fields */
+int  cm_abi_version(void);                       /* 4: + cm_adjoint_history, cm_direct_history, cm_hessian_history */
 const char* cm_last_hip_error(void);             /* name of the last HIP error behind a CM_ERR_LAUNCH */
 int  cm_sizeof_model_desc(void);                 /* sizeof(cm_model_desc) as compiled, for binding checks */
 int  cm_num_xi(const cm_model_desc* m);          /* local dofs per point, <0 if unsupported */
@@ -338,6 +338,63 @@ int cm_update_history(const cm_model_desc* m, int64_t B, int32_t K, const double
 int cm_direct_step(const cm_model_desc* m, int64_t B,
                    const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                    const double* dxi_prev_dp, double* dxi_dp, double* dsigma_dp, void* stream);
+
+/*
+ * cm_adjoint_history: the adjoint recursion of a whole K-step load history per point for an ARBITRARY quantity of
+ * interest, one launch.  Replaces MPAdjointObjective._evaluate's reverse loop (cmad/objectives/mp_objective.py:112-142)
+ * for any QoI (cmad/qois/qoi.py:80-110): the caller evaluates its QoI on the stresses / states of cm_update_history and
+ * hands in, per step, sigma_bar = dJ_k/dsigma (the 6 stored global entries) and, optionally, xi_bar = the explicit
+ * dJ_k/dxi (e.g. the lateral stretches of cmad/qois/uniaxial_calibration.py:70-85).  The forward pass is recomputed
+ * with the state in registers (as in cm_objective_grad_history), then
+ *     lam_k = A_k^-T ((dsigma/dxi)^T sigma_bar_k + xi_bar_k + incoming) ,   grad += sigma_bar_k . dsigma/dp - lam_k . dC_k/dp
+ *   in : gradu_hist[(K+1)][n_gradu][B], sigma_bar_hist[(K+1)][6][B], xi_bar_hist[(K+1)][n_xi][B] (NULL = none;
+ *        slot 0 of both unused), xi0[n_xi][B]
+ *   out: xi_hist[(K+1)][n_xi][B], lam_hist[(K+1)][n_xi][B] (NULL = not stored; slot 0 unused; the reference's
+ *        phi_k = -lam_k, what the second-order pass cm_hessian_history needs), grad_p[CM_NUM_PARAMS] summed over the batch
+ */
+int cm_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K,
+                       const double* gradu_hist, const double* sigma_bar_hist, const double* xi_bar_hist, const double* xi0,
+                       double* xi_hist, double* lam_hist, double* grad_p,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * cm_direct_history: the forward-sensitivity recursion of MPDirectObjective._evaluate
+ * (cmad/objectives/mp_objective.py:158-215) over a stored K-step history per point, one launch (= K cm_direct_step
+ * calls with the sensitivity block carried from step to step), with the gradient contraction on the device:
+ *     grad_p[j] = sum_b sum_k sigma_bar_k . dsigma_k/dp_j + xi_bar_k . dxi_k/dp_j
+ *   in : gradu_hist[(K+1)][n_gradu][B], xi_hist[(K+1)][n_xi][B] (converged states, e.g. from cm_update_history),
+ *        sigma_bar_hist[(K+1)][6][B] / xi_bar_hist[(K+1)][n_xi][B] (QoI cotangents as in cm_adjoint_history; needed
+ *        only when grad_p is requested, xi_bar_hist may be NULL)
+ *   out (each may be NULL, not all): dxi_dp_hist[(K+1)][n_xi*CM_NUM_PARAMS][B], dsigma_dp_hist[(K+1)][6*CM_NUM_PARAMS][B]
+ *        (slot 0 = 0; entry layout as cm_direct_step), grad_p[CM_NUM_PARAMS]
+ *   workspace: cm_direct_workspace_bytes(B) when grad_p is requested
+ */
+int64_t cm_direct_workspace_bytes(int64_t B);
+int cm_direct_history(const cm_model_desc* m, int64_t B, int32_t K,
+                      const double* gradu_hist, const double* xi_hist,
+                      const double* sigma_bar_hist, const double* xi_bar_hist,
+                      double* dxi_dp_hist, double* dsigma_dp_hist, double* grad_p,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * cm_hessian_history: Hessian of the objective w.r.t. the CM_NUM_PARAMS native parameters by the direct-adjoint method,
+ * replacing the second loop of MPDirectAdjointObjective._evaluate (cmad/objectives/mp_objective.py:283-341) together
+ * with Model.evaluate_hessians (cmad/models/model.py:245-270) and the QoI Hessians (cmad/qois/qoi.py:160-188).
+ * With q = [xi_k, xi_{k-1}, p] and D_k = dq/dp = [dxi_k/dp ; dxi_{k-1}/dp ; I]:
+ *     hess_pp = sum_b sum_k D_k^T W_k D_k ,
+ *     W_k[a][b] = sigma_bar_k . d2sigma/dq_a dq_b + sum_r hss_r dsigma_r/dq_a dsigma_r/dq_b - lam_k . d2C_k/dq_a dq_b
+ * (the reference's 13 einsum terms are the blocks of this one quadratic form).  hss6[6] (HOST) is the diagonal
+ * d2J_k/dsigma_r^2 of the QoI in the 6 stored entries (Calibration: the folded squared weights, as wsq6).
+ *   in : gradu_hist, xi_hist (converged), lam_hist (cm_adjoint_history), dxi_dp_hist (cm_direct_history), sigma_bar_hist
+ *   out: hess_pp[CM_NUM_PARAMS * CM_NUM_PARAMS] row-major, KP order
+ *   workspace: cm_hessian_workspace_bytes(m, B, K)
+ * J2 / Hill / Hosford; both model kinds (rate form: FULL_3D, PLANE_STRESS).
+ */
+int64_t cm_hessian_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K);
+int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K,
+                       const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* dxi_dp_hist,
+                       const double* sigma_bar_hist, const double* hss6, double* hess_pp,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,11 +19,10 @@ def golden_dir():
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no built artefacts (they are git-ignored): build the HIP library (hipcc cross-compiles
-    without a GPU) and the CPU oracle once, only if they are missing."""
+    """Build the HIP library (hipcc cross-compiles without a GPU) and the CPU oracle when they are missing OR older than
+    their sources (both builders compare mtimes and return at once when nothing changed): a test run never validates a
+    stale binary after an edit to the kernels or the oracle."""
     from cmad_amd import build
-    if not os.path.exists(build.LIB):
-        build.build()
+    build.build()
     import oracle_lib
-    if not os.path.exists(os.path.join(ROOT, "oracle", "libcmad_oracle.so")):
-        oracle_lib.build(force=True)
+    oracle_lib.build()

@@ -11,7 +11,37 @@ from cmad_amd.models.deriv_types import DerivType
 from cmad_amd.models.device import NewtonSettings
 
 
+class HostHistoryEngine:
+    """`cmad_amd.models.history_engine.HistoryEngine` with every launch replaced by the host build of the same per-point
+    code (cm::primal_history_point, history_point, direct_history_point, hessian_weight)."""
+
+    def __init__(self, model=None, newton=None, desc=None, info=None):
+        self._desc, self.info = model._desc(newton=newton) if model is not None else (desc, info)
+
+    def primal(self, gradu_hist, xi0):
+        xi_hist, sig_hist, _ = hh.primal_history(self._desc, gradu_hist, xi0)
+        return xi_hist, sig_hist
+
+    def calibration(self, gradu_hist, data6_hist, wsq6, xi0):
+        out, _ = hh.history(self._desc, gradu_hist, data6_hist, wsq6, xi0)
+        return float(out[0]), out[1:]
+
+    def adjoint(self, gradu_hist, sbar_hist, xi0, xibar_hist=None, want_lam=False):
+        g, _, lam = hh.adjoint_history(self._desc, gradu_hist, sbar_hist, xi0, xibar_hist, want_lam=want_lam)
+        return g, lam
+
+    def direct(self, gradu_hist, xi_hist, sbar_hist, xibar_hist=None, want_blocks=False):
+        g, dx, _ = hh.direct_history(self._desc, gradu_hist, xi_hist, sbar_hist, xibar_hist, want_blocks=want_blocks)
+        return g, dx
+
+    def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss6):
+        return hh.hessian_history(self._desc, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss6)
+
+
 class HostSmallElasticPlastic(SmallElasticPlastic):
+    def history_engine(self, newton=None):
+        return HostHistoryEngine(self, newton)
+
     def _point_evaluate(self, which, xi, xi_prev, params, U, want_jac=True, U_prev=None):
         desc, info = self._desc(params)
         nx = self.num_dofs

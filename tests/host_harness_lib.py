@@ -104,6 +104,55 @@ def history(desc, gradu_hist, data_hist, wsq6, xi0):
     return out, xi_hist
 
 
+def adjoint_history(desc, gradu_hist, sbar_hist, xi0, xibar_hist=None, want_lam=False):
+    """cm_adjoint_history on the host build: (grad KP (12,), xi_hist (K+1, nx, B), lam_hist (K+1, nx, B) or None)."""
+    L = lib()
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    gradu_hist, sbar_hist, xibar_hist, xi0 = c(gradu_hist), c(sbar_hist), c(xibar_hist), c(xi0)
+    K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+    xi_hist = np.zeros((K + 1,) + xi0.shape); grad = np.zeros(12)
+    lam = np.zeros((K + 1,) + xi0.shape) if want_lam else None
+    rc = L.hh_adjoint_history(C.byref(desc), C.c_int64(B), C.c_int(K), _p(gradu_hist), _p(sbar_hist), _p(xibar_hist), _p(xi0),
+                              _p(xi_hist), _p(lam), _p(grad))
+    assert rc == 0
+    return grad, xi_hist, lam
+
+
+def direct_history(desc, gradu_hist, xi_hist, sbar_hist=None, xibar_hist=None, want_blocks=True):
+    """cm_direct_history on the host build: (grad KP (12,), dxi_dp_hist (K+1, nx, 12, B), dsigma_dp_hist (K+1, 6, 12, B))."""
+    L = lib()
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    gradu_hist, xi_hist, sbar_hist, xibar_hist = c(gradu_hist), c(xi_hist), c(sbar_hist), c(xibar_hist)
+    K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
+    dx = np.zeros((K + 1, nx, 12, B)) if want_blocks else None
+    ds = np.zeros((K + 1, 6, 12, B)) if want_blocks else None
+    grad = np.zeros(12)
+    rc = L.hh_direct_history(C.byref(desc), C.c_int64(B), C.c_int(K), _p(gradu_hist), _p(xi_hist), _p(sbar_hist), _p(xibar_hist),
+                             _p(dx), _p(ds), _p(grad))
+    assert rc == 0
+    return grad, dx, ds
+
+
+def hessian_history(desc, gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss6):
+    """cm_hessian_history on the host build: stage 1 (W per point and step) by cm::hessian_weight, the quadratic form
+    sum D^T W D in numpy.  Returns hess (12, 12), KP order."""
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss6 = map(c, (gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss6))
+    K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
+    nq = 2 * nx + 12
+    W = np.zeros((K, B, nq, nq))
+    rc = L.hh_hessian_weights(C.byref(desc), C.c_int64(B), C.c_int(K), _p(gradu_hist), _p(xi_hist), _p(lam_hist), _p(sbar_hist),
+                              _p(hss6), _p(W))
+    assert rc == 0
+    H = np.zeros((12, 12))
+    for k in range(1, K + 1):
+        for b in range(B):
+            D = np.vstack([dx_dp_hist[k, :, :, b], dx_dp_hist[k - 1, :, :, b], np.eye(12)])
+            H += D.T @ W[k - 1, b] @ D
+    return H
+
+
 def direct_step(desc, gradu, xi_prev, xi, dxp_dp=None, gradu_prev=None):
     """cm::direct_point over the batch: dxi_dp (nx, 12, B), dsigma_dp (6, 12, B)."""
     L = lib()

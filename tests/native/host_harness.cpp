@@ -238,11 +238,14 @@ struct HostRowsIO {
     template <int N> void store(double* base, int64_t row0, const double* v) const { for (int k = 0; k < N; ++k) base[(row0 + k) * B + b] = v[k]; }
     void phase_barrier() const {}
     void store_status(uint32_t* base, int64_t row, uint32_t v) const { base[row * B + b] = v; }
+    double get(const double* base, int64_t row) const { return base[row * B + b]; }
+    void put(double* base, int64_t row, double v) const { base[row * B + b] = v; }
 };
 
 template <int DEF, int YK, bool ROT, int MK>
 static void run_history(const cm_model_desc& m, int64_t B, int K, const double* gradu_hist, const double* data_hist,
-                        const double* wsq6, const double* xi0, double* xi_hist, double* out) {
+                        const double* wsq6, const double* xi0, double* xi_hist, double* out,
+                        HistoryCotangents hc = HistoryCotangents{nullptr, nullptr, nullptr}) {
     for (int k = 0; k < 1 + CM_NUM_PARAMS; ++k) out[k] = 0.0;
     const bool ls = m.ls_max_evals > 0;
     for (int64_t b = 0; b < B; ++b) {
@@ -253,14 +256,14 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
         bool done = false;
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && DEF == CM_FULL_3D && YK == CM_YIELD_J2) {   // same choice as launch_history
             if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
-                if (ls) history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
-                else history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
+                if (ls) history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
+                else history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
                 done = true;
             }
         }
         if (done) {}
-        else if (ls) history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
-        else history_point<DEF, YK, ROT, false, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red);
+        else if (ls) history_point<DEF, YK, ROT, true, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
+        else history_point<DEF, YK, ROT, false, MK>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
         for (int k = 0; k < 1 + CM_NUM_PARAMS; ++k) out[k] += red[k];
     }
 }
@@ -413,6 +416,71 @@ int hh_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+}
+#endif
+#if HH_HAS(6)
+// cm_adjoint_history: the history adjoint for caller-supplied QoI cotangents (grad[12] = KP gradient)
+int hh_adjoint_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* sbar_hist,
+                       const double* xibar_hist, const double* xi0, double* xi_hist, double* lam_hist, double* grad) {
+    double out[1 + CM_NUM_PARAMS];
+    const double wsq0[6] = {0, 0, 0, 0, 0, 0};
+    const HistoryCotangents hc{sbar_hist, xibar_hist, lam_hist};
+    int rc;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        rc = dispatch(m, [&]<int D, int Y, bool R>() {
+            if constexpr (!is_dense_yield(Y)) run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, nullptr, wsq0, xi0, xi_hist, out, hc); });
+    else
+        rc = dispatch<true>(m, [&]<int D, int Y, bool R>() {
+            run_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, nullptr, wsq0, xi0, xi_hist, out, hc); });
+    for (int j = 0; j < CM_NUM_PARAMS; ++j) grad[j] = out[1 + j];
+    return rc;
+}
+#endif
+#if HH_HAS(3)
+// cm_direct_history (cm::direct_history_point over the batch)
+int hh_direct_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi_hist,
+                      const double* sbar_hist, const double* xibar_hist, double* dx_dp_hist, double* ds_dp_hist, double* grad) {
+    for (int j = 0; j < CM_NUM_PARAMS; ++j) grad[j] = 0.0;
+    auto body = [&]<int D, int Y, bool R, int MK>() {
+        for (int64_t b = 0; b < B; ++b) {
+            double g[CM_NUM_PARAMS];
+            direct_history_point<D, Y, true, MK>(*m, K, gradu_hist, xi_hist, sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist, HostRowsIO{B, b}, g);
+            for (int j = 0; j < CM_NUM_PARAMS; ++j) grad[j] += g[j];
+        }
+    };
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+}
+#endif
+#if HH_HAS(4)
+// stage 1 of cm_hessian_history: W[(step-1)*B + pt][NQ][NQ] (cm::hessian_weight per pair)
+int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi_hist,
+                       const double* lam_hist, const double* sbar_hist, const double* hss6, double* W) {
+    auto body = [&]<int D, int Y, bool R, int MK>() {
+        constexpr int NX = nx_of<D, MK>(), NU = Dims<D>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
+        for (int step = 1; step <= K; ++step) for (int64_t pt = 0; pt < B; ++pt) {
+            double G[NU], xp[NX], x[NX], lam[NX], sbar[6];
+            for (int k = 0; k < NU; ++k) {
+                G[k] = gradu_hist[((int64_t)step * NU + k) * B + pt];
+                if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_hist[((int64_t)(step - 1) * NU + k) * B + pt];
+            }
+            for (int k = 0; k < NX; ++k) {
+                xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + pt];
+                x[k] = xi_hist[((int64_t)step * NX + k) * B + pt];
+                lam[k] = lam_hist[((int64_t)step * NX + k) * B + pt];
+            }
+            for (int r = 0; r < 6; ++r) sbar[r] = sbar_hist[((int64_t)step * 6 + r) * B + pt];
+            const int64_t ps = (int64_t)(step - 1) * B + pt;
+            for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
+                const double w = hessian_weight<D, Y, true, MK>(*m, G, x, xp, lam, sbar, hss6, a, b);
+                W[(ps * NQ + a) * NQ + b] = w; W[(ps * NQ + b) * NQ + a] = w;
+            }
+        }
+    };
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
 #if HH_HAS(0)

@@ -541,3 +541,222 @@ def check_edge_cases(backend):
     ok = cv_o.astype(bool) & ((status.astype(np.uint32) >> 16) & 1).astype(bool)
     assert ok.mean() > 0.99
     np.testing.assert_allclose(xi_d[:, ok], xi_o[:, ok], rtol=1e-10, atol=1e-11)
+
+
+# ---- second derivatives (cm_hessians / cm_hessians_rate) against the oracle's nested duals -----------------------------
+# `hessians(desc, gradu, xi_prev, xi, nx, gradu_prev=None, values=False)` and `evaluate(desc, which, gradu, xi_prev, xi, nx)`
+# / `evaluate_rate(desc, which, gradu, gradu_prev, xi_prev, xi, nx)` are numpy-in / numpy-out wrappers of the host build
+# (tests/host_harness_lib.py) or of the C-ABI on the GPU (tests/gpu_api.py): the same assertions run on both.
+KP2O = [ol.P_EL1, ol.P_EL0, ol.P_Y, ol.P_VOCE_S, ol.P_VOCE_D, ol.P_LIN_K] + [ol.P_YC + j for j in range(6)]
+_V6_OF_9 = [0, 1, 2, 4, 5, 8]
+
+
+def _lame_values(rng, yield_kind, kw, rot=True):
+    values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+    E, nu = values["elastic"]["E"], values["elastic"]["nu"]
+    values["elastic"] = {"lambda": E * nu / ((1 + nu) * (1 - 2 * nu)), "mu": E / (2 * (1 + nu))}   # KP == native
+    return values
+
+
+def check_second_derivs(hessians, evaluate, def_type, yield_kind, kw, plastic, rot=True, seed=12):
+    """Every block of d2C and d2 sigma w.r.t. (xi, xi_prev, params) vs the oracle, and the first derivatives of the same
+    pass vs the hand-derived cm_evaluate blocks (reference cmad/models/model.py:133-147, 245-270)."""
+    from cmad_amd.models.device import build_desc
+    from test_oracle_vs_torch_ad import _state
+    rng = np.random.default_rng(seed)
+    values = _lame_values(rng, yield_kind, kw, rot)
+    mat = ol.Material(values, def_type=def_type, uniaxial_idx=1)
+    desc, info = build_desc(values, def_type=def_type, uniaxial_stress_idx=1)
+    for _ in range(50):
+        xi, xp, U = _state(rng, mat, plastic)
+        if (mat.yield_state(xi, U)[1] > 0) == plastic:
+            break
+    nx = mat.nx
+    d2C, d2S, dC, dS = hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    oC, oS = mat.second_derivs(xi, xp, U)
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in KP2O]
+    refC = oC[:, qmap][:, :, qmap]
+    refS = oS[_V6_OF_9][:, qmap][:, :, qmap]
+    if yield_kind != "hill":                 # yc slots are unused for J2; Hosford's exponent is compared too
+        keep = list(range(2 * nx + 6)) + ([2 * nx + 6] if yield_kind == "hosford" else [])
+    else:
+        keep = list(range(2 * nx + 12))
+    sel = np.ix_(range(nx), keep, keep)
+    scale = max(1.0, np.abs(refC[sel]).max())
+    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * scale)
+    sel6 = np.ix_(range(6), keep, keep)
+    np.testing.assert_allclose(d2S[0][sel6], refS[sel6], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refS[sel6]).max()))
+    # first derivatives of the same pass == hand-derived blocks
+    for which, lo in ((0, 0), (1, nx)):
+        C_, J, s_, S = evaluate(desc, which, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+        np.testing.assert_allclose(dS[0][:, lo:lo + nx], S[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(S).max()))
+    C_, J, s_, S = evaluate(desc, 2, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    npar = 12 if yield_kind == "hill" else 6
+    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], J[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+    np.testing.assert_allclose(dS[0][:, 2 * nx:2 * nx + npar], S[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(S).max()))
+    # and the first derivatives against the oracle directly (dC/dxi, dC/dxi_prev, dC/dparams)
+    for which, lo in ((ol.W_XI, 0), (ol.W_XI_PREV, nx)):
+        Jo = mat.jacobian(which, xi, xp, U)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], Jo, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+    Jp = mat.jacobian(ol.W_PARAMS, xi, xp, U)[:, KP2O]
+    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], Jp[:, :npar], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jp).max()))
+
+
+def check_rate_second_derivs(hessians, evaluate_rate, def_type, yield_kind, kw, plastic, rot=True, seed=21):
+    """cm_hessians_rate vs the oracle's nested duals, both branches; first derivatives of the same pass vs the
+    hand-derived cm_evaluate_rate blocks."""
+    from cmad_amd.models.device import build_desc
+    rng = np.random.default_rng(seed)
+    values = _lame_values(rng, yield_kind, kw, rot)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1)
+    nx, nd = mat.nx, (3 if def_type == ol.FULL_3D else 2)
+    for _ in range(200):
+        sdev = rng.normal(size=6) * (260.0 if plastic else 60.0)
+        xi = np.r_[sdev, abs(rng.normal()) * 2e-3] if nx == 7 else np.r_[sdev, abs(rng.normal()) * 2e-3, 1.0 + 1e-3 * rng.normal()]
+        xp = xi.copy(); xp[:6] -= rng.normal(size=6) * 20.0; xp[6] *= 0.5
+        if nx == 8:
+            xp[7] = 1.0 + 1e-3 * rng.normal()
+        U, Up = rng.normal(size=nd * nd) * 2e-3, rng.normal(size=nd * nd) * 1e-3
+        f = mat.yield_state(xi, U)[1]
+        if (f > 1e-6) == plastic and abs(f) > 1e-6:
+            break
+    else:
+        raise AssertionError("no state on the requested branch")
+    d2C, d2S, dC, dS = hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx, gradu_prev=Up.reshape(-1, 1))
+    oC, oS = mat.second_derivs(xi, xp, U, Up)
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in KP2O]
+    refC = oC[:, qmap][:, :, qmap]
+    keep = list(range(2 * nx + (12 if yield_kind == "hill" else 6))) + ([2 * nx + 6] if yield_kind == "hosford" else [])
+    sel = np.ix_(range(nx), keep, keep)
+    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refC[sel]).max()))
+    assert not d2S.any()                                       # sigma = Q x[0:6] Q^T is linear in the state
+    for which, lo in ((0, 0), (1, nx)):
+        C_, J, s_, S = evaluate_rate(desc, which, U.reshape(-1, 1), Up.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+        np.testing.assert_allclose(dS[0][:, lo:lo + nx], S[:, :, 0], rtol=1e-9, atol=1e-12)
+    C_, J, s_, S = evaluate_rate(desc, 2, U.reshape(-1, 1), Up.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    npar = 12 if yield_kind == "hill" else 6
+    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], J[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+    for which, lo in ((ol.W_XI, 0), (ol.W_XI_PREV, nx)):
+        Jo = mat.jacobian(which, xi, xp, U, Up)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], Jo, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+
+
+def check_rate_uniaxial_dual(hessians, yield_kind, kw, idx, plastic):
+    """small_rate_elastic_plastic under UNIAXIAL_STRESS (12 local dofs, small_rate_elastic_plastic.py:171-196, :34-75,
+    :249-346), served by dual-number evaluation of the residual in the product code (cm_hessians_rate): residual, stress,
+    every first-derivative block and the second derivatives against the oracle."""
+    from cmad_amd.models.device import build_desc
+    rng = np.random.default_rng(31 + idx)
+    values = _lame_values(rng, yield_kind, kw)
+    mat = ol.Material(values, def_type=ol.UNIAXIAL_STRESS, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=idx)
+    desc, info = build_desc(values, def_type=ol.UNIAXIAL_STRESS, model_kind=1, uniaxial_stress_idx=idx)
+    nx = mat.nx
+    assert nx == 12
+    for _ in range(200):
+        xi = np.r_[rng.normal(size=6) * (260.0 if plastic else 60.0), abs(rng.normal()) * 2e-3,
+                   1.0 + 1e-3 * rng.normal(size=2), 1e-3 * rng.normal(size=3)]
+        xp = xi.copy(); xp[:6] -= rng.normal(size=6) * 20.0; xp[6] *= 0.5; xp[7:9] = 1.0 + 1e-3 * rng.normal(size=2)
+        xp[9:] = 1e-3 * rng.normal(size=3)                       # unused by the residual (the shear unknowns are increments)
+        U, Up = rng.normal(size=1) * 2e-3, rng.normal(size=1) * 1e-3
+        f = mat.yield_state(xi, U)[1]
+        if (f > 1e-6) == plastic and abs(f) > 1e-6:
+            break
+    else:
+        raise AssertionError("no state on the requested branch")
+    d2C, d2S, dC, dS, C0, S0 = hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx,
+                                        gradu_prev=Up.reshape(-1, 1), values=True)
+    np.testing.assert_allclose(C0[0], mat.residual(xi, xp, U, Up), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(S0[0], np.asarray(mat.cauchy(xi, U)).reshape(9)[_V6_OF_9], rtol=1e-12, atol=1e-10)
+    for which, lo in ((ol.W_XI, 0), (ol.W_XI_PREV, nx)):
+        J = mat.jacobian(which, xi, xp, U, Up)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(J).max()))
+    Jp = mat.jacobian(ol.W_PARAMS, xi, xp, U, Up)[:, KP2O]
+    npar = 12 if yield_kind == "hill" else 6
+    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], Jp[:, :npar], rtol=1e-9, atol=1e-12 * max(1.0, np.abs(Jp).max()))
+    oC, oS = mat.second_derivs(xi, xp, U, Up)
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in KP2O]
+    refC = oC[:, qmap][:, :, qmap]
+    keep = list(range(2 * nx + npar))
+    sel = np.ix_(range(nx), keep, keep)
+    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refC[sel]).max()))
+
+
+# ---- whole-history first- and second-order sensitivities against an assembly from the oracle's AD blocks ---------------
+def check_history_second_order(engine, desc_info, def_type, yield_kind, kw, rate=False, B=3, K=4, seed=5):
+    """cm_adjoint_history (gradient, lam per step), cm_direct_history (gradient, dxi/dp per step) and cm_hessian_history
+    (d2J/dp2) for a generic stress QoI J = sum_k 1/2 hss . (sigma_k - data_k)^2, against the same quantities assembled in
+    numpy from the oracle's per-step Jacobians and second derivatives (forward-mode / nested-dual AD of the reference
+    residual): dx_k = -A^-1 (P + B dx_{k-1}), lam_k = A^-T (S_x^T sbar + incoming), H = sum D^T W D.
+    `engine(desc, info)` returns the history engine under test; `desc_info(values, ...)` builds its description."""
+    from cmad_amd.synthetic import gauss_point_batch
+    rng = np.random.default_rng(seed)
+    values = _lame_values(rng, yield_kind, kw)
+    mk = ol.SMALL_RATE_EP if rate else ol.SMALL_EP
+    mat = ol.Material(values, def_type=def_type, model_kind=mk)
+    desc, info = desc_info(values, def_type, 1 if rate else 0)
+    eng = engine(desc, info)
+    nx, nd = mat.nx, (3 if def_type == ol.FULL_3D else 2)
+    base = gauss_point_batch(B, seed=seed, ndims=nd)
+    gh = np.stack([k * 0.7 * base for k in range(K + 1)])
+    xi0 = np.repeat(mat.init_xi()[:, None], B, axis=1)
+    st = ol.newton_settings()
+    xs, sigs = [xi0], [np.zeros((6, B))]
+    for k in range(1, K + 1):
+        x, s, _, cv = mat.update_batch(st, gh[k], xs[-1], gradu_prev=gh[k - 1] if rate else None)
+        assert cv.all()
+        xs.append(x); sigs.append(s)
+    xs, sigs = np.stack(xs), np.stack(sigs)
+    assert (np.abs(xs[K][6]) > 0).any(), "the history must reach the plastic branch"
+    hss6 = rng.uniform(0.5, 2.0, 6)
+    data = sigs + rng.normal(0., 5., sigs.shape)
+    sbar = hss6[None, :, None] * (sigs - data); sbar[0] = 0.0
+    npar = 12 if yield_kind == "hill" else 6        # (the Hosford exponent has no first-order kernel sensitivity)
+    # ---- the engine under test
+    xi_hist, sig_hist = eng.primal(gh, xi0)
+    np.testing.assert_allclose(xi_hist, xs, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sig_hist[1:], sigs[1:], rtol=1e-9, atol=1e-7)
+    g_adj, lam_hist = eng.adjoint(gh, sbar, xi0, want_lam=True)
+    g_dir, dx_hist = eng.direct(gh, xs, sbar, want_blocks=True)
+    H = eng.hessian(gh, xs, lam_hist, dx_hist, sbar, hss6)
+    # ---- the same from the oracle's AD blocks
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in KP2O]
+    g_ref, H_ref = np.zeros(12), np.zeros((12, 12))
+    lam_ref, dx_ref = np.zeros((K + 1, nx, B)), np.zeros((K + 1, nx, 12, B))
+    for b in range(B):
+        blocks = []
+        for k in range(1, K + 1):
+            U, Up = gh[k][:, b], (gh[k - 1][:, b] if rate else None)
+            x, xp = xs[k][:, b], xs[k - 1][:, b]
+            A = mat.jacobian(ol.W_XI, x, xp, U, Up); Bm = mat.jacobian(ol.W_XI_PREV, x, xp, U, Up)
+            P = mat.jacobian(ol.W_PARAMS, x, xp, U, Up)[:, KP2O]
+            Sx = mat.dcauchy(ol.W_XI, x, xp, U, Up)[_V6_OF_9]; Sp = mat.dcauchy(ol.W_PARAMS, x, xp, U, Up)[_V6_OF_9][:, KP2O]
+            blocks.append((A, Bm, P, Sx, Sp))
+        dxp = np.zeros((nx, 12))
+        for k in range(1, K + 1):
+            A, Bm, P, Sx, Sp = blocks[k - 1]
+            dxp = -np.linalg.solve(A, P + Bm @ dxp)
+            dx_ref[k, :, :, b] = dxp
+        xin = np.zeros(nx)
+        for k in range(K, 0, -1):
+            A, Bm, P, Sx, Sp = blocks[k - 1]
+            lam = np.linalg.solve(A.T, Sx.T @ sbar[k][:, b] + xin)
+            lam_ref[k, :, b] = lam
+            g_ref += Sp.T @ sbar[k][:, b] - P.T @ lam
+            xin = -Bm.T @ lam
+            U, Up = gh[k][:, b], (gh[k - 1][:, b] if rate else None)
+            oC, oS = mat.second_derivs(xs[k][:, b], xs[k - 1][:, b], U, Up)
+            d2C = oC[:, qmap][:, :, qmap]; d2S = oS[_V6_OF_9][:, qmap][:, :, qmap]
+            dS = np.hstack([Sx, np.zeros((6, nx)), Sp])
+            W = np.einsum("r,rab->ab", sbar[k][:, b], d2S) + np.einsum("r,ra,rb->ab", hss6, dS, dS) - np.einsum("r,rab->ab", lam, d2C)
+            D = np.vstack([dx_ref[k, :, :, b], dx_ref[k - 1, :, :, b], np.eye(12)])
+            H_ref += D.T @ W @ D
+    sl = slice(0, npar)
+    np.testing.assert_allclose(lam_hist[1:], lam_ref[1:], rtol=1e-8, atol=1e-10 * np.abs(lam_ref).max())
+    np.testing.assert_allclose(dx_hist[:, :, sl], dx_ref[:, :, sl], rtol=1e-8, atol=1e-10 * np.abs(dx_ref[:, :, sl]).max())
+    np.testing.assert_allclose(g_adj[sl], g_ref[sl], rtol=1e-8, atol=1e-10 * np.abs(g_ref[sl]).max())
+    np.testing.assert_allclose(g_dir[sl], g_ref[sl], rtol=1e-8, atol=1e-10 * np.abs(g_ref[sl]).max())
+    Hs, Hr = H[sl, sl], H_ref[sl, sl]
+    np.testing.assert_allclose(Hs, Hr, rtol=1e-7, atol=1e-9 * np.abs(Hr).max())

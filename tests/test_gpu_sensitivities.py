@@ -352,3 +352,49 @@ def test_direct_sensitivities(def_type, yield_kind, kw, rot, rate):
         dx, ds = DeviceEvaluator(desc, info).direct_step(t(g), t(xp), t(x), dxi_prev_dp=t(dxp), gradu_prev=t(gp))
         return dx.cpu().numpy(), ds.cpu().numpy()
     pc.check_direct(direct, def_type, yield_kind, kw, rot, rate=rate, B=300, uniaxial_idx=0)
+
+
+# ---- second derivatives: cm_hessians / cm_hessians_rate on the GPU against the oracle's nested duals -------------------
+# (reference cmad/models/model.py:133-147, 245-270; pinned there by tests/objectives/test_jvp_vs_original.py:97)
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("plastic", [True, False])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, rot):
+    """cm_hessians through the C-ABI: d2C, d2 sigma (every block w.r.t. xi, xi_prev, params) and the first derivatives of
+    the same pass (dC, d sigma) against `orc_second_derivs` / `orc_jacobian` and against the hand-derived cm_evaluate blocks."""
+    import gpu_api
+    pc.check_second_derivs(gpu_api.hessians, gpu_api.evaluate, def_type, yield_kind, kw, plastic, rot=rot)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("plastic", [True, False])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_rate_form_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, rot):
+    """cm_hessians_rate through the C-ABI against the oracle, both branches."""
+    import gpu_api
+    pc.check_rate_second_derivs(gpu_api.hessians, gpu_api.evaluate_rate, def_type, yield_kind, kw, plastic, rot=rot)
+
+
+@pytest.mark.parametrize("plastic", [True, False])
+@pytest.mark.parametrize("idx", [0, 1, 2])
+@pytest.mark.parametrize("yield_kind,kw", [pc.YIELDS[0], pc.YIELDS[1]])
+def test_rate_form_uniaxial_by_dual_numbers(yield_kind, kw, idx, plastic):
+    """The 12-dof rate form under UNIAXIAL_STRESS (cm_hessians_rate: residual, stress, first and second derivatives)."""
+    import gpu_api
+    pc.check_rate_uniaxial_dual(gpu_api.hessians, yield_kind, kw, idx, plastic)
+
+
+@pytest.mark.parametrize("rate", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_history_second_order_vs_oracle(def_type, yield_kind, kw, rate):
+    """cm_adjoint_history, cm_direct_history and cm_hessian_history through the C-ABI: gradient (both ways), the adjoint
+    vector and the forward sensitivities of every step and the Hessian d2J/dp2, against the same quantities assembled from
+    the oracle's per-step AD blocks (reference cmad/objectives/mp_objective.py:95-345)."""
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    from cmad_amd.models.history_engine import HistoryEngine
+    pc.check_history_second_order(lambda desc, info: HistoryEngine(DeviceEvaluator(desc, info)),
+                                  lambda values, dt, mk: build_desc(values, def_type=dt, model_kind=mk),
+                                  def_type, yield_kind, kw, rate=rate)

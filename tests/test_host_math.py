@@ -296,151 +296,34 @@ def test_edge_cases():
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_variant):
-    """cm_hessians (hyper-dual evaluation of the residual in the product code) vs the oracle's nested duals:
-    every block of d2C and d2 sigma w.r.t. (xi, xi_prev, params), and the first derivatives of the same pass vs
-    the hand-derived cm_evaluate blocks."""
-    import numpy as np
+    """cm_hessians (hyper-dual evaluation of the residual in the product code, host build) vs the oracle's nested duals."""
     import host_harness_lib as hh
-    from cmad_amd.models.device import build_desc
-    from test_oracle_vs_torch_ad import _state
     if solver_variant == "dense":
         pytest.skip("not solver dependent")
-    rng = np.random.default_rng(12)
-    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng), **kw)
-    E, nu = values["elastic"]["E"], values["elastic"]["nu"]
-    values["elastic"] = {"lambda": E * nu / ((1 + nu) * (1 - 2 * nu)), "mu": E / (2 * (1 + nu))}   # KP == native
-    mat = ol.Material(values, def_type=def_type, uniaxial_idx=1)
-    desc, info = build_desc(values, def_type=def_type, uniaxial_stress_idx=1)
-    for _ in range(50):
-        xi, xp, U = _state(rng, mat, plastic)
-        if (mat.yield_state(xi, U)[1] > 0) == plastic:
-            break
-    nx = mat.nx
-    d2C, d2S, dC, dS = hh.hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
-    oC, oS = mat.second_derivs(xi, xp, U)
-    # KP index -> oracle p index (elastic stored as (mu, lambda) in the oracle's pair order)
-    kp2o = [ol.P_EL1, ol.P_EL0, ol.P_Y, ol.P_VOCE_S, ol.P_VOCE_D, ol.P_LIN_K] + [ol.P_YC + j for j in range(6)]
-    qmap = list(range(2 * nx)) + [2 * nx + j for j in kp2o]
-    V6 = [0, 1, 2, 4, 5, 8]
-    refC = oC[:, qmap][:, :, qmap]
-    refS = oS[V6][:, qmap][:, :, qmap]
-    if yield_kind != "hill":                 # yc slots are unused for J2; Hosford's exponent is compared too
-        keep = list(range(2 * nx + 6)) + ([2 * nx + 6] if yield_kind == "hosford" else [])
-    else:
-        keep = list(range(2 * nx + 12))
-    sel = np.ix_(range(nx), keep, keep)
-    scale = max(1.0, np.abs(refC[sel]).max())
-    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * scale)
-    sel6 = np.ix_(range(6), keep, keep)
-    np.testing.assert_allclose(d2S[0][sel6], refS[sel6], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refS[sel6]).max()))
-    # first derivatives of the same pass == hand-derived blocks
-    for which, lo in ((0, 0), (1, nx)):
-        C_, J, s_, S = hh.evaluate(desc, which, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
-        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
-        np.testing.assert_allclose(dS[0][:, lo:lo + nx], S[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(S).max()))
-    C_, J, s_, S = hh.evaluate(desc, 2, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
-    npar = 12 if yield_kind == "hill" else 6
-    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], J[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
-    np.testing.assert_allclose(dS[0][:, 2 * nx:2 * nx + npar], S[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(S).max()))
+    pc.check_second_derivs(hh.hessians, hh.evaluate, def_type, yield_kind, kw, plastic)
 
 
 @pytest.mark.parametrize("plastic", [True, False])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_rate_form_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_variant):
-    """cm_hessians_rate (hyper-dual evaluation of the rate-form residual) vs the oracle's nested duals, both
-    branches; first derivatives of the same pass vs the hand-derived cm_evaluate_rate blocks."""
-    import numpy as np
+    """cm_hessians_rate (host build) vs the oracle's nested duals, both branches."""
     import host_harness_lib as hh
-    from cmad_amd.models.device import build_desc
     if solver_variant == "dense":
         pytest.skip("not solver dependent")
-    rng = np.random.default_rng(21)
-    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng), **kw)
-    E, nu = values["elastic"]["E"], values["elastic"]["nu"]
-    values["elastic"] = {"lambda": E * nu / ((1 + nu) * (1 - 2 * nu)), "mu": E / (2 * (1 + nu))}   # KP == native
-    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
-    desc, info = build_desc(values, def_type=def_type, model_kind=1)
-    nx, nd = mat.nx, (3 if def_type == ol.FULL_3D else 2)
-    for _ in range(200):
-        sdev = rng.normal(size=6) * (260.0 if plastic else 60.0)
-        xi = np.r_[sdev, abs(rng.normal()) * 2e-3] if nx == 7 else np.r_[sdev, abs(rng.normal()) * 2e-3, 1.0 + 1e-3 * rng.normal()]
-        xp = xi.copy(); xp[:6] -= rng.normal(size=6) * 20.0; xp[6] *= 0.5
-        if nx == 8:
-            xp[7] = 1.0 + 1e-3 * rng.normal()
-        U, Up = rng.normal(size=nd * nd) * 2e-3, rng.normal(size=nd * nd) * 1e-3
-        f = mat.yield_state(xi, U)[1]
-        if (f > 1e-6) == plastic and abs(f) > 1e-6:
-            break
-    else:
-        raise AssertionError("no state on the requested branch")
-    d2C, d2S, dC, dS = hh.hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx, gradu_prev=Up.reshape(-1, 1))
-    oC, oS = mat.second_derivs(xi, xp, U, Up)
-    kp2o = [ol.P_EL1, ol.P_EL0, ol.P_Y, ol.P_VOCE_S, ol.P_VOCE_D, ol.P_LIN_K] + [ol.P_YC + j for j in range(6)]
-    qmap = list(range(2 * nx)) + [2 * nx + j for j in kp2o]
-    refC = oC[:, qmap][:, :, qmap]
-    keep = list(range(2 * nx + (12 if yield_kind == "hill" else 6))) + ([2 * nx + 6] if yield_kind == "hosford" else [])
-    sel = np.ix_(range(nx), keep, keep)
-    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refC[sel]).max()))
-    assert not d2S.any()                                       # sigma = Q x[0:6] Q^T is linear in the state
-    for which, lo in ((0, 0), (1, nx)):
-        C_, J, s_, S = hh.evaluate_rate(desc, which, U.reshape(-1, 1), Up.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
-        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J[:, :, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
-        np.testing.assert_allclose(dS[0][:, lo:lo + nx], S[:, :, 0], rtol=1e-9, atol=1e-12)
-    C_, J, s_, S = hh.evaluate_rate(desc, 2, U.reshape(-1, 1), Up.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
-    npar = 12 if yield_kind == "hill" else 6
-    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], J[:, :npar, 0], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(J).max()))
+    pc.check_rate_second_derivs(hh.hessians, hh.evaluate_rate, def_type, yield_kind, kw, plastic)
 
 
 @pytest.mark.parametrize("plastic", [True, False])
 @pytest.mark.parametrize("idx", [0, 1, 2])
 @pytest.mark.parametrize("yield_kind,kw", [pc.YIELDS[0], pc.YIELDS[1]])
 def test_rate_form_uniaxial_by_dual_numbers(yield_kind, kw, idx, plastic, solver_variant):
-    """small_rate_elastic_plastic under UNIAXIAL_STRESS (12 local dofs, small_rate_elastic_plastic.py:171-196,
-    :34-75, :249-346): served by dual-number evaluation of the residual in the product code (cm_hessians_rate);
-    residual, stress, every first-derivative block and the second derivatives against the oracle."""
-    import numpy as np
+    """small_rate_elastic_plastic under UNIAXIAL_STRESS (12 local dofs) by dual-number evaluation (host build)."""
     import host_harness_lib as hh
-    from cmad_amd.models.device import build_desc
     if solver_variant == "dense":
         pytest.skip("not solver dependent")
-    rng = np.random.default_rng(31 + idx)
-    values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng), **kw)
-    E, nu = values["elastic"]["E"], values["elastic"]["nu"]
-    values["elastic"] = {"lambda": E * nu / ((1 + nu) * (1 - 2 * nu)), "mu": E / (2 * (1 + nu))}   # KP == native
-    mat = ol.Material(values, def_type=ol.UNIAXIAL_STRESS, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=idx)
-    desc, info = build_desc(values, def_type=ol.UNIAXIAL_STRESS, model_kind=1, uniaxial_stress_idx=idx)
-    nx = mat.nx
-    assert nx == 12
-    for _ in range(200):
-        xi = np.r_[rng.normal(size=6) * (260.0 if plastic else 60.0), abs(rng.normal()) * 2e-3,
-                   1.0 + 1e-3 * rng.normal(size=2), 1e-3 * rng.normal(size=3)]
-        xp = xi.copy(); xp[:6] -= rng.normal(size=6) * 20.0; xp[6] *= 0.5; xp[7:9] = 1.0 + 1e-3 * rng.normal(size=2)
-        xp[9:] = 1e-3 * rng.normal(size=3)                       # unused by the residual (the shear unknowns are increments)
-        U, Up = rng.normal(size=1) * 2e-3, rng.normal(size=1) * 1e-3
-        f = mat.yield_state(xi, U)[1]
-        if (f > 1e-6) == plastic and abs(f) > 1e-6:
-            break
-    else:
-        raise AssertionError("no state on the requested branch")
-    d2C, d2S, dC, dS, C0, S0 = hh.hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx,
-                                           gradu_prev=Up.reshape(-1, 1), values=True)
-    np.testing.assert_allclose(C0[0], mat.residual(xi, xp, U, Up), rtol=1e-10, atol=1e-14)
-    V6 = [0, 1, 2, 4, 5, 8]
-    np.testing.assert_allclose(S0[0], np.asarray(mat.cauchy(xi, U)).reshape(9)[V6], rtol=1e-12, atol=1e-10)
-    for which, lo in ((ol.W_XI, 0), (ol.W_XI_PREV, nx)):
-        J = mat.jacobian(which, xi, xp, U, Up)
-        np.testing.assert_allclose(dC[0][:, lo:lo + nx], J, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(J).max()))
-    kp2o = [ol.P_EL1, ol.P_EL0, ol.P_Y, ol.P_VOCE_S, ol.P_VOCE_D, ol.P_LIN_K] + [ol.P_YC + j for j in range(6)]
-    Jp = mat.jacobian(ol.W_PARAMS, xi, xp, U, Up)[:, kp2o]
-    npar = 12 if yield_kind == "hill" else 6
-    np.testing.assert_allclose(dC[0][:, 2 * nx:2 * nx + npar], Jp[:, :npar], rtol=1e-9, atol=1e-12 * max(1.0, np.abs(Jp).max()))
-    oC, oS = mat.second_derivs(xi, xp, U, Up)
-    qmap = list(range(2 * nx)) + [2 * nx + j for j in kp2o]
-    refC = oC[:, qmap][:, :, qmap]
-    keep = list(range(2 * nx + npar))
-    sel = np.ix_(range(nx), keep, keep)
-    np.testing.assert_allclose(d2C[0][sel], refC[sel], rtol=1e-8, atol=1e-10 * max(1.0, np.abs(refC[sel]).max()))
+    pc.check_rate_uniaxial_dual(hh.hessians, yield_kind, kw, idx, plastic)
+
 
 
 @pytest.mark.parametrize("rot", [False, True])
@@ -509,3 +392,18 @@ def test_softplus_pieces():
         sg_ref = np.where(a >= 0, 1. / (1. + np.exp(-np.abs(a))), np.exp(-np.abs(a)) / (1. + np.exp(-np.abs(a))))
     np.testing.assert_allclose(sp, sp_ref, rtol=1e-15, atol=1e-320)
     np.testing.assert_allclose(sg, sg_ref, rtol=1e-15, atol=1e-320)
+
+
+@pytest.mark.parametrize("rate", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_history_second_order_vs_oracle(def_type, yield_kind, kw, rate, solver_variant):
+    """cm_adjoint_history / cm_direct_history / cm_hessian_history (host build of their per-point code) against the
+    oracle-assembled gradient, adjoint vectors, forward sensitivities and Hessian."""
+    from cmad_amd.models.device import build_desc
+    from host_facade import HostHistoryEngine
+    if solver_variant == "dense":
+        pytest.skip("not solver dependent")
+    pc.check_history_second_order(lambda desc, info: HostHistoryEngine(desc=desc, info=info),
+                                  lambda values, dt, mk: build_desc(values, def_type=dt, model_kind=mk),
+                                  def_type, yield_kind, kw, rate=rate)
