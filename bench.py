@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--general-newton", action="store_true",
                     help="CM_SOLVER_GENERAL_NEWTON: force the general 7-dof Newton where the J2 radial-line "
                          "restriction (same iterates) would apply; side measurement")
+    ap.add_argument("--lockstep", action="store_true",
+                    help="CM_SOLVER_LOCKSTEP: one point per lane for the whole kernel instead of the work-pool kernel (A/B)")
     ap.add_argument("--ls-evals", type=int, default=0,
                     help="J2 workloads: line-search evaluations per Newton iteration (0 = newton_solve defaults, "
                          "4 = make_newton_solve defaults)")
@@ -282,6 +284,7 @@ def main():
         if wl == "j2_objective_grad":
             bytes_per_update -= 8                  # no xi written
     from cmad_amd.models.deformation_types import DefType
+    newton.lockstep = bool(args.lockstep)
     desc, info = build_desc(values, def_type=DefType.PLANE_STRESS if ps else DefType.FULL_3D, newton=newton, hybrid=hybrid)
     ev = DeviceEvaluator(desc, info)
     nxi = 8 if ps else 7

@@ -24,7 +24,7 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-NPARTS = 9          # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
+NPARTS = 10         # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
 
 
 def build(force=False, verbose=False, jobs=None):

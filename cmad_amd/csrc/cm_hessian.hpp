@@ -42,7 +42,27 @@ CM_D HD hd_exp(const HD& x) { const double e = exp(x.v); return hd_chain(x, e, e
 CM_D HD hd_log(const HD& x) { return hd_chain(x, log(x.v), 1.0 / x.v, -1.0 / (x.v * x.v)); }
 CM_D HD hd_abs(const HD& x) { const double s = (x.v > 0.0) ? 1.0 : ((x.v < 0.0) ? -1.0 : 0.0); return HD{fabs(x.v), s * x.a, s * x.b, s * x.ab}; }
 
-// scalar-type dispatch so the same templates run on double (host tests) and HD
+// first-order dual number (value, one directional derivative): the arithmetic of the extended parameter sensitivities
+struct D1 {
+    double v, d;
+};
+CM_D D1 d1(double c) { return D1{c, 0.0}; }
+CM_D D1 operator+(const D1& x, const D1& y) { return D1{x.v + y.v, x.d + y.d}; }
+CM_D D1 operator-(const D1& x, const D1& y) { return D1{x.v - y.v, x.d - y.d}; }
+CM_D D1 operator-(const D1& x) { return D1{-x.v, -x.d}; }
+CM_D D1 operator*(const D1& x, const D1& y) { return D1{x.v * y.v, x.d * y.v + x.v * y.d}; }
+CM_D D1 operator*(double c, const D1& x) { return D1{c * x.v, c * x.d}; }
+CM_D D1 operator*(const D1& x, double c) { return c * x; }
+CM_D D1 operator+(const D1& x, double c) { return D1{x.v + c, x.d}; }
+CM_D D1 operator+(double c, const D1& x) { return x + c; }
+CM_D D1 operator-(const D1& x, double c) { return D1{x.v - c, x.d}; }
+CM_D D1 operator-(double c, const D1& x) { return D1{c - x.v, -x.d}; }
+CM_D D1 d1_chain(const D1& x, double g0, double g1) { return D1{g0, g1 * x.d}; }
+CM_D D1 operator/(const D1& x, const D1& y) { const double i = 1.0 / y.v; return D1{x.v * i, (x.d - x.v * i * y.d) * i}; }
+CM_D D1 operator/(const D1& x, double c) { return (1.0 / c) * x; }
+CM_D D1 operator/(double c, const D1& y) { const double i = 1.0 / y.v; return D1{c * i, -c * i * i * y.d}; }
+
+// scalar-type dispatch so the same templates run on double (host tests), D1 and HD
 CM_D double t_sqrt(double x) { return sqrt(x); }
 CM_D double t_exp(double x) { return exp(x); }
 CM_D double t_log(double x) { return log(x); }
@@ -53,15 +73,177 @@ CM_D HD t_exp(const HD& x) { return hd_exp(x); }
 CM_D HD t_log(const HD& x) { return hd_log(x); }
 CM_D HD t_abs(const HD& x) { return hd_abs(x); }
 CM_D double t_val(const HD& x) { return x.v; }
+CM_D D1 t_sqrt(const D1& x) { const double r = sqrt(x.v); return d1_chain(x, r, 0.5 / r); }
+CM_D D1 t_exp(const D1& x) { const double e = exp(x.v); return d1_chain(x, e, e); }
+CM_D D1 t_log(const D1& x) { return d1_chain(x, log(x.v), 1.0 / x.v); }
+CM_D D1 t_abs(const D1& x) { const double sg = (x.v > 0.0) ? 1.0 : ((x.v < 0.0) ? -1.0 : 0.0); return D1{fabs(x.v), sg * x.d}; }
+CM_D double t_val(const D1& x) { return x.v; }
+// constants of type T, and the seed of a differentiation variable (D1: its one direction)
+template <class T> CM_D T t_const(double c);
+template <> CM_D double t_const<double>(double c) { return c; }
+template <> CM_D D1 t_const<D1>(double c) { return D1{c, 0.0}; }
+template <> CM_D HD t_const<HD>(double c) { return HD{c, 0.0, 0.0, 0.0}; }
+CM_D void t_seed(double&) {}
+CM_D void t_seed(D1& x) { x.d = 1.0; }
+CM_D void t_seed(HD&) {}
 
 // parameters as scalars of type T, KP order (include/cmad_hip.h cm_param_index)
+// yc: the yield-surface coefficients as cm_model_desc.yc (Hill F..N | Hosford a | Barlat 18 + a), Q: the rotation matrix,
+// nn: the packed network weights (plain doubles; weight nn_seed, if any, carries the derivative direction).
 template <class T>
-struct MatT { T lambda, mu, Y, S, D, K, yc[6]; };
+struct MatT {
+    T lambda, mu, Y, S, D, K, yc[19], Q[9];
+    const double* nn;
+    int nn_seed;
+    CM_D T nn_at(int i) const {
+        T w = t_const<T>(nn[i]);
+        if (i == nn_seed) t_seed(w);
+        return w;
+    }
+};
+
+// every parameter at its value in the model description (no derivative parts)
+template <class T>
+CM_D void mat_from_desc(const cm_model_desc& m, MatT<T>& p) {
+    p.lambda = t_const<T>(m.lambda); p.mu = t_const<T>(m.mu); p.Y = t_const<T>(m.Y);
+    p.S = t_const<T>(m.voce_S); p.D = t_const<T>(m.voce_D); p.K = t_const<T>(m.lin_K);
+    for (int k = 0; k < 19; ++k) p.yc[k] = t_const<T>(m.yc[k]);
+    for (int k = 0; k < 9; ++k) p.Q[k] = t_const<T>(m.Q[k]);
+    p.nn = m.nn_weights; p.nn_seed = -1;
+}
+
+// Extended parameter ("EP") index of the sensitivities beyond the 12 of cm_param_index: 0..11 = KP order,
+// 12..24 = yc[6..18] (Barlat), 25..33 = Q[0..8] row-major, 34 + i = packed network weight i.
+enum { CM_EP_YC6 = 12, CM_EP_Q0 = 25, CM_EP_NN0 = 34 };
+template <class T>
+CM_D void mat_seed(MatT<T>& p, int e) {
+    if (e == CM_P_LAMBDA) t_seed(p.lambda);
+    else if (e == CM_P_MU) t_seed(p.mu);
+    else if (e == CM_P_Y) t_seed(p.Y);
+    else if (e == CM_P_VOCE_S) t_seed(p.S);
+    else if (e == CM_P_VOCE_D) t_seed(p.D);
+    else if (e == CM_P_LIN_K) t_seed(p.K);
+    else if (e < CM_EP_Q0) t_seed(p.yc[e - CM_P_YC0]);
+    else if (e < CM_EP_NN0) t_seed(p.Q[e - CM_EP_Q0]);
+    else p.nn_seed = e - CM_EP_NN0;
+}
+
+// ---- the network term of the hybrid surface in arithmetic T (cm::icnn_yield_term: value and d/ds6) ---------------------
+// jax.nn.softplus = logaddexp(a, 0) and its derivative, the logistic function, in the overflow-safe forms
+template <class T>
+CM_D void softplus_T(const T& a, T& sp, T& sg) {
+    const bool pos = t_val(a) > 0.0;
+    const T e = t_exp(pos ? -a : a);                           // exp(-|a|)
+    const T inv = 1.0 / (1.0 + e);
+    const T l = t_log(1.0 + e);
+    sp = pos ? a + l : l;
+    sg = pos ? inv : e * inv;
+}
+template <class T>
+CM_D void icnn_yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& val, T g6[6]) {
+    const int H = m.nn_widths[1];
+    const int oW0 = 0, ob0 = 6 * H, ob1 = 7 * H + 6, oWz = 7 * H + 7;
+    const double* sc = p.nn + 8 * H + 7;                         // in_scale[6], in_min[6], out_scale, out_min (constants)
+    const T h = (s[0] + s[3] + s[5]) * (1.0 / 3.0);
+    const T x[6] = {s[0] - h, s[3] - h, s[5] - h, s[1], s[2], s[4]};
+    T xs[6];
+    for (int i = 0; i < 6; ++i) xs[i] = sc[i] * x[i] + sc[6 + i];
+    T F = 2.0 * p.nn_at(ob1), f0 = p.nn_at(ob1), G[6];
+    for (int i = 0; i < 6; ++i) G[i] = t_const<T>(0.0);
+    for (int o = 0; o < H; ++o) {
+        T wc[6], t = t_const<T>(0.0);
+        for (int i = 0; i < 6; ++i) { wc[i] = p.nn_at(oW0 + i * H + o); t = t + xs[i] * wc[i]; }
+        const T b = p.nn_at(ob0 + o), wz = p.nn_at(oWz + o);
+        T spp, sgp, spn, sgn, sp0, sg0;
+        softplus_T(b + t, spp, sgp);
+        softplus_T(b - t, spn, sgn);
+        softplus_T(b, sp0, sg0);                               // the network at the origin: forward(0) = softplus(b0) . Wz + b1
+        F = F + (spp + spn) * wz;
+        f0 = f0 + sp0 * wz;
+        const T c1 = (sgp - sgn) * wz;
+        for (int i = 0; i < 6; ++i) G[i] = G[i] + c1 * wc[i];
+    }
+    const double ios = 1.0 / sc[12];
+    val = (0.5 * F - f0 - sc[13]) * ios;                        // (1/2 (f(x) + f(-x)) - f(0) - out_min) / out_scale
+    T gx[6];
+    for (int i = 0; i < 6; ++i) gx[i] = (0.5 * sc[i] * ios) * G[i];
+    constexpr int XI[6] = {0, 3, 4, 1, 5, 2};
+    const T gm = (gx[0] + gx[1] + gx[2]) * (1.0 / 3.0);
+    for (int k = 0; k < 6; ++k) { g6[k] = gx[XI[k]]; if (kDiag[k]) g6[k] = g6[k] - gm; }
+}
 
 // effective stress value and 6-vector gradient gt in arithmetic T (the closed forms of yield_eval)
 template <int YK, class T>
-CM_D void yield_T(const MatT<T>& p, const T s[6], T& phi, T gt[6]) {
-    if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
+CM_D void yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& phi, T gt[6]) {
+    if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
+        yield_T<CM_YIELD_HILL, T>(m, p, s, phi, gt);
+        T v, g6[6];
+        icnn_yield_T<T>(m, p, s, v, g6);
+        phi = phi + v;
+        for (int k = 0; k < 6; ++k) gt[k] = gt[k] + g6[k];
+    } else if constexpr (YK == CM_YIELD_SCALED_HYBRID_HILL_NN) {
+        // cm::scaled_hybrid_eval: phi(s) = phi_h(beta s) / beta, beta from the scalar Newton on phi_h(beta s) / Yeq - 1 (same
+        // iteration and line search, decided on the values); two more plain Newton steps in arithmetic T at the converged
+        // value carry the first and second derivative parts of beta to the implicit-function values
+        T pj, gj[6];
+        yield_T<CM_YIELD_J2, T>(m, p, s, pj, gj);
+        if (!(fabs(t_val(pj)) > 1e-14)) {
+            phi = pj;
+            for (int k = 0; k < 6; ++k) gt[k] = t_const<T>(0.0);
+            return;
+        }
+        const double iy = 1.0 / m.beta_equivalent_stress;
+        auto r_dr = [&](const T& b, T& r, T& dr) {
+            T t[6], ph, g[6];
+            for (int k = 0; k < 6; ++k) t[k] = b * s[k];
+            yield_T<CM_YIELD_HYBRID_HILL_NN, T>(m, p, t, ph, g);
+            T gs = g[0] * s[0];
+            for (int k = 1; k < 6; ++k) gs = gs + g[k] * s[k];
+            r = ph * iy - 1.0; dr = gs * iy;
+        };
+        T beta = p.Y / pj;
+        {
+            constexpr int kMaxEvals = 4;
+            T C, dC;
+            r_dr(beta, C, dC);
+            const double n0 = fabs(t_val(C));
+            for (int it = 0; it < m.beta_max_iters; ++it) {
+                const double nrm = fabs(t_val(C));
+                if (nrm / n0 < m.beta_rel_tol || nrm < m.beta_abs_tol) break;
+                const T delta = C / dC;
+                const double cv = t_val(C), phi0 = 0.5 * cv * cv, dphi0 = -cv * cv, armijo = m.ls_c1 * dphi0;
+                int n = 0;
+                double alpha = 1.0, best_alpha = 1.0, best_phi = INFINITY;
+                T best_C = C, best_dC = dC, Ct = C, dCt = dC;
+                bool accepted = false, have_best = false;
+                while (n < kMaxEvals && !accepted) {
+                    r_dr(beta - alpha * delta, Ct, dCt);
+                    const double ph = 0.5 * t_val(Ct) * t_val(Ct);
+                    const bool finite = isfinite(ph);
+                    if (finite && ph < best_phi) { best_alpha = alpha; best_phi = ph; best_C = Ct; best_dC = dCt; have_best = true; }
+                    accepted = finite && (ph <= phi0 + alpha * armijo);
+                    const double am = quad_min(phi0, dphi0, alpha, ph);
+                    const double ac = fmin(fmax(am, m.ls_lo * alpha), m.ls_hi * alpha);
+                    if (!accepted) alpha = finite ? ac : 0.5 * alpha;
+                    ++n;
+                }
+                if (accepted) { beta = beta - alpha * delta; C = Ct; dC = dCt; }
+                else if (have_best) { beta = beta - best_alpha * delta; C = best_C; dC = best_dC; }
+                else { beta = beta - delta; T Cn; r_dr(beta, Cn, dC); }
+            }
+            for (int polish = 0; polish < 2; ++polish) {
+                r_dr(beta, C, dC);
+                beta = beta - C / dC;
+            }
+        }
+        T tau[6], ph, g[6];
+        for (int k = 0; k < 6; ++k) tau[k] = beta * s[k];
+        yield_T<CM_YIELD_HYBRID_HILL_NN, T>(m, p, tau, ph, g);
+        T c = g[0] * tau[0];
+        for (int k = 1; k < 6; ++k) c = c + g[k] * tau[k];
+        phi = ph / beta;
+        for (int k = 0; k < 6; ++k) gt[k] = ph * g[k] / c;
+    } else if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
         T a00, a33, a55, a03, a05, a35, a11, a22, a44;
         if constexpr (YK == CM_YIELD_J2) {
             a00 = a33 = a55 = T{1.0}; a03 = a05 = a35 = T{-0.5}; a11 = a22 = a44 = T{3.0};
@@ -97,21 +279,46 @@ CM_D void yield_T(const MatT<T>& p, const T s[6], T& phi, T gt[6]) {
     }
 }
 
-// residual C(x, xp, p) and material stress s in arithmetic T for the total-form model; `eg`, `z` are plain
-// doubles (the second derivatives taken here are w.r.t. xi, xi_prev and the parameters only).
+// out = V(M^T T(a) M) (TRANSPOSE_FIRST) or V(M T(a) M^T), M row-major 3x3 of type T (cm::congruence)
+template <bool TRANSPOSE_FIRST, class T>
+CM_D void congruence_T(const T* M, const T a[6], T out[6]) {
+    const T A[3][3] = {{a[0], a[1], a[2]}, {a[1], a[3], a[4]}, {a[2], a[4], a[5]}};
+    T Tm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            T acc = A[i][0] * (TRANSPOSE_FIRST ? M[j] : M[3 * j]);
+            for (int k = 1; k < 3; ++k) acc = acc + A[i][k] * (TRANSPOSE_FIRST ? M[3 * k + j] : M[3 * j + k]);
+            Tm[i][j] = acc;
+        }
+    constexpr int I6[6] = {0, 0, 0, 1, 1, 2}, J6[6] = {0, 1, 2, 1, 2, 2};
+    for (int r = 0; r < 6; ++r) {
+        T acc = (TRANSPOSE_FIRST ? M[I6[r]] : M[3 * I6[r]]) * Tm[0][J6[r]];
+        for (int k = 1; k < 3; ++k) acc = acc + (TRANSPOSE_FIRST ? M[3 * k + I6[r]] : M[3 * I6[r] + k]) * Tm[k][J6[r]];
+        out[r] = acc;
+    }
+}
+
+// residual C(x, xp, p) and material stress s in arithmetic T for the total-form model; the material-frame strain `eg`
+// and the frame vectors `z` are of type T as well (they depend on the rotation matrix, kinematics_T).
 // `plastic` is decided on the primal value (jnp.where semantics, cmad/models/paths.py:26-27).
 template <int DEF, int YK, class T>
-CM_D void residual_T(const cm_model_desc& m, const MatT<T>& p, const double eg[6], const double* z,
-                     const T* x, const T* xp, T* C, T s[6]) {
+CM_D void residual_T(const cm_model_desc& m, const MatT<T>& p, const T eg[6], const T* z,
+                     const T* x, const T* xp, T* C, T s[6], double dU = 0.0) {
     T e[6];
     if constexpr (DEF == CM_UNIAXIAL_STRESS) {
-        T t[3] = {T{0.0}, x[7] - 1.0, x[8] - 1.0};
-        for (int i = 0; i < 3; ++i) {
-            T pv = T{0.0};
-            for (int k = 0; k < 6; ++k) pv = pv + (kW[k] * z[6 * i + k]) * x[k];
-            t[i] = t[i] - pv;
-        }
-        for (int k = 0; k < 6; ++k) e[k] = eg[k] + z[k] * t[0] + z[6 + k] * t[1] + z[12 + k] * t[2];
+        // small_elastic_plastic.py:38-62 as written (no use of Q^T Q = I, so that derivatives w.r.t. the entries of Q are the
+        // reference's): global total strain with the off-axis shears of the global plastic strain Q eps_p Q^T, the on-axis
+        // entry dU and the off-axis stretches on the diagonal, rotated back to the material frame.  `dU` = grad u.
+        const int on = m.uniaxial_idx, ia = (on == 0) ? 1 : 0, ib = (on == 2) ? 1 : 2;
+        constexpr int DIAG6[3] = {0, 3, 5};
+        T v6[6], gp6[6], em6[6];
+        for (int k = 0; k < 6; ++k) v6[k] = x[k];
+        congruence_T<false, T>(p.Q, v6, gp6);                  // Q eps_p Q^T
+        gp6[DIAG6[on]] = t_const<T>(dU);
+        gp6[DIAG6[ia]] = x[7] - 1.0;
+        gp6[DIAG6[ib]] = x[8] - 1.0;
+        congruence_T<true, T>(p.Q, gp6, em6);                  // Q^T (constrained global total strain) Q
+        for (int k = 0; k < 6; ++k) e[k] = em6[k] - x[k];
     } else {
         for (int k = 0; k < 6; ++k) {
             e[k] = eg[k] - x[k];
@@ -122,7 +329,7 @@ CM_D void residual_T(const cm_model_desc& m, const MatT<T>& p, const double eg[6
     const T twomu = 2.0 * p.mu;
     for (int k = 0; k < 6; ++k) { s[k] = twomu * e[k]; if (kDiag[k]) s[k] = s[k] + p.lambda * tr; }
     T phi, gt[6];
-    yield_T<YK, T>(p, s, phi, gt);
+    yield_T<YK, T>(m, p, s, phi, gt);
     T H = T{0.0};
     if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
     if (m.has_linear) H = H + p.K * x[6];
@@ -137,12 +344,12 @@ CM_D void residual_T(const cm_model_desc& m, const MatT<T>& p, const double eg[6
     C[6] = plastic ? f : dg;
     if constexpr (DEF == CM_PLANE_STRESS) {
         T r = T{0.0};
-        for (int k = 0; k < 6; ++k) r = r + (kW[k] * z[k]) * s[k];
+        for (int k = 0; k < 6; ++k) r = r + kW[k] * (z[k] * s[k]);
         C[7] = r / twomu;
     }
     if constexpr (DEF == CM_UNIAXIAL_STRESS) {
         T ra = T{0.0}, rb = T{0.0};
-        for (int k = 0; k < 6; ++k) { ra = ra + (kW[k] * z[6 + k]) * s[k]; rb = rb + (kW[k] * z[12 + k]) * s[k]; }
+        for (int k = 0; k < 6; ++k) { ra = ra + kW[k] * (z[6 + k] * s[k]); rb = rb + kW[k] * (z[12 + k] * s[k]); }
         C[7] = ra / twomu; C[8] = rb / twomu;
     }
 }
@@ -150,19 +357,19 @@ CM_D void residual_T(const cm_model_desc& m, const MatT<T>& p, const double eg[6
 // the rate-form residual (cm::residual_rate, cmad/models/small_rate_elastic_plastic.py:249-346) in arithmetic T:
 // the unknown x[0:6] is the material stress itself, `deg` the material strain increment (plain doubles).
 template <int DEF, int YK, class T>
-CM_D void residual_rate_T(const cm_model_desc& m, const MatT<T>& p, const double deg[6], const double* z,
+CM_D void residual_rate_T(const cm_model_desc& m, const MatT<T>& p, const T deg[6], const T* z,
                           const T* x, const T* xp, T* C, T s[6]) {
     static_assert(DEF != CM_UNIAXIAL_STRESS, "rate form: FULL_3D and PLANE_STRESS");
     T e[6];
     for (int k = 0; k < 6; ++k) {
         s[k] = x[k];
-        e[k] = T{deg[k]};
+        e[k] = deg[k];
         if constexpr (DEF == CM_PLANE_STRESS) e[k] = e[k] + z[k] * (x[7] - xp[7]);
     }
     const T tr = e[0] + e[3] + e[5];
     const T twomu = 2.0 * p.mu;
     T phi, gt[6];
-    yield_T<YK, T>(p, s, phi, gt);
+    yield_T<YK, T>(m, p, s, phi, gt);
     T H = T{0.0};
     if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
     if (m.has_linear) H = H + p.K * x[6];
@@ -181,7 +388,7 @@ CM_D void residual_rate_T(const cm_model_desc& m, const MatT<T>& p, const double
             dc = dc - dg * cn;
         }
         C[k] = (x[k] - xp[k] - dc) / twomu;
-        if constexpr (DEF == CM_PLANE_STRESS) r7 = r7 + (kW[k] * z[k]) * dc;
+        if constexpr (DEF == CM_PLANE_STRESS) r7 = r7 + kW[k] * (z[k] * dc);
     }
     C[6] = plastic ? f : dg;
     if constexpr (DEF == CM_PLANE_STRESS) C[7] = r7 / twomu;
@@ -210,7 +417,7 @@ CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, dou
     T em[3][3];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
         T acc = T{0.0};
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc = acc + (m.Q[3 * a + i] * m.Q[3 * b + j]) * eg[a][b];
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc = acc + (p.Q[3 * a + i] * p.Q[3 * b + j]) * eg[a][b];
         em[i][j] = acc;
     }
     const T e[6] = {em[0][0], em[0][1], em[0][2], em[1][1], em[1][2], em[2][2]};
@@ -218,7 +425,7 @@ CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, dou
     const T tr = e[0] + e[3] + e[5];
     const T twomu = 2.0 * p.mu;
     T phi, gt[6];
-    yield_T<YK, T>(p, s, phi, gt);
+    yield_T<YK, T>(m, p, s, phi, gt);
     T H = T{0.0};
     if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
     if (m.has_linear) H = H + p.K * x[6];
@@ -244,56 +451,106 @@ CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, dou
     T dgl[3][3];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
         T acc = T{0.0};
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc = acc + (m.Q[3 * i + a] * m.Q[3 * j + b]) * dm[a][b];
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) acc = acc + (p.Q[3 * i + a] * p.Q[3 * j + b]) * dm[a][b];
         dgl[i][j] = acc;
     }
     C[7] = dgl[ia][ia] / twomu; C[8] = dgl[ib][ib] / twomu;
     C[9] = dgl[0][1] / twomu; C[10] = dgl[0][2] / twomu; C[11] = dgl[1][2] / twomu;
 }
 
+// ---- the whole model in arithmetic T: kinematics with the rotation matrix, residual, global Cauchy stress -----------------
+// material-frame total strain and frame vectors (cm::strain_from_gradu, cm::strain_z, cm::uniaxial_frame) for a rotation
+// matrix of type T; G: grad u (rate form: grad u - grad u_prev), plain doubles
+template <int DEF, class T>
+CM_D void kinematics_T(const cm_model_desc& m, const MatT<T>& p, const double* G, T eg[6], T* z /* Dims<DEF>::NZ */) {
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        const int on = m.uniaxial_idx, ia = (on == 0) ? 1 : 0, ib = (on == 2) ? 1 : 2;
+        const int rows[3] = {on, ia, ib};
+        for (int r = 0; r < 3; ++r) {
+            const T* q = p.Q + 3 * rows[r];
+            T* Z = z + 6 * r;
+            Z[0] = q[0] * q[0]; Z[1] = q[0] * q[1]; Z[2] = q[0] * q[2]; Z[3] = q[1] * q[1]; Z[4] = q[1] * q[2]; Z[5] = q[2] * q[2];
+        }
+        for (int k = 0; k < 6; ++k) eg[k] = G[0] * z[k];
+    } else {
+        T E[6];
+        if constexpr (DEF == CM_FULL_3D) {
+            E[0] = t_const<T>(G[0]); E[1] = t_const<T>(0.5 * (G[1] + G[3])); E[2] = t_const<T>(0.5 * (G[2] + G[6]));
+            E[3] = t_const<T>(G[4]); E[4] = t_const<T>(0.5 * (G[5] + G[7])); E[5] = t_const<T>(G[8]);
+        } else {
+            E[0] = t_const<T>(G[0]); E[1] = t_const<T>(0.5 * (G[1] + G[2])); E[2] = t_const<T>(0.0);
+            E[3] = t_const<T>(G[3]); E[4] = t_const<T>(0.0); E[5] = t_const<T>(0.0);
+        }
+        congruence_T<true, T>(p.Q, E, eg);
+        const T* q = p.Q + 6;                                   // third row: d(material strain)/dF33 = V(q3 q3^T)
+        z[0] = q[0] * q[0]; z[1] = q[0] * q[1]; z[2] = q[0] * q[2]; z[3] = q[1] * q[1]; z[4] = q[1] * q[2]; z[5] = q[2] * q[2];
+    }
+}
+
+// C(x, xp, p) and the GLOBAL Cauchy stress sg(x, p) of either model kind in arithmetic T, everything (rotation matrix,
+// yield-surface coefficients, network weights included) taken from p.  G as kinematics_T.
+template <int DEF, int YK, int MK, class T>
+CM_D void model_eval_T(const cm_model_desc& m, const MatT<T>& p, const double* G, const T* x, const T* xp, T* C, T sg[6]) {
+    T s[6];
+    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS) {
+        residual_rate_uniaxial_T<YK, T>(m, p, G[0], x, xp, C, s);
+    } else {
+        T eg[6], z[Dims<DEF>::NZ];
+        kinematics_T<DEF, T>(m, p, G, eg, z);
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) residual_rate_T<DEF, YK, T>(m, p, eg, z, x, xp, C, s);
+        else residual_T<DEF, YK, T>(m, p, eg, z, x, xp, C, s, G[0]);
+    }
+    congruence_T<false, T>(p.Q, s, sg);
+}
+
 // one (a, b) pair: out_C[NX] = d2 C / dq_a dq_b, out_S[6] = d2 sigma_global / dq_a dq_b,
 // and the first derivatives wrt q_a (for cross-checks): out_Ca[NX], out_Sa[6]
 // MK = CM_SMALL_RATE_ELASTIC_PLASTIC: G must already hold grad u - grad u_prev (the strain is linear in it).
+// (ROT is kept in the signature for the callers; the rotation products always run here: Q = I reproduces the plain result.)
 template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv, const double* xpv, int a, int b,
                        double* out_C, double* out_S, double* out_Ca, double* out_Sa,
                        double* out_C0 = nullptr, double* out_S0 = nullptr, double* out_Sb = nullptr) {
     constexpr int NX = nx_of<DEF, MK>();
-    constexpr bool RATE_UNI = (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS);
-    double eg[6], z[Dims<DEF>::NZ];
-    if constexpr (!RATE_UNI) {
-        strain_from_gradu<DEF, ROT>(m, G, eg);
-        strain_z<DEF, ROT>(m, z);
-    }
-    HD x[NX], xp[NX], C[NX], s[6];
+    HD x[NX], xp[NX], C[NX], sg[6];
     MatT<HD> p;
-    double pv[CM_NUM_PARAMS] = {m.lambda, m.mu, m.Y, m.voce_S, m.voce_D, m.lin_K,
-                                m.yc[0], m.yc[1], m.yc[2], m.yc[3], m.yc[4], m.yc[5]};
-    HD q[2 * NX + CM_NUM_PARAMS];
-    for (int k = 0; k < NX; ++k) { q[k] = hd(xv[k]); q[NX + k] = hd(xpv[k]); }
-    for (int k = 0; k < CM_NUM_PARAMS; ++k) q[2 * NX + k] = hd(pv[k]);
-    q[a].a = 1.0; q[b].b = 1.0;
-    for (int k = 0; k < NX; ++k) { x[k] = q[k]; xp[k] = q[NX + k]; }
-    const HD* pp = q + 2 * NX;
-    p.lambda = pp[0]; p.mu = pp[1]; p.Y = pp[2]; p.S = pp[3]; p.D = pp[4]; p.K = pp[5];
-    for (int k = 0; k < 6; ++k) p.yc[k] = pp[6 + k];
-    if constexpr (RATE_UNI) residual_rate_uniaxial_T<YK, HD>(m, p, G[0], x, xp, C, s);
-    else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) residual_rate_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
-    else residual_T<DEF, YK, HD>(m, p, eg, z, x, xp, C, s);
+    mat_from_desc<HD>(m, p);
+    for (int k = 0; k < NX; ++k) { x[k] = hd(xv[k]); xp[k] = hd(xpv[k]); }
+    // q = [xi, xi_prev, p (KP)]: direction a in the first derivative slot, b in the second
+    auto slot = [&](int i) -> HD& {
+        if (i < NX) return x[i];
+        if (i < 2 * NX) return xp[i - NX];
+        const int e = i - 2 * NX;
+        return e == CM_P_LAMBDA ? p.lambda : e == CM_P_MU ? p.mu : e == CM_P_Y ? p.Y : e == CM_P_VOCE_S ? p.S :
+               e == CM_P_VOCE_D ? p.D : e == CM_P_LIN_K ? p.K : p.yc[e - CM_P_YC0];
+    };
+    slot(a).a = 1.0;
+    slot(b).b = 1.0;
+    model_eval_T<DEF, YK, MK, HD>(m, p, G, x, xp, C, sg);
     for (int k = 0; k < NX; ++k) { out_C[k] = C[k].ab; out_Ca[k] = C[k].a; }
-    double s2[6], s1[6], s0[6], g2[6], g1[6], g0[6];
-    for (int k = 0; k < 6; ++k) { s2[k] = s[k].ab; s1[k] = s[k].a; s0[k] = s[k].v; }
-    to_global<ROT>(m, s2, g2);
-    to_global<ROT>(m, s1, g1);
-    for (int k = 0; k < 6; ++k) { out_S[k] = g2[k]; out_Sa[k] = g1[k]; }
-    if (out_Sb) {                                         // first derivative of the global stress w.r.t. q_b
-        double sb1[6], gb1[6];
-        for (int k = 0; k < 6; ++k) sb1[k] = s[k].b;
-        to_global<ROT>(m, sb1, gb1);
-        for (int k = 0; k < 6; ++k) out_Sb[k] = gb1[k];
-    }
+    for (int k = 0; k < 6; ++k) { out_S[k] = sg[k].ab; out_Sa[k] = sg[k].a; }
+    if (out_Sb) for (int k = 0; k < 6; ++k) out_Sb[k] = sg[k].b;
     if (out_C0) for (int k = 0; k < NX; ++k) out_C0[k] = C[k].v;
-    if (out_S0) { to_global<ROT>(m, s0, g0); for (int k = 0; k < 6; ++k) out_S0[k] = g0[k]; }
+    if (out_S0) for (int k = 0; k < 6; ++k) out_S0[k] = sg[k].v;
+}
+
+// ---- first-order sensitivities w.r.t. ONE extended parameter (EP index e, see mat_seed) at a given state ---------------
+// dC[NX] = dC/dp_e, dS[6] = d sigma_global/dp_e by forward-mode evaluation of the whole model: the way every parameter the
+// hand-derived kernels have no closed form for (rotation matrix, Hosford exponent, Hill coefficients of the network
+// surfaces, network weights) is differentiated -- the reference's jacrev over the params pytree
+// (cmad/models/model.py:125-153, cmad/parameters/parameters.py:368-377).
+template <int DEF, int YK, int MK>
+CM_D void param_direction(const cm_model_desc& m, const double* G, const double* xv, const double* xpv, int e,
+                          double* dC, double* dS) {
+    constexpr int NX = nx_of<DEF, MK>();
+    D1 x[NX], xp[NX], C[NX], sg[6];
+    MatT<D1> p;
+    mat_from_desc<D1>(m, p);
+    mat_seed<D1>(p, e);
+    for (int k = 0; k < NX; ++k) { x[k] = d1(xv[k]); xp[k] = d1(xpv[k]); }
+    model_eval_T<DEF, YK, MK, D1>(m, p, G, x, xp, C, sg);
+    for (int k = 0; k < NX; ++k) dC[k] = C[k].d;
+    for (int k = 0; k < 6; ++k) dS[k] = sg[k].d;
 }
 
 // ---- one entry of the second-order weight matrix of a history step (cm_hessian_history) ---------------------------------

@@ -17,6 +17,12 @@
 //
 // ~1/3 of the flops of the dense path (no 6x6 Hessian, no 7x7 LU); iterates agree with it to round-off, which
 // tests/test_host_math.py checks by running both against the oracle.
+//
+// The surfaces with a dense 6x6 Hessian (hybrid Hill + network, its beta-rescaled form, Barlat Yld2004) are pressure
+// independent as well (they see the stress through its deviator / through L' s, L'' s with zero row sums), so the same
+// elimination holds with  B = M = I + beta W^-1 Ht  (dense 6x6, rho = 0): one 6x6 LU and a scalar Schur complement instead of
+// assembling and factoring the 7x7 (8x8) system.  M^T = W M W^-1 (W diagonal, Ht symmetric), so transposed solves reuse the
+// same factors.
 #pragma once
 #include "cm_device.hpp"
 
@@ -27,10 +33,13 @@ namespace cm {
 template <int YK>
 struct YieldS {
     static constexpr bool QUAD = (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL);
+    static constexpr bool DENSE = is_dense_yield(YK);
     double phi, rho;
     double gt[6];
-    double Sst[QUAD ? 1 : 6];      // Hosford only: S00,S03,S05,S33,S35,S55
+    double Sst[QUAD ? 1 : (DENSE ? 21 : 6)];   // Hosford: S00,S03,S05,S33,S35,S55; dense surfaces: upper triangle of Ht, row-major
 };
+// position of Ht[k][l] (any order of k, l) in the packed upper triangle
+CM_D constexpr int sym6(int k, int l) { return (k <= l) ? (k * (11 - k)) / 2 + l : (l * (11 - l)) / 2 + k; }
 
 // S (3x3 on slots 0,3,5: S00,S03,S05,S33,S35,S55) and t (shear slots 1,2,4)
 template <int YK>
@@ -66,6 +75,14 @@ CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS<YK>& y)
 #pragma unroll
         for (int k = 0; k < 6; ++k) y.gt[k] = As[k] * ip;
         y.rho = ip;
+    } else if constexpr (YieldS<YK>::DENSE) {
+        double Ht[6][6];
+        yield_eval<YK, true>(m, s, y.phi, y.gt, Ht);
+        y.rho = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int l = k; l < 6; ++l) y.Sst[sym6(k, l)] = Ht[k][l];
     } else {
         double Ht[6][6];
         yield_eval<YK, true>(m, s, y.phi, y.gt, Ht);          // Hosford: Ht lives on the normal block only
@@ -78,6 +95,16 @@ CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS<YK>& y)
 // blk(S, t) u
 template <int YK>
 CM_D void blk_apply(const cm_model_desc& m, const YieldS<YK>& y, const double u[6], double out[6]) {
+    if constexpr (YieldS<YK>::DENSE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) a += y.Sst[sym6(k, l)] * u[l];
+            out[k] = a;
+        }
+        return;
+    }
     double S[6], t[3];
     yield_blocks<YK>(m, y, S, t);
     out[0] = S[0] * u[0] + S[1] * u[3] + S[2] * u[5];
@@ -150,22 +177,37 @@ CM_D void residual_s(const cm_model_desc& m, const double eg[6], const double* x
 }
 
 // A = dC/dx in structured form at an evaluated state
-struct PlasticOp {
+template <bool DENSE>
+struct PlasticOpT {
     double inv3[6];   // (I + beta S)^-1, symmetric: 00,03,05,33,35,55
     double ib[3];     // 1 / (1 + beta t_j / 2)
     double eta, j66, k, beta;
     bool plastic, ok;
+    double M[DENSE ? 6 : 1][DENSE ? 6 : 1];   // dense surfaces: LU factors of I + beta W^-1 Ht (cm::lu_factor layout)
 };
+using PlasticOp = PlasticOpT<false>;
+template <int YK> using PlasticOpFor = PlasticOpT<is_dense_yield(YK)>;
 
 // J2: A3 = 3/2 I - 1/2 1 1^T and a11 = a22 = a44 = 3, so B = a I - c (1 1^T on the normal block) with
 // a = 1 + 3/2 beta rho, c = 1/2 beta rho, and B^-1 v = (v + c (v0+v3+v5) d) / a   (Sherman-Morrison, a - 3c = 1).
 // Stored as inv3[0] = 1/a, inv3[1] = c.
 template <int YK>
-CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOp& op) {
+CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOpFor<YK>& op) {
     const YieldS<YK>& y = ev.y;
     op.plastic = ev.plastic;
     op.beta = 2.0 * m.mu * ev.dgam;
     const double b = op.beta;
+    if constexpr (YieldS<YK>::DENSE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int l = 0; l < 6; ++l) op.M[k][l] = ((k == l) ? 1.0 : 0.0) + b * kIW[k] * y.Sst[sym6(k, l)];
+        op.ok = lu_factor<6>(op.M);
+        op.eta = 0.0;
+        op.j66 = -ev.hd.dH * half_over_mu(m);
+        op.k = 1.0;
+        return;
+    }
     if constexpr (YK == CM_YIELD_J2) {
         const double br = b * y.rho;
         const double a = 1.0 + 1.5 * br;
@@ -194,8 +236,18 @@ CM_D void op_build(const cm_model_desc& m, const EvalS<YK>& ev, PlasticOp& op) {
     op.k = 1.0 + op.j66 * op.eta;
 }
 
-template <int YK>
-CM_D void binv(const PlasticOp& op, const double v[6], double out[6]) {
+// out = B^-1 v (TRANSPOSED: B^-T v; B is symmetric except for the dense surfaces, where B^T = W B W^-1)
+template <int YK, bool TRANSPOSED = false>
+CM_D void binv(const PlasticOpFor<YK>& op, const double v[6], double out[6]) {
+    if constexpr (YieldS<YK>::DENSE) {
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = TRANSPOSED ? v[k] * kIW[k] : v[k];
+        lu_subst<6>(op.M, t);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = TRANSPOSED ? t[k] * kW[k] : t[k];
+        return;
+    }
     if constexpr (YK == CM_YIELD_J2) {
         const double ia = op.inv3[0], cs = op.inv3[1] * (v[0] + v[3] + v[5]);
 #pragma unroll
@@ -210,7 +262,7 @@ CM_D void binv(const PlasticOp& op, const double v[6], double out[6]) {
 
 // x = A^-1 b (TRANSPOSED: A^-T b); b and x may alias
 template <bool TRANSPOSED, int YK>
-CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, double* x) {
+CM_D void op_solve(const PlasticOpFor<YK>& op, const YieldS<YK>& y, const double* b, double* x) {
     if (!op.plastic) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) x[k] = b[k];
@@ -243,8 +295,8 @@ CM_D void op_solve(const PlasticOp& op, const YieldS<YK>& y, const double* b, do
     for (int k = 0; k < 6; ++k) n[k] = y.gt[k] * kIW[k];
     const double* col = TRANSPOSED ? y.gt : n;      // the vector multiplying tau
     const double* row = TRANSPOSED ? n : y.gt;      // the vector contracted with x_v
-    binv<YK>(op, b, p);
-    binv<YK>(op, col, q);
+    binv<YK, TRANSPOSED>(op, b, p);
+    binv<YK, TRANSPOSED>(op, col, q);
     const double rp = dot<6>(row, p), rq = dot<6>(row, q);
     const double tau = (b[6] + op.k * rp) * rcp(op.j66 - op.k * rq);
     const double s = rp + rq * tau;
@@ -263,7 +315,7 @@ struct Border {
     double u[7], r[6], d;
 };
 template <int YK>
-CM_D void border_build(const cm_model_desc& m, const PlasticOp& op, const EvalS<YK>& ev, const double z[6], Border& bd) {
+CM_D void border_build(const cm_model_desc& m, const PlasticOpFor<YK>& op, const EvalS<YK>& ev, const double z[6], Border& bd) {
     const double l2m = m.lambda * half_over_mu(m), zt = z[0] + z[3] + z[5];
     double dd = l2m * zt * zt;
 #pragma unroll
@@ -281,7 +333,7 @@ CM_D void border_build(const cm_model_desc& m, const PlasticOp& op, const EvalS<
 
 // y = A^-1 b (TRANSPOSED: A^-T b) for DEF's full system; b and y may alias.  Returns false on a zero pivot.
 template <int DEF, bool TRANSPOSED, int YK>
-CM_D bool solve_s(const cm_model_desc& m, const PlasticOp& op, const EvalS<YK>& ev, const double* z, const double* b, double* y) {
+CM_D bool solve_s(const cm_model_desc& m, const PlasticOpFor<YK>& op, const EvalS<YK>& ev, const double* z, const double* b, double* y) {
     if constexpr (DEF == CM_FULL_3D) {
         op_solve<TRANSPOSED>(op, ev.y, b, y);
         return true;
@@ -347,7 +399,7 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
             if (!__any(running)) break;
             if (running) {
                 double delta[NX];
-                PlasticOp op;
+                PlasticOpFor<YK> op;
                 op_build<YK>(m, ev, op);               // ev is the evaluation at the current x (carried)
                 if (!op.ok) flags |= CM_STATUS_SINGULAR;
                 if (!solve_s<DEF, false>(m, op, ev, z, C, delta)) flags |= CM_STATUS_SINGULAR;
@@ -410,7 +462,7 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
                 else if (it >= m.max_iters) running = false;
                 else {
                     double delta[NX];
-                    PlasticOp op;
+                    PlasticOpFor<YK> op;
                     op_build<YK>(m, ev, op);
                     if (!op.ok) flags |= CM_STATUS_SINGULAR;
                     if (!solve_s<DEF, false>(m, op, ev, z, C, delta)) flags |= CM_STATUS_SINGULAR;
@@ -517,7 +569,7 @@ CM_D bool reverse_point_s(const cm_model_desc& m, const double eg[6], const doub
     const double etr = ee[0] + ee[3] + ee[5];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ss[k] = 2.0 * m.mu * ee[k] + (kDiag[k] ? m.lambda * etr : 0.0);
-    PlasticOp op;
+    PlasticOpFor<YK> op;
     op_build<YK>(m, ev, op);
     double csb[6];
     apply_cel(m, sbm, csb);
@@ -609,7 +661,7 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
     EvalS<YK> ev;
     double C[NX];
     residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);
-    PlasticOp op;
+    PlasticOpFor<YK> op;
     op_build<YK>(m, ev, op);
     const YieldS<YK>& y = ev.y;
     bool ok = op.ok;
@@ -641,11 +693,11 @@ CM_D bool tangent_point_s(const cm_model_desc& m, const double eg[6], const doub
     return ok;
 }
 
-// ---- front doors: structured for FULL_3D / PLANE_STRESS with J2, Hill, Hosford; dense otherwise
-// (STRUCT = false forces the dense path) -------------------------------------------------------------------
+// ---- front doors: structured for FULL_3D / PLANE_STRESS (every yield surface is pressure independent); the dense
+// unrolled LU for UNIAXIAL_STRESS and the rate form (STRUCT = false forces the dense path) -------------------------------------------------------------------
 template <int DEF, int YK>
 constexpr bool has_structured() {
-    return (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS) && !is_dense_yield(YK);
+    return DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS;
 }
 // RL: the J2 radial-line iteration (default; cm_model_desc.solver_flags & CM_SOLVER_GENERAL_NEWTON disables it); a compile-time
 // variant chosen by the launcher so that the default kernels do not carry its code and registers.
@@ -834,11 +886,10 @@ CM_D void direct_history_point(const cm_model_desc& m, int K, const double* grad
     for (int i = 0; i < NX * NP_; ++i) din[i] = 0.0;
     if (dx_dp_hist) for (int i = 0; i < NX * NP_; ++i) io.put(dx_dp_hist, i, 0.0);                   // slot 0
     if (ds_dp_hist) for (int i = 0; i < 6 * NP_; ++i) io.put(ds_dp_hist, i, 0.0);
-    for (int k = 0; k < NU; ++k) Gp[k] = io.get(gradu_hist, k);
-    for (int k = 0; k < NX; ++k) xp[k] = io.get(xi_hist, k);
     for (int step = 1; step <= K; ++step) {
-        for (int k = 0; k < NU; ++k) G[k] = io.get(gradu_hist, (int64_t)step * NU + k);
-        for (int k = 0; k < NX; ++k) x[k] = io.get(xi_hist, (int64_t)step * NX + k);
+        // both configurations and both states are read per step (nothing but the sensitivity block is carried)
+        for (int k = 0; k < NU; ++k) { G[k] = io.get(gradu_hist, (int64_t)step * NU + k); Gp[k] = io.get(gradu_hist, (int64_t)(step - 1) * NU + k); }
+        for (int k = 0; k < NX; ++k) { x[k] = io.get(xi_hist, (int64_t)step * NX + k); xp[k] = io.get(xi_hist, (int64_t)(step - 1) * NX + k); }
         direct_point<MK, DEF, YK, ROT>(m, G, Gp, x, xp, step > 1 ? din : nullptr, dout, dsig);
         if (dx_dp_hist) for (int i = 0; i < NX * NP_; ++i) io.put(dx_dp_hist, (int64_t)step * NX * NP_ + i, dout[i]);
         if (ds_dp_hist) for (int i = 0; i < 6 * NP_; ++i) io.put(ds_dp_hist, (int64_t)step * 6 * NP_ + i, dsig[i]);
@@ -855,8 +906,6 @@ CM_D void direct_history_point(const cm_model_desc& m, int K, const double* grad
             }
         }
         for (int i = 0; i < NX * NP_; ++i) din[i] = dout[i];
-        for (int k = 0; k < NU; ++k) Gp[k] = G[k];
-        for (int k = 0; k < NX; ++k) xp[k] = x[k];
     }
 }
 

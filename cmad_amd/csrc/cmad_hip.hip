@@ -3,11 +3,12 @@
 // element [k*B + b] -> every global access is a 512-byte contiguous row per wave instruction.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
-#include "cm_structured.hpp"
+#include "cm_pool.hpp"
 #include "cm_hessian.hpp"
 
 // The library can be built from this one file in nine independent pieces (hipcc -DCM_PART=0..8, see
 // cmad_amd/build.py) so the template instantiations compile in parallel; without CM_PART everything is one TU.
+//   9: cm_param_blocks, cm_param_adjoint_history (extended parameter sensitivities)
 //   0: cm_update            2: cm_update_vjp, cm_adjoint_step   4: cm_update_tangent          6: cm_objective_grad,
 //   1: cm_update_rate, info 3: cm_update_and_vjp                5: cm_evaluate(_rate)            cm_hessians
 #ifndef CM_PART
@@ -170,6 +171,105 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>()))
                 for (int r = 0; r < 6; ++r) (dsig + (int64_t)(r * NU + c) * B)[b] = tg[r];
             }
         }
+    }
+}
+
+// ---- cm_update on a work pool: every lane iterates, no lane waits for the slowest point of its wavefront ---------------
+// One wavefront per workgroup, persistent: wavefront w owns the chunks w, w + W, w + 2W, ... of kPoolChunk consecutive
+// points (W = wavefronts in the grid; static assignment -- no atomics, no workspace, results independent of scheduling).
+// Each lane runs the resumable Newton of cm_pool.hpp on its current point; when kPoolRefill lanes of the wavefront have
+// finished theirs (or nothing is left to hand out), those lanes store their results and take the next consecutive points
+// of the wavefront's chunk, so a refill reads and writes contiguous runs of every SoA row.  Used for the iteration-bound
+// configurations (everything but J2 / FULL_3D): a lockstep wavefront runs max(iterations) over its 64 points there.
+#ifndef CM_POOL_REFILL
+#define CM_POOL_REFILL 16
+#endif
+constexpr int kPoolRefill = CM_POOL_REFILL;
+
+template <int DEF, int YK>
+constexpr int min_waves_pool() { return is_dense_yield(YK) ? 2 : 1; }
+// Where the pool pays (measured, profiles/r02_pool_ab.txt): a pass must cost much more than the retire / refill bookkeeping and
+// the per-lane addressing -- the dense surfaces (network, Barlat: 1.6-1.8x) and Hosford under the line search (a = 100 with
+// the notch deck's settings: 2.1x).  J2 / Hill on the structured solve lose 10-30 % and stay in lockstep.
+template <int YK, bool LS>
+constexpr bool pool_pays() { return is_dense_yield(YK) || (YK == CM_YIELD_HOSFORD && LS); }
+
+template <int DEF, int YK, bool ROT, bool LS>
+__global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int kPoolChunk,
+        const double* __restrict__ gradu, const double* __restrict__ xi_prev,
+        double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    __shared__ double ls_stage[LS ? 2 * NX * 64 : 1];
+    const LaneStage stage{ls_stage + (LS ? threadIdx.x : 0), 64};
+    const int64_t nwaves = gridDim.x;
+    int64_t chunk = blockIdx.x;                                  // wave-uniform cursor over this wavefront's chunks
+    int64_t cur = chunk * kPoolChunk, cend = cur + kPoolChunk < B ? cur + kPoolChunk : B;
+    double x[NX], xp[NX], eg[6], z[Dims<DEF>::NZ];
+    strain_z<DEF, ROT>(m, z);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) { x[k] = 0.0; xp[k] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) eg[k] = 0.0;
+    int64_t pt = -1;
+    bool running = false;
+    PassState st;
+    pass_reset(st);
+    for (;;) {
+        const uint64_t idle_mask = __ballot(!running);
+        const int nidle = __popcll(idle_mask);
+        const bool more = cur < B;                               // uniform: points left in this wavefront's chunks
+        if (nidle == 64 || (more && nidle >= kPoolRefill)) {
+            if (!running && pt >= 0) {                           // retire: state, stress and status of the finished point
+                Eval<DEF> ev;
+                strain_stress<DEF>(m, eg, z, x, ev);
+                double sg[6];
+                to_global<ROT>(m, ev.s, sg);
+#pragma unroll
+                for (int k = 0; k < NX; ++k) (xi + (int64_t)k * B)[pt] = x[k];
+                if (sigma) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) (sigma + (int64_t)k * B)[pt] = sg[k];
+                }
+                if (status) {
+                    uint32_t sw = st.flags | (uint32_t)st.it;
+                    double phi, gt[6], Ht[6][6];
+                    yield_eval<YK, false>(m, ev.s, phi, gt, Ht);
+                    const double f = (phi - (m.Y + hardening(m, x[6]).H)) * 0.5 / m.mu;
+                    if ((f > m.yield_tol) || (fabs(f) < m.yield_tol)) sw |= CM_STATUS_PLASTIC;
+                    status[pt] = sw;
+                }
+                pt = -1;
+            }
+            if (more) {                                          // refill: consecutive points to the idle lanes, in lane order
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                int need = nidle, first = 0;
+                while (need > 0 && cur < B) {                    // uniform; at most two chunks per refill
+                    const int avail = (int)(cend - cur);
+                    const int take = need < avail ? need : avail;
+                    if (!running && pt < 0 && rank >= first && rank < first + take) pt = cur + (rank - first);
+                    cur += take; first += take; need -= take;
+                    if (cur == cend) {
+                        chunk += nwaves;
+                        cur = chunk * kPoolChunk;
+                        cend = cur + kPoolChunk < B ? cur + kPoolChunk : B;
+                        if (cur > B) cur = B;
+                    }
+                }
+                if (!running && pt >= 0) {
+                    double G[NU];
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) G[k] = (gradu + (int64_t)k * B)[pt];
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) { xp[k] = (xi_prev + (int64_t)k * B)[pt]; x[k] = xp[k]; }
+                    strain_from_gradu<DEF, ROT>(m, G, eg);
+                    pass_reset(st);
+                    running = true;
+                }
+            }
+        }
+        if (!__any(running)) break;
+        newton_pass<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, st, running, stage);
     }
 }
 
@@ -808,6 +908,60 @@ __global__ __launch_bounds__(256) void k_sum_rows(const double* __restrict__ par
     out[j] = acc;
 }
 
+// ---- extended parameter sensitivities: forward-mode evaluation of the whole model (cm::param_direction) ----------------
+// surfaces the arithmetic-T model (cm_hessian.hpp) covers: everything but Barlat (its eigen-decomposition is hand-derived only)
+constexpr bool has_generic_eval(int yk) { return yk != CM_YIELD_BARLAT; }
+
+// cm_param_blocks: one thread per (point, requested parameter): dC/dp_e [n_xi] and d sigma/dp_e [6]
+template <int DEF, int YK, int MK>
+__global__ __launch_bounds__(64) void k_param_blocks(cm_model_desc m, int64_t B, int n_ep, const int32_t* __restrict__ ep_index,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
+        const double* __restrict__ xi, double* __restrict__ dC, double* __restrict__ dS) {
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * n_ep) return;
+    const int64_t pt = tid / n_ep;
+    const int j = (int)(tid % n_ep);
+    double G[NU], xp[NX], x[NX], oC[NX], oS[6];
+    for (int k = 0; k < NU; ++k) {
+        G[k] = gradu[(int64_t)k * B + pt];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_prev[(int64_t)k * B + pt];
+    }
+    for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + pt]; x[k] = xi[(int64_t)k * B + pt]; }
+    param_direction<DEF, YK, MK>(m, G, x, xp, ep_index[j], oC, oS);
+    if (dC) for (int k = 0; k < NX; ++k) dC[((int64_t)j * NX + k) * B + pt] = oC[k];
+    if (dS) for (int k = 0; k < 6; ++k) dS[((int64_t)j * 6 + k) * B + pt] = oS[k];
+}
+
+// cm_param_adjoint_history: rows[pt][j] = sum_k sbar_k . d sigma_k/dp_e - lam_k . dC_k/dp_e over the stored history
+template <int DEF, int YK, int MK>
+__global__ __launch_bounds__(64) void k_param_adjoint_history(cm_model_desc m, int64_t B, int K, int n_ep,
+        const int32_t* __restrict__ ep_index, const double* __restrict__ gradu_hist, const double* __restrict__ xi_hist,
+        const double* __restrict__ lam_hist, const double* __restrict__ sbar_hist, double* __restrict__ rows) {
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * n_ep) return;
+    const int64_t pt = tid / n_ep;
+    const int j = (int)(tid % n_ep);
+    const int e = ep_index[j];
+    double acc = 0.0;
+    for (int step = 1; step <= K; ++step) {
+        double G[NU], xp[NX], x[NX], oC[NX], oS[6];
+        for (int k = 0; k < NU; ++k) {
+            G[k] = gradu_hist[((int64_t)step * NU + k) * B + pt];
+            if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_hist[((int64_t)(step - 1) * NU + k) * B + pt];
+        }
+        for (int k = 0; k < NX; ++k) {
+            xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + pt];
+            x[k] = xi_hist[((int64_t)step * NX + k) * B + pt];
+        }
+        param_direction<DEF, YK, MK>(m, G, x, xp, e, oC, oS);
+        for (int k = 0; k < NX; ++k) acc -= lam_hist[((int64_t)step * NX + k) * B + pt] * oC[k];
+        for (int r = 0; r < 6; ++r) acc += sbar_hist[((int64_t)step * 6 + r) * B + pt] * oS[r];
+    }
+    rows[pt * n_ep + j] = acc;
+}
+
 // ---- dispatch --------------------------------------------------------------------------------------
 inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
 
@@ -870,6 +1024,17 @@ inline int check_launch() {
     return CM_OK;
 }
 
+// wavefronts of a one-wave-per-workgroup kernel the device keeps resident (persistent grids of the work-pool kernels)
+inline int pool_resident_waves(const void* kernel) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
+        (void)hipGetLastError();
+        return 256 * 8;                                          // MI355X: 256 CUs, two waves per SIMD
+    }
+    return cus * per_cu;
+}
+
 template <bool TANGENT>
 int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                   double* xi, double* sigma, double* dsig, uint32_t* status, void* stream) {
@@ -885,6 +1050,18 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
         if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
+                return;
+            }
+        }
+        if constexpr (!TANGENT && pool_pays<Y, LS>()) {
+            // expensive, iteration-bound passes: the work-pool kernel (CM_SOLVER_LOCKSTEP: one point per lane as everywhere else)
+            if (!(m->solver_flags & CM_SOLVER_LOCKSTEP) && B >= 256) {
+                static const int resident = pool_resident_waves((const void*)k_update_pool<D, Y, R, LS>);
+                // chunks of 256 points when every resident wavefront gets at least eight of them, else of 64
+                const int chunk = (B >= (int64_t)resident * 256 * 8) ? 256 : 64;
+                const int64_t nchunks = (B + chunk - 1) / chunk;
+                const unsigned nw = (unsigned)(nchunks < resident ? nchunks : resident);
+                hipLaunchKernelGGL((k_update_pool<D, Y, R, LS>), dim3(nw), dim3(64), 0, s, md, B, chunk, gradu, xi_prev, xi, sigma, status);
                 return;
             }
         }
@@ -1088,7 +1265,7 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
                     const double* xi_prev, const double* xi,
                     double* d2C, double* d2S, double* dC, double* dS, double* C0, double* S0, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind)) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
@@ -1098,7 +1275,7 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
     const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!is_dense_yield(Y))
+        if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y)))
             hipLaunchKernelGGL((k_hessians<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi,
                                d2C, d2S, dC, dS, C0, S0);
     });
@@ -1111,8 +1288,9 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
                            const double* lam_hist, const double* dx_dp_hist, const double* sbar_hist, const double* hss6,
                            double* out, void* workspace, int64_t wbytes, void* stream) {
     if (!m || B < 0 || K < 1 || !out || !workspace || !hss6) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || is_dense_yield(m->yield_kind) ||
-        (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) ||
+        (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (m->def_type == CM_UNIAXIAL_STRESS || is_dense_yield(m->yield_kind))))
+        return CM_ERR_UNSUPPORTED;
     if (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !dx_dp_hist || !sbar_hist)) return CM_ERR_BAD_ARG;
     if (wbytes < cm_hessian_workspace_bytes(m, B, K)) return CM_ERR_WORKSPACE;
     const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
@@ -1128,7 +1306,7 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
         const int64_t nthreads = nps * (int64_t)(nq * (nq + 1) / 2);
         const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (!is_dense_yield(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS)) {
+            if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (D == CM_UNIAXIAL_STRESS || is_dense_yield(Y)))) {
                 hipLaunchKernelGGL((k_hessian_weights<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist, lam_hist,
                                    sbar_hist, h, W);
                 hipLaunchKernelGGL((k_hessian_quadform<Dims<D>::NX>), dim3((unsigned)nps), dim3(192), 0, s, B, K, W, dx_dp_hist, part);
@@ -1138,6 +1316,55 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, s, part, nps, NPP, out);
+    return check_launch();
+}
+#endif
+
+
+#if CM_HAS_PART(9)
+template <int MK>
+int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu,
+                        const double* gradu_prev, const double* xi_prev, const double* xi, double* dC, double* dS, void* stream) {
+    if (!m || B < 0 || n_ep < 0) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (B == 0 || n_ep == 0) return CM_OK;
+    if (!ep_index || !gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    const dim3 grid((unsigned)((B * n_ep + 63) / 64)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y)))
+            hipLaunchKernelGGL((k_param_blocks<D, Y, MK>), grid, block, 0, s, md, B, n_ep, ep_index, gradu, gradu_prev, xi_prev, xi, dC, dS);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+
+template <int MK>
+int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n_ep, const int32_t* ep_index,
+                                 const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* sbar_hist,
+                                 double* grad_ep, void* workspace, int64_t wbytes, void* stream) {
+    if (!m || B < 0 || K < 1 || n_ep < 0 || !grad_ep) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (n_ep == 0) return CM_OK;
+    if (!workspace || wbytes < (B > 0 ? B : 1) * (int64_t)n_ep * (int64_t)sizeof(double)) return CM_ERR_WORKSPACE;
+    if (!ep_index || (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !sbar_hist))) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    hipStream_t s = (hipStream_t)stream;
+    double* rows = (double*)workspace;
+    if (B > 0) {
+        const dim3 grid((unsigned)((B * n_ep + 63) / 64)), block(64);
+        const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y)))
+                hipLaunchKernelGGL((k_param_adjoint_history<D, Y, MK>), grid, block, 0, s, md, B, K, n_ep, ep_index, gradu_hist, xi_hist,
+                                   lam_hist, sbar_hist, rows);
+        });
+        if (!found) return CM_ERR_UNSUPPORTED;
+        if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)((n_ep + 255) / 256)), dim3(256), 0, s, rows, B, n_ep, grad_ep);
     return check_launch();
 }
 #endif
@@ -1300,6 +1527,27 @@ int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K, const doubl
                                                                      sigma_bar_hist, hss6, hess_pp, workspace, workspace_bytes, stream);
     return launch_hessian_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sigma_bar_hist,
                                                             hss6, hess_pp, workspace, workspace_bytes, stream);
+}
+#endif
+
+#if CM_HAS_PART(9)
+int cm_param_blocks(const cm_model_desc* m, int64_t B, int32_t n_ep, const int32_t* ep_index,
+                    const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
+                    double* dC_dp, double* dsigma_dp, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return launch_param_blocks<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, n_ep, ep_index, gradu, gradu_prev, xi_prev, xi, dC_dp, dsigma_dp, stream);
+    return launch_param_blocks<CM_SMALL_ELASTIC_PLASTIC>(m, B, n_ep, ep_index, gradu, nullptr, xi_prev, xi, dC_dp, dsigma_dp, stream);
+}
+int cm_param_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
+                             const double* gradu_hist, const double* xi_hist, const double* lam_hist,
+                             const double* sigma_bar_hist, double* grad_ep, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return launch_param_adjoint_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, n_ep, ep_index, gradu_hist, xi_hist, lam_hist,
+                                                                           sigma_bar_hist, grad_ep, workspace, workspace_bytes, stream);
+    return launch_param_adjoint_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, n_ep, ep_index, gradu_hist, xi_hist, lam_hist, sigma_bar_hist,
+                                                                  grad_ep, workspace, workspace_bytes, stream);
 }
 #endif
 

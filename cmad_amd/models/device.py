@@ -44,6 +44,9 @@ class NewtonSettings:
     # leaves (same iterates and counts).  False forces the general 7-dof iteration
     # (include/cmad_hip.h CM_SOLVER_GENERAL_NEWTON).  Ignored for every other configuration.
     j2_radial_line: bool = True
+    # cm_update runs the iteration-bound configurations on a work pool (a lane that has finished its point takes the next
+    # one, include/cmad_hip.h CM_SOLVER_LOCKSTEP); True keeps one point per lane for the whole kernel (A/B measurements).
+    lockstep: bool = False
 
     @classmethod
     def traced(cls, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search_settings=None):
@@ -151,7 +154,8 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     d.ls_c1 = float(ls.get("sufficient decrease", 1e-4))
     d.ls_lo = float(ls.get("min backtrack factor", 0.5))
     d.ls_hi = float(ls.get("max backtrack factor", 0.9))
-    d.solver_flags = 0 if getattr(newton, "j2_radial_line", True) else _lib.SOLVER_GENERAL_NEWTON
+    d.solver_flags = (0 if getattr(newton, "j2_radial_line", True) else _lib.SOLVER_GENERAL_NEWTON) | \
+                     (_lib.SOLVER_LOCKSTEP if getattr(newton, "lockstep", False) else 0)
     info = {"elastic_names": names, "lame_jac": J, "yield_type": ytype}
     if hybrid is not None:
         widths, packed = hybrid.packed(values)
@@ -159,6 +163,7 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
         for i, w in enumerate(widths):
             d.nn_widths[i] = int(w)
         info["yield_type"] = "hybrid"
+        info["nn_widths"] = [int(w) for w in widths]
         info["nn_packed"] = np.ascontiguousarray(packed, dtype=np.float64)   # the caller places it and sets d.nn_weights
     return d, info
 
@@ -193,6 +198,45 @@ def kp_to_leaf_grad(path, g_kp, info):
     if parent == "barlat":
         raise NotImplementedError("sensitivities w.r.t. the Barlat coefficients are not available in the HIP path")
     raise KeyError(path)
+
+
+# extended parameter ("EP") indexing of cm_param_blocks / cm_param_adjoint_history (include/cmad_hip.h)
+EP_YC6, EP_Q0, EP_NN0 = 12, 25, 34
+
+
+def leaf_ep_index(path, info):
+    """EP index of the parameter-tree entry at `path` (as `Parameters.active_paths()` gives it: array leaves end with the
+    flat element index) when the entry is differentiated by forward-mode evaluation of the whole model (rotation matrix,
+    Hosford exponent, Hill coefficients of the network surfaces, network weights); None when the 12 hand-derived native
+    sensitivities (`kp_to_leaf_grad`) cover it."""
+    if path[0] == "rotation matrix":
+        idx = [k for k in path[1:] if isinstance(k, (int, np.integer))]
+        flat = idx[0] if len(idx) == 1 else 3 * idx[0] + idx[1]
+        return EP_Q0 + int(flat)
+    names = [k for k in path if isinstance(k, str)]
+    if "neural network" in names:
+        widths = info.get("nn_widths")
+        if widths is None or len(widths) != 3:
+            raise NotImplementedError("network-weight sensitivities need the hybrid surface with layer widths [6, H, 1]")
+        H = widths[1]
+        ints = [k for k in path if isinstance(k, (int, np.integer))]
+        layer, elem = int(ints[0]), (int(ints[1]) if len(ints) > 1 else 0)
+        kind, what = ("x params" in names), names[-1]
+        if kind and layer == 0:
+            return EP_NN0 + (elem if what == "weights" else 6 * H + elem)
+        if kind and layer == 1:
+            return EP_NN0 + (7 * H + elem if what == "weights" else 7 * H + 6)
+        if "z params" in names and layer == 0:
+            return EP_NN0 + 7 * H + 7 + elem
+        raise KeyError(path)
+    parent = names[-2] if len(names) >= 2 else None
+    if parent == "hosford":
+        return _lib.P_YC0
+    if parent == "hill" and info.get("yield_type") == "hybrid":
+        return _lib.P_YC0 + HILL_NAMES.index(names[-1])
+    if parent == "barlat":
+        raise NotImplementedError("sensitivities w.r.t. the Barlat coefficients are not available in the HIP path")
+    return None
 
 
 def _torch():
@@ -538,6 +582,37 @@ class DeviceEvaluator:
                                        _ptr(sigma_bar_hist), h, _ptr(H), _ptr(ws), need, self._stream())
         _lib.check(rc, "cm_hessian_history")
         return H
+
+    def param_blocks(self, ep_index, gradu, xi_prev, xi, gradu_prev=None):
+        """`cm_param_blocks`: (dC_dp (n_ep, n_xi, B), dsigma_dp (n_ep, 6, B)) for the extended parameter indices."""
+        torch = _torch()
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu"); _check_soa(xi_prev, self.nx, B, "xi_prev"); _check_soa(xi, self.nx, B, "xi")
+        gp = self._rate_prev(gradu_prev, B)
+        dev = gradu.device
+        ep = torch.tensor([int(e) for e in ep_index], dtype=torch.int32, device=dev)
+        dC = torch.empty((len(ep_index), self.nx, B), dtype=torch.float64, device=dev)
+        dS = torch.empty((len(ep_index), 6, B), dtype=torch.float64, device=dev)
+        rc = self.L.cm_param_blocks(C.byref(self.desc), B, len(ep_index), _ptr(ep), _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(xi),
+                                    _ptr(dC), _ptr(dS), self._stream())
+        _lib.check(rc, "cm_param_blocks")
+        return dC, dS
+
+    def param_adjoint_history(self, ep_index, gradu_hist, xi_hist, lam_hist, sigma_bar_hist):
+        """`cm_param_adjoint_history`: the extended parameters' share of the objective gradient, (n_ep,) device tensor."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        self._check_hist(gradu_hist, self.nu, K, B, "gradu_hist"); self._check_hist(xi_hist, self.nx, K, B, "xi_hist")
+        self._check_hist(lam_hist, self.nx, K, B, "lam_hist"); self._check_hist(sigma_bar_hist, 6, K, B, "sigma_bar_hist")
+        dev = gradu_hist.device
+        n = len(ep_index)
+        ep = torch.tensor([int(e) for e in ep_index], dtype=torch.int32, device=dev)
+        g = torch.empty(n, dtype=torch.float64, device=dev)
+        ws = torch.empty(max(1, B * n), dtype=torch.float64, device=dev)
+        rc = self.L.cm_param_adjoint_history(C.byref(self.desc), B, K, n, _ptr(ep), _ptr(gradu_hist), _ptr(xi_hist), _ptr(lam_hist),
+                                             _ptr(sigma_bar_hist), _ptr(g), _ptr(ws), ws.numel() * 8, self._stream())
+        _lib.check(rc, "cm_param_adjoint_history")
+        return g
 
     def adjoint_step(self, gradu, xi_prev, xi, data6, wsq6, hist_in, hist_out, out, accumulate=True, gradu_prev=None):
         B = gradu.shape[1]

@@ -8,6 +8,7 @@ axis is last, B = 1 for the reference's material-point drivers, any B for batche
     adjoint      cm_adjoint_history           the adjoint recursion for any QoI (the caller supplies dJ/dsigma, dJ/dxi)
     direct       cm_direct_history            the forward-sensitivity recursion + gradient contraction
     hessian      cm_hessian_history           the second-order (direct-adjoint) quadratic form
+    extended     cm_param_adjoint_history     gradient share of the leaves differentiated by forward-mode evaluation
 
 There is no CPU implementation behind it.  tests/host_facade.py substitutes a host build of the same kernel arithmetic
 for CPU CI of the Python logic above it.
@@ -64,3 +65,8 @@ class HistoryEngine:
         H = self._ev.hessian_history(self._dev(gradu_hist, "g"), self._dev(xi_hist), self._dev(lam_hist), self._dev(dxi_dp_hist),
                                      self._dev(sbar_hist), hss6)
         return H.cpu().numpy()
+
+    def extended(self, ep_index, gradu_hist, xi_hist, lam_hist, sbar_hist):
+        g = self._ev.param_adjoint_history(ep_index, self._dev(gradu_hist, "g"), self._dev(xi_hist), self._dev(lam_hist),
+                                           self._dev(sbar_hist))
+        return g.cpu().numpy()

@@ -19,7 +19,7 @@ from .. import _lib
 from ..parameters.parameters import Parameters
 from .deformation_types import DefType
 from .deriv_types import DerivType
-from .device import DeviceEvaluator, NewtonSettings, _ptr, build_desc, kp_to_leaf_grad
+from .device import DeviceEvaluator, NewtonSettings, _ptr, build_desc, kp_to_leaf_grad, leaf_ep_index
 from .global_fields import GlobalFieldsAtPoint
 from .var_types import VarType
 
@@ -159,11 +159,38 @@ class Model(ABC):
         out_S = S.cpu().numpy().reshape(6, ncols) if want_jac and which != DerivType.DNONE else None
         return Cd.cpu().numpy()[:, 0], out_J, s.cpu().numpy()[:, 0], out_S, info
 
-    def _active_columns(self, M_kp, info):
+    def extended_active(self, info=None):
+        """[(position among the active parameters, EP index)] of the active leaves that are differentiated by forward-mode
+        evaluation of the whole model (`leaf_ep_index`): rotation matrix, Hosford exponent, Hill coefficients of the network
+        surfaces, network weights."""
+        info = info or self._desc()[1]
+        out = []
+        for pos, path in enumerate(self.parameters.active_paths()):
+            e = leaf_ep_index(path, info)
+            if e is not None:
+                out.append((pos, e))
+        return out
+
+    def _extended_blocks(self, ep_list, xi, xi_prev, params, U, U_prev):
+        """cm_param_blocks at the gathered state (one point): dC (n_ep, n_xi), dsigma6 (n_ep, 6)."""
+        import torch
+        ev = DeviceEvaluator(*self._desc(params))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).cuda()
+        G = np.asarray(U.grad_fields["u"], dtype=np.float64)
+        gp = None
+        if self._model_kind == 1:
+            gp = t(np.zeros_like(G) if U_prev is None else np.asarray(U_prev.grad_fields["u"], dtype=np.float64))
+        dC, dS = ev.param_blocks(ep_list, t(G), t(self._flat(xi_prev)), t(self._flat(xi)), gradu_prev=gp)
+        return dC.cpu().numpy()[:, :, 0], dS.cpu().numpy()[:, :, 0]
+
+    def _active_columns(self, M_kp, info, ext=None):
         """(rows, KP) kernel-order block -> (rows, num_active_params) in Parameters' flat active order
-        (reference `_active_params_jacobian`, parameters.py:368-377)."""
-        cols = [kp_to_leaf_grad(path[:-1] if isinstance(path[-1], int) else path, M_kp.T, info)
-                for path in self.parameters.active_paths()]
+        (reference `_active_params_jacobian`, parameters.py:368-377).  `ext`: {active position: column} for the leaves
+        served by `cm_param_blocks`."""
+        ext = ext or {}
+        cols = [ext[pos] if pos in ext else
+                kp_to_leaf_grad(path[:-1] if isinstance(path[-1], (int, np.integer)) else path, M_kp.T, info)
+                for pos, path in enumerate(self.parameters.active_paths())]
         return np.stack(cols, axis=1) if cols else np.zeros((M_kp.shape[0], 0))
 
     # ------------------------------------------------------------------ reference :168-190
@@ -177,7 +204,12 @@ class Model(ABC):
             self._Jac = None
         elif mode == DerivType.DPARAMS:
             _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U, U_prev=U_prev)
-            self._Jac = np.asarray(self._active_columns(J, info), dtype=np.float64)
+            ext = self.extended_active(info)
+            cols = {}
+            if ext:
+                dC, _ = self._extended_blocks([e for _, e in ext], xi, xi_prev, params, U, U_prev)
+                cols = {pos: dC[i] for i, (pos, _) in enumerate(ext)}
+            self._Jac = np.asarray(self._active_columns(J, info, cols), dtype=np.float64)
         elif mode == DerivType.DU_PREV and self._model_kind == 0:
             nu = self._ndims ** 2
             self._Jac = np.zeros((self.num_dofs, nu))          # the total-form residual ignores U_prev
@@ -212,10 +244,11 @@ class Model(ABC):
     def _second_derivative_pass(self):
         """cm_hessians for the gathered state -> raw arrays w.r.t. q = [xi, xi_prev, p(KP)]."""
         import torch
-        if self._hybrid is not None:
-            raise NotImplementedError("second derivatives are built for J2 / Hill / Hosford")
         xi, xi_prev, params, U, U_prev = self.variables()
         desc, info = self._desc(params)
+        if "nn_packed" in info:                                           # network surfaces: weights on the device
+            nn_dev = torch.from_numpy(info["nn_packed"]).cuda()
+            desc.nn_weights = nn_dev.data_ptr()
         L = _lib.lib()
         nx, nu = L.cm_num_xi(C.byref(desc)), L.cm_num_gradu(C.byref(desc))
         nq = 2 * nx + _lib.CM_NUM_PARAMS
@@ -265,7 +298,12 @@ class Model(ABC):
         elif mode == DerivType.DPARAMS:
             _, _, _, S, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U, U_prev=U_prev)
             S9 = _sym3(S).reshape(9, -1)                                   # (9, KP)
-            self._dSigma = np.asarray(self._active_columns(S9, info), dtype=np.float64)
+            ext = self.extended_active(info)
+            cols = {}
+            if ext:
+                _, dS = self._extended_blocks([e for _, e in ext], xi, xi_prev, params, U, U_prev)
+                cols = {pos: _sym3(dS[i]).reshape(9) for i, (pos, _) in enumerate(ext)}
+            self._dSigma = np.asarray(self._active_columns(S9, info, cols), dtype=np.float64)
         else:
             _, _, _, S, _ = self._point_evaluate(mode, xi, xi_prev, params, U, U_prev=U_prev)
             self._dSigma = _sym3(S)                                         # (3, 3, n_xi) == np.dstack of blocks
@@ -507,13 +545,16 @@ class Model(ABC):
     def update_tangent_batch(self, gradu, xi_prev, newton: NewtonSettings | None = None):
         return self.device_evaluator(newton).update(gradu, xi_prev, tangent=True)
 
-    def active_grad_from_kp(self, g_kp, info=None):
+    def active_grad_from_kp(self, g_kp, info=None, g_ext=None):
         """Kernel-order gradient (12,) -> Parameters' flat active order, NATIVE parameters (apply
-        `parameters.transform_grad` afterwards for canonical ones, as the objectives do)."""
+        `parameters.transform_grad` afterwards for canonical ones, as the objectives do).  `g_ext`: {active position:
+        value} for the leaves of `extended_active()` (from `cm_param_adjoint_history`)."""
         info = info or self._desc()[1]
         g = np.asarray(g_kp, dtype=np.float64)
-        return np.array([kp_to_leaf_grad(path[:-1] if isinstance(path[-1], int) else path, g, info)
-                         for path in self.parameters.active_paths()])
+        g_ext = g_ext or {}
+        return np.array([g_ext[pos] if pos in g_ext else
+                         kp_to_leaf_grad(path[:-1] if isinstance(path[-1], (int, np.integer)) else path, g, info)
+                         for pos, path in enumerate(self.parameters.active_paths())])
 
     def update_vjp_batch(self, gradu, xi_prev, xi, sigma_bar, newton: NewtonSettings | None = None, **kw):
         ev = self.device_evaluator(newton)

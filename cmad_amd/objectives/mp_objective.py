@@ -56,11 +56,23 @@ class MPObjective(ABC):
         J, sbar, xibar = self._qoi.history_cotangents(sigma_hist, xi_hist)
         return xi0, xi_hist, J, sbar, xibar
 
-    def _canonical_gradient(self, g_kp, info):
-        grad = self._model.active_grad_from_kp(g_kp, info)
+    def _canonical_gradient(self, g_kp, info, g_ext=None):
+        grad = self._model.active_grad_from_kp(g_kp, info, g_ext)
         native = grad.copy()
         self._parameters.transform_grad(grad)
         return grad, native
+
+    def _extended_gradient(self, engine, xi0, xi_hist, sbar, xibar, lam_hist=None):
+        """{active position: dJ/dp} of the active leaves that are differentiated by forward-mode evaluation of the model
+        (rotation matrix, Hosford exponent, Hill coefficients of the network surfaces, network weights; `cm_param_blocks`
+        arithmetic contracted with the adjoint vectors of the history: one more launch, `cm_param_adjoint_history`)."""
+        ext = self._model.extended_active(engine.info)
+        if not ext:
+            return None
+        if lam_hist is None:
+            _, lam_hist = engine.adjoint(self._gradu_hist, sbar, xi0, xibar, want_lam=True)
+        g = engine.extended([e for _, e in ext], self._gradu_hist, xi_hist, lam_hist, sbar)
+        return {pos: float(g[i]) for i, (pos, _) in enumerate(ext)}
 
 
 class MPAdjointObjective(MPObjective):
@@ -68,14 +80,16 @@ class MPAdjointObjective(MPObjective):
 
     def _evaluate(self, engine) -> GradientResult:
         fused = self._qoi.fused_calibration()
-        if fused is not None:
+        g_ext = None
+        if fused is not None and not self._model.extended_active(engine.info):
             wsq6, data6_hist, const = fused
             J, g_kp = engine.calibration(self._gradu_hist, data6_hist, wsq6, self._model.init_state(1))
             J += const
         else:
-            xi0, _, J, sbar, xibar = self._primal_and_cotangents(engine)
-            g_kp, _ = engine.adjoint(self._gradu_hist, sbar, xi0, xibar)
-        grad, _ = self._canonical_gradient(g_kp, engine.info)
+            xi0, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
+            g_kp, lam_hist = engine.adjoint(self._gradu_hist, sbar, xi0, xibar, want_lam=True)
+            g_ext = self._extended_gradient(engine, xi0, xi_hist, sbar, xibar, lam_hist)
+        grad, _ = self._canonical_gradient(g_kp, engine.info, g_ext)
         return GradientResult(J=float(J), grad=grad)
 
 
@@ -83,9 +97,11 @@ class MPDirectObjective(MPObjective):
     """Gradient by forward sensitivities: dxi_k/dp carried through the history, contracted with the QoI cotangents."""
 
     def _evaluate(self, engine) -> GradientResult:
-        _, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
+        xi0, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
         g_kp, _ = engine.direct(self._gradu_hist, xi_hist, sbar, xibar)
-        grad, _ = self._canonical_gradient(g_kp, engine.info)
+        # leaves outside the 12 native parameters have no carried sensitivity block: their share comes from the adjoint form
+        g_ext = self._extended_gradient(engine, xi0, xi_hist, sbar, xibar)
+        grad, _ = self._canonical_gradient(g_kp, engine.info, g_ext)
         return GradientResult(J=float(J), grad=grad)
 
 
@@ -103,6 +119,9 @@ class MPDirectAdjointObjective(MPObjective):
         xi0, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
         if xibar is not None:
             raise NotImplementedError("the second-order pass takes QoIs of the stress only")
+        if model.extended_active(engine.info):
+            raise NotImplementedError("second-order sensitivities cover the 12 native parameters (no rotation matrix, Hosford "
+                                      "exponent, network-surface coefficients or weights)")
         g_kp, lam_hist = engine.adjoint(self._gradu_hist, sbar, xi0, want_lam=True)
         _, dxi_dp_hist = engine.direct(self._gradu_hist, xi_hist, sbar, want_blocks=True)
         H_kp = engine.hessian(self._gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar, hss6)

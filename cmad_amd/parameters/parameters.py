@@ -341,4 +341,4 @@ class Parameters:
         return list(self._flat_paths)
 
     def active_paths(self):
-        return [self._flat_paths[i] for i in self.active_idx]
+        return [self._flat_paths[i] for i in getattr(self, "active_idx", [])]

@@ -60,6 +60,10 @@ enum cm_param_index {
  * CM_SOLVER_J2_RADIAL_LINE is accepted for compatibility (the restriction is the default). */
 #define CM_SOLVER_J2_RADIAL_LINE 1
 #define CM_SOLVER_GENERAL_NEWTON 2
+/* cm_update runs the iteration-bound configurations (everything but J2 / FULL_3D) on a work pool: a lane that has
+ * finished its Gauss point takes the next one instead of waiting for the slowest point of its wavefront (same
+ * iteration per point, same results).  CM_SOLVER_LOCKSTEP keeps one point per lane for the whole kernel. */
+#define CM_SOLVER_LOCKSTEP 4
 
 /* status word written per point by cm_update* (all optional outputs may be NULL) */
 #define CM_STATUS_ITERS_MASK 0xFFFFu
@@ -388,13 +392,39 @@ int cm_direct_history(const cm_model_desc* m, int64_t B, int32_t K,
  *   in : gradu_hist, xi_hist (converged), lam_hist (cm_adjoint_history), dxi_dp_hist (cm_direct_history), sigma_bar_hist
  *   out: hess_pp[CM_NUM_PARAMS * CM_NUM_PARAMS] row-major, KP order
  *   workspace: cm_hessian_workspace_bytes(m, B, K)
- * J2 / Hill / Hosford; both model kinds (rate form: FULL_3D, PLANE_STRESS).
+ * J2 / Hill / Hosford and the network surfaces; both model kinds (rate form: FULL_3D, PLANE_STRESS, J2 / Hill / Hosford).
  */
 int64_t cm_hessian_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K);
 int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K,
                        const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* dxi_dp_hist,
                        const double* sigma_bar_hist, const double* hss6, double* hess_pp,
                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * Extended parameter sensitivities.  The hand-derived kernels differentiate w.r.t. the 12 native parameters of
+ * cm_param_index; the reference differentiates w.r.t. EVERY leaf of the params pytree (jacrev in cmad/models/model.py:125-153,
+ * flattened by cmad/parameters/parameters.py:368-377).  The remaining leaves -- rotation matrix, Hosford exponent, Hill
+ * coefficients of the network surfaces, network weights -- are served by forward-mode evaluation of the whole model
+ * (residual, kinematics with the rotation matrix, global stress) in dual-number arithmetic, one direction per thread.
+ * Extended parameter ("EP") index: 0..11 = cm_param_index; 12..24 = yc[6..18]; 25..33 = Q[0..8] (row-major);
+ * 34 + i = packed network weight i (W0[6][H], b0[H], Wx1[6], b1, Wz[H]).  All surfaces but Barlat; both model kinds
+ * (the rate form under UNIAXIAL_STRESS included).
+ *
+ * cm_param_blocks: dC/dp_e and d sigma/dp_e at given states (the DPARAMS blocks of Model.evaluate / evaluate_cauchy,
+ * cmad/models/model.py:168-190, 273-293, for those leaves).
+ *   in : ep_index[n_ep] (DEVICE, int32), gradu, gradu_prev (rate form, else NULL), xi_prev, xi
+ *   out: dC_dp[n_ep][n_xi][B], dsigma_dp[n_ep][6][B] (either may be NULL)
+ * cm_param_adjoint_history: grad_ep[j] = sum_b sum_k sigma_bar_k . d sigma_k/dp_e - lam_k . dC_k/dp_e over a stored history
+ * with the adjoint vectors of cm_adjoint_history -- the extended leaves' share of the objective gradient.
+ *   workspace: B * n_ep doubles
+ */
+int cm_param_blocks(const cm_model_desc* m, int64_t B, int32_t n_ep, const int32_t* ep_index,
+                    const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
+                    double* dC_dp, double* dsigma_dp, void* stream);
+int cm_param_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
+                             const double* gradu_hist, const double* xi_hist, const double* lam_hist,
+                             const double* sigma_bar_hist, double* grad_ep,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

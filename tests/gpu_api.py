@@ -78,3 +78,22 @@ def evaluate(desc, which, gradu, xi_prev, xi, nx, info=None):
 
 def evaluate_rate(desc, which, gradu, gradu_prev, xi_prev, xi, nx, info=None):
     return _evaluate(desc, which, gradu, gradu_prev, xi_prev, xi, nx, info)
+
+
+def param_blocks(desc, ep_index, gradu, xi_prev, xi, nx, gradu_prev=None, info=None):
+    """cm_param_blocks: dC_dp (n_ep, nx, B), dsigma_dp (n_ep, 6, B) for the extended parameter indices."""
+    import torch
+    from cmad_amd import _lib
+    L = _lib.lib()
+    keep = []
+    _place_network(desc, info or {}, keep)
+    ep = torch.tensor(list(ep_index), dtype=torch.int32, device="cuda")
+    B = gradu.shape[1]
+    dC = torch.zeros((len(ep_index), nx, B), dtype=torch.float64, device="cuda")
+    dS = torch.zeros((len(ep_index), 6, B), dtype=torch.float64, device="cuda")
+    g, xp, x = _t(gradu), _t(xi_prev), _t(xi)
+    gp = None if gradu_prev is None else _t(gradu_prev)
+    rc = L.cm_param_blocks(C.byref(desc), B, len(ep_index), _ptr(ep), _ptr(g), _ptr(gp), _ptr(xp), _ptr(x), _ptr(dC), _ptr(dS), None)
+    _lib.check(rc, "cm_param_blocks")
+    torch.cuda.synchronize()
+    return dC.cpu().numpy(), dS.cpu().numpy()

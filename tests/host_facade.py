@@ -37,6 +37,16 @@ class HostHistoryEngine:
     def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss6):
         return hh.hessian_history(self._desc, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss6)
 
+    def extended(self, ep_index, gradu_hist, xi_hist, lam_hist, sbar_hist):
+        K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
+        g = np.zeros(len(ep_index))
+        rate = self._desc.model_kind == 1
+        for k in range(1, K + 1):
+            dC, dS = hh.param_blocks(self._desc, ep_index, gradu_hist[k], xi_hist[k - 1], xi_hist[k], nx,
+                                     gradu_prev=gradu_hist[k - 1] if rate else None)
+            g += np.einsum("erb,rb->e", dS, sbar_hist[k]) - np.einsum("exb,xb->e", dC, lam_hist[k])
+        return g
+
 
 class HostSmallElasticPlastic(SmallElasticPlastic):
     def history_engine(self, newton=None):
@@ -59,6 +69,12 @@ class HostSmallElasticPlastic(SmallElasticPlastic):
         self._xi = [b.astype(self.dtype) for b in self._split(xi[:, 0])]
         s = int(status[0])
         return s & _lib.STATUS_ITERS_MASK, bool(s & _lib.STATUS_CONVERGED)
+
+    def _extended_blocks(self, ep_list, xi, xi_prev, params, U, U_prev):
+        desc, info = self._desc(params)
+        G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
+        dC, dS = hh.param_blocks(desc, ep_list, G, self._flat(xi_prev).reshape(-1, 1), self._flat(xi).reshape(-1, 1), self.num_dofs)
+        return dC[:, :, 0], dS[:, :, 0]
 
     def _second_derivative_pass(self):
         xi, xi_prev, params, U, U_prev = self.variables()

@@ -19,7 +19,8 @@ NPARTS = 7          # host_harness.cpp compiles in independent pieces selected b
 def build(force=False, sanitize=False):
     src = os.path.join(_DIR, "host_harness.cpp")
     deps = [src, os.path.join(_ROOT, "cmad_amd", "csrc", "cm_device.hpp"), os.path.join(_ROOT, "cmad_amd", "csrc", "cm_structured.hpp"),
-            os.path.join(_ROOT, "cmad_amd", "csrc", "cm_hessian.hpp"), os.path.join(_ROOT, "include", "cmad_hip.h")]
+            os.path.join(_ROOT, "cmad_amd", "csrc", "cm_hessian.hpp"), os.path.join(_ROOT, "cmad_amd", "csrc", "cm_pool.hpp"),
+            os.path.join(_ROOT, "include", "cmad_hip.h")]
     out = _SO if not sanitize else os.path.join(_DIR, "libhost_harness_asan.so")
     stale = (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
     if force or stale:
@@ -50,6 +51,12 @@ def lib():
 def set_dense(flag):
     """Force the dense 7x7 path also for FULL_3D (the kernels use the structured solve there)."""
     lib().hh_set_dense(int(bool(flag)))
+
+
+def set_passes(flag):
+    """Solve by cm::newton_pass (cm_pool.hpp: the resumable, one-evaluation-per-pass form of the same iteration that the
+    work-pool kernels run) instead of cm::newton / cm::newton_s."""
+    lib().hh_set_passes(int(bool(flag)))
 
 
 def _p(a):
@@ -153,6 +160,20 @@ def hessian_history(desc, gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, 
     return H
 
 
+def param_blocks(desc, ep_index, gradu, xi_prev, xi, nx, gradu_prev=None, info=None):
+    """cm_param_blocks on the host build: dC_dp (n_ep, nx, B), dsigma_dp (n_ep, 6, B) for the extended parameter indices."""
+    L = lib()
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    gradu, xi_prev, xi, gradu_prev = c(gradu), c(xi_prev), c(xi), c(gradu_prev)
+    ep = np.ascontiguousarray(ep_index, dtype=np.int32)
+    B = gradu.shape[1]
+    dC = np.zeros((len(ep), nx, B)); dS = np.zeros((len(ep), 6, B))
+    rc = L.hh_param_blocks(C.byref(desc), C.c_int64(B), C.c_int(len(ep)), ep.ctypes.data_as(C.c_void_p), _p(gradu), _p(gradu_prev),
+                           _p(xi_prev), _p(xi), _p(dC), _p(dS))
+    assert rc == 0
+    return dC, dS
+
+
 def direct_step(desc, gradu, xi_prev, xi, dxp_dp=None, gradu_prev=None):
     """cm::direct_point over the batch: dxi_dp (nx, 12, B), dsigma_dp (6, 12, B)."""
     L = lib()
@@ -226,7 +247,7 @@ def evaluate_rate(desc, which, gradu, gradu_prev, xi_prev, xi, nx):
     return Cc, J.reshape(nx, ncols, B), s, S.reshape(6, ncols, B)
 
 
-def hessians(desc, gradu, xi_prev, xi, nx, gradu_prev=None, values=False):
+def hessians(desc, gradu, xi_prev, xi, nx, gradu_prev=None, values=False, info=None):
     """d2C (B,nx,nq,nq), d2S (B,6,nq,nq), dC (B,nx,nq), dS (B,6,nq); q = [xi, xi_prev, p(KP)].
     gradu_prev: rate-form model (desc.model_kind = 1)."""
     L = lib()

@@ -5,7 +5,7 @@
 #include <cstdint>
 #include <cstring>
 #define CM_HOST_BUILD 1
-#include "../../cmad_amd/csrc/cm_structured.hpp"
+#include "../../cmad_amd/csrc/cm_pool.hpp"
 #include "../../cmad_amd/csrc/cm_hessian.hpp"
 
 using namespace cm;
@@ -19,8 +19,10 @@ using namespace cm;
 #define g_dense hh_g_dense
 #if HH_HAS(0)
 int hh_g_dense = 0;       // 1: force the dense 7x7 path also for FULL_3D
+int hh_g_passes = 0;      // 1: solve by cm::newton_pass (the resumable form the work-pool kernels run)
 #else
 extern int hh_g_dense;
+extern int hh_g_passes;
 #endif
 
 template <int DEF, int YK, bool ROT>
@@ -38,8 +40,13 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         const LaneStage stage{parked, 1};
         uint32_t st;
         bool done = false;
+        if (hh_g_passes) {
+            st = ls ? newton_by_passes<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, true>(m, eg, z, xp, x, stage)
+                    : newton_by_passes<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, false>(m, eg, z, xp, x, stage);
+            done = true;
+        }
         if constexpr (DEF == CM_FULL_3D && YK == CM_YIELD_J2) {     // same choice as launch_update (cmad_hip.hip)
-            if (!g_dense && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+            if (!done && !g_dense && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 st = ls ? newton_any<DEF, YK, true, true, true>(m, eg, z, xp, x, true, stage)
                         : newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
                 done = true;
@@ -153,8 +160,13 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, deg);
         strain_z<DEF, ROT>(m, z);
-        uint32_t st = (m.ls_max_evals > 0) ? newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, true)
-                                           : newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, true);
+        double parked[2 * 9];
+        const LaneStage stage{parked, 1};
+        uint32_t st;
+        if (hh_g_passes) st = (m.ls_max_evals > 0) ? newton_by_passes<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, stage)
+                                                   : newton_by_passes<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, stage);
+        else st = (m.ls_max_evals > 0) ? newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, true)
+                                       : newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, true);
         to_global<ROT>(m, x, sg);
         for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
         for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
@@ -208,7 +220,7 @@ template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                          double* d2C, double* d2S, double* dC, double* dS, double* C0 = nullptr, double* S0 = nullptr) {
     constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
-    if constexpr (!is_dense_yield(YK)) {
+    if constexpr (YK != CM_YIELD_BARLAT && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(YK))) {
         for (int64_t pt = 0; pt < B; ++pt) {
             double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6], oC0[NX], oS0[6];
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt] - (gradu_prev ? gradu_prev[k * B + pt] : 0.0);
@@ -480,7 +492,27 @@ int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* g
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
-    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (Y != CM_YIELD_BARLAT) body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+}
+#endif
+#if HH_HAS(5)
+// cm_param_blocks (cm::param_direction per point and requested extended parameter)
+int hh_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu, const double* gradu_prev,
+                    const double* xi_prev, const double* xi, double* dC, double* dS) {
+    auto body = [&]<int D, int Y, int MK>() {
+        constexpr int NX = nx_of<D, MK>(), NU = Dims<D>::NU;
+        for (int64_t pt = 0; pt < B; ++pt) for (int j = 0; j < n_ep; ++j) {
+            double G[NU], xp[NX], x[NX], oC[NX], oS[6];
+            for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt] - (gradu_prev ? gradu_prev[k * B + pt] : 0.0);
+            for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + pt]; x[k] = xi[k * B + pt]; }
+            param_direction<D, Y, MK>(*m, G, x, xp, ep_index[j], oC, oS);
+            for (int k = 0; k < NX; ++k) dC[((int64_t)j * NX + k) * B + pt] = oC[k];
+            for (int k = 0; k < 6; ++k) dS[((int64_t)j * 6 + k) * B + pt] = oS[k];
+        }
+    };
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (Y != CM_YIELD_BARLAT) body.template operator()<D, Y, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
 #if HH_HAS(0)
@@ -494,6 +526,7 @@ void hh_exp_s(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n
 #endif
 #if HH_HAS(0)
 void hh_set_dense(int d) { g_dense = d; }
+void hh_set_passes(int d) { hh_g_passes = d; }
 #endif
 #if HH_HAS(0)
 int hh_sizeof_desc(void) { return (int)sizeof(cm_model_desc); }

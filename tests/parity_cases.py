@@ -760,3 +760,142 @@ def check_history_second_order(engine, desc_info, def_type, yield_kind, kw, rate
     np.testing.assert_allclose(g_dir[sl], g_ref[sl], rtol=1e-8, atol=1e-10 * np.abs(g_ref[sl]).max())
     Hs, Hr = H[sl, sl], H_ref[sl, sl]
     np.testing.assert_allclose(Hs, Hr, rtol=1e-7, atol=1e-9 * np.abs(Hr).max())
+
+
+# ---- extended parameter sensitivities (cm_param_blocks) ------------------------------------------------------------------
+EP_Q0, EP_NN0 = 25, 34
+
+
+def check_param_blocks(param_blocks, def_type, yield_kind, kw, rate=False, uniaxial_idx=1, seed=9):
+    """dC/dp_e and d sigma/dp_e for the leaves the hand-derived kernels have no closed form for -- the 9 entries of the
+    rotation matrix, the Hosford exponent, every native parameter again through the same evaluation -- against the oracle's
+    forward-mode AD of the reference residual (`orc_jacobian(W_PARAMS)`, `orc_dcauchy(W_PARAMS)`; reference
+    cmad/models/model.py:125-153).  `param_blocks(desc, ep_index, gradu, xi_prev, xi, nx, gradu_prev=None)`."""
+    from cmad_amd.models.device import build_desc
+    from test_oracle_vs_torch_ad import _state
+    rng = np.random.default_rng(seed)
+    values = _lame_values(rng, yield_kind, kw)
+    mk = ol.SMALL_RATE_EP if rate else ol.SMALL_EP
+    mat = ol.Material(values, def_type=def_type, model_kind=mk, uniaxial_idx=uniaxial_idx)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1 if rate else 0, uniaxial_stress_idx=uniaxial_idx)
+    nx, nu = mat.nx, mat.nu
+    for plastic in (True, False):
+        if rate:
+            for _ in range(400):
+                xi = np.r_[rng.normal(size=6) * (260.0 if plastic else 60.0), abs(rng.normal()) * 2e-3, 1.0 + 1e-3 * rng.normal(size=nx - 7)]
+                if nx == 12:
+                    xi[9:] = 1e-3 * rng.normal(size=3)
+                xp = xi.copy(); xp[:6] -= rng.normal(size=6) * 20.0; xp[6] *= 0.5
+                U, Up = rng.normal(size=nu) * 2e-3, rng.normal(size=nu) * 1e-3
+                f = mat.yield_state(xi, U)[1]
+                if (f > 1e-6) == plastic and abs(f) > 1e-6:
+                    break
+            else:
+                raise AssertionError("no state on the requested branch")
+        else:
+            for _ in range(50):
+                xi, xp, U = _state(rng, mat, plastic)
+                if (mat.yield_state(xi, U)[1] > 0) == plastic:
+                    break
+            Up = None
+        # EP indices and the oracle columns they correspond to (elastic pair = (lambda, mu): KP == native)
+        ep = list(range(6)) + [EP_Q0 + i for i in range(9)]
+        oc = [ol.P_EL1, ol.P_EL0, ol.P_Y, ol.P_VOCE_S, ol.P_VOCE_D, ol.P_LIN_K] + [ol.P_Q + i for i in range(9)]
+        if yield_kind == "hill":
+            ep += [6 + j for j in range(6)]; oc += [ol.P_YC + j for j in range(6)]
+        if yield_kind == "hosford":
+            ep += [6]; oc += [ol.P_YC]
+        dC, dS = param_blocks(desc, ep, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx,
+                              gradu_prev=None if Up is None else Up.reshape(-1, 1))
+        Jp = mat.jacobian(ol.W_PARAMS, xi, xp, U, Up)[:, oc]                      # (nx, n)
+        Sp = mat.dcauchy(ol.W_PARAMS, xi, xp, U, Up)[_V6_OF_9][:, oc]             # (6, n)
+        np.testing.assert_allclose(dC[:, :, 0].T, Jp, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jp).max()))
+        np.testing.assert_allclose(dS[:, :, 0].T, Sp, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Sp).max()))
+
+
+def check_param_blocks_network(param_blocks, def_type=ol.FULL_3D, scaled=False, seed=3):
+    """Hybrid Hill + network surface: sensitivities w.r.t. the Hill coefficients (oracle AD) and w.r.t. every packed network
+    weight (central differences of the oracle's residual and stress -- the oracle holds the weights outside its
+    differentiable parameter vector) at plastic states."""
+    from cmad_amd.models.device import HybridHillEffectiveStress, ScaledHybridHillEffectiveStress, build_desc
+    icnn, values = al7079_hybrid_setup()
+    hyb = ScaledHybridHillEffectiveStress(icnn, 525.0) if scaled else HybridHillEffectiveStress(icnn)
+    E, nu_ = values["elastic"]["E"], values["elastic"]["nu"]
+    values["elastic"] = {"lambda": E * nu_ / ((1 + nu_) * (1 - 2 * nu_)), "mu": E / (2 * (1 + nu_))}
+    desc, info = build_desc(values, def_type=def_type, hybrid=hyb)
+    packed = np.array(info["nn_packed"])
+    widths = [desc.nn_widths[i] for i in range(desc.nn_nlayers)]
+    H = widths[1]
+    nw = 8 * H + 7                                                                # differentiable weights (scalers follow)
+
+    def material(w):
+        # the device layout appends f(0) to the oracle's packing; the oracle evaluates the network at the origin itself
+        return ol.Material(values, def_type=def_type, nn=(widths, np.ascontiguousarray(w[:-1])),
+                           scaled=(525.0, 10, 1e-14, 1e-14) if scaled else None)
+    mat = material(packed)
+    rng = np.random.default_rng(seed)
+    nx, nu = mat.nx, mat.nu
+    Y = values["plastic"]["flow stress"]["initial yield"]["Y"]
+    mu = values["elastic"]["mu"]
+    for _ in range(200):
+        U = rng.normal(size=nu) * 1.5 * Y / (2 * mu)
+        xp = np.r_[np.zeros(6), 0.0, np.ones(nx - 7)]
+        xi = xp.copy(); xi[:6] = rng.normal(size=6) * 2e-4; xi[6] = abs(rng.normal()) * 2e-4
+        if mat.yield_state(xi, U)[1] > 1e-5:
+            break
+    else:
+        raise AssertionError("no plastic state")
+    ep = [6 + j for j in range(6)] + [EP_NN0 + i for i in range(nw)]
+    desc.nn_weights = info["nn_packed"].ctypes.data                               # host build reads host memory; the GPU wrapper re-places it
+    dC, dS = param_blocks(desc, ep, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx, info=info)
+    oc = [ol.P_YC + j for j in range(6)]
+    Jp = mat.jacobian(ol.W_PARAMS, xi, xp, U)[:, oc]
+    Sp = mat.dcauchy(ol.W_PARAMS, xi, xp, U)[_V6_OF_9][:, oc]
+    np.testing.assert_allclose(dC[:6, :, 0].T, Jp, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Jp).max()))
+    np.testing.assert_allclose(dS[:6, :, 0].T, Sp, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Sp).max()))
+    assert not dS[6:].any()                                                       # the stress does not see the network
+    sel = rng.choice(nw, size=24, replace=False)                                  # a sample of the weights by central differences
+    for i in sel:
+        h = 1e-6 * max(1.0, abs(packed[i]))
+        wp, wm = packed.copy(), packed.copy()
+        wp[i] += h; wm[i] -= h
+        # f(0) of the packed layout follows the weights: the oracle recomputes it from them
+        fd = (material(wp).residual(xi, xp, U) - material(wm).residual(xi, xp, U)) / (2 * h)
+        np.testing.assert_allclose(dC[6 + i, :, 0], fd, rtol=2e-5, atol=1e-9 * max(1.0, np.abs(fd).max()))
+
+
+def check_second_derivs_network(hessians, def_type=ol.FULL_3D, scaled=False, seed=3):
+    """cm_hessians for the hybrid Hill + network surfaces (hyper-dual evaluation of the arithmetic-T model) against the
+    oracle's nested duals: every block of d2C and d2 sigma w.r.t. (xi, xi_prev, native parameters incl. the Hill coefficients)."""
+    from cmad_amd.models.device import HybridHillEffectiveStress, ScaledHybridHillEffectiveStress, build_desc
+    icnn, values = al7079_hybrid_setup()
+    hyb = ScaledHybridHillEffectiveStress(icnn, 525.0) if scaled else HybridHillEffectiveStress(icnn)
+    E, nu_ = values["elastic"]["E"], values["elastic"]["nu"]
+    values["elastic"] = {"lambda": E * nu_ / ((1 + nu_) * (1 - 2 * nu_)), "mu": E / (2 * (1 + nu_))}
+    values["rotation matrix"] = rand_rot(np.random.default_rng(seed))
+    desc, info = build_desc(values, def_type=def_type, hybrid=hyb)
+    widths = [desc.nn_widths[i] for i in range(desc.nn_nlayers)]
+    mat = ol.Material(values, def_type=def_type, nn=(widths, np.ascontiguousarray(info["nn_packed"][:-1])),
+                      scaled=(525.0, 10, 1e-14, 1e-14) if scaled else None)
+    rng = np.random.default_rng(seed)
+    nx, nu = mat.nx, mat.nu
+    Y, mu = values["plastic"]["flow stress"]["initial yield"]["Y"], values["elastic"]["mu"]
+    for _ in range(200):
+        U = rng.normal(size=nu) * 1.5 * Y / (2 * mu)
+        xp = np.r_[np.zeros(6), 0.0, np.ones(nx - 7)]
+        xi = xp.copy(); xi[:6] = rng.normal(size=6) * 2e-4; xi[6] = abs(rng.normal()) * 2e-4
+        if mat.yield_state(xi, U)[1] > 1e-5:
+            break
+    else:
+        raise AssertionError("no plastic state")
+    desc.nn_weights = info["nn_packed"].ctypes.data
+    d2C, d2S, dC, dS = hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx, info=info)
+    oC, oS = mat.second_derivs(xi, xp, U)
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in KP2O]
+    refC = oC[:, qmap][:, :, qmap]
+    refS = oS[_V6_OF_9][:, qmap][:, :, qmap]
+    np.testing.assert_allclose(d2C[0], refC, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(refC).max()))
+    np.testing.assert_allclose(d2S[0], refS, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(refS).max()))
+    for which, lo in ((ol.W_XI, 0), (ol.W_XI_PREV, nx)):
+        Jo = mat.jacobian(which, xi, xp, U)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], Jo, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jo).max()))

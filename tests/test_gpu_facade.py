@@ -14,6 +14,7 @@ import oracle_lib as ol
 from problems import params_J2_voce, plane_stress_F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _models():
@@ -557,9 +558,17 @@ def test_evaluate_hessians_shapes_and_errors():
     from cmad_amd.synthetic import al7079_hybrid_setup
     icnn, values = al7079_hybrid_setup()
     hmodel = SmallElasticPlastic(Parameters(values), DefType.FULL_3D, effective_stress_fun=HybridHillEffectiveStress(icnn))
-    hmodel.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
-    with pytest.raises(NotImplementedError):
-        hmodel.evaluate_hessians()
+    hmodel.gather_global(mp_U_from_F(np.eye(3) + 3.0 * G), mp_U_from_F(np.eye(3)))
+    newton_solve(hmodel, max_iters=50)
+    hmodel.evaluate_hessians()                                                  # network surfaces: arithmetic-T model (cm_hessians)
+    assert hmodel.d2C_dxi2.shape == (7, 7, 7) and np.isfinite(hmodel.d2C_dxi2).all() and np.abs(hmodel.d2C_dxi2).max() > 0
+    from cmad_amd.models.device import BARLAT_NAMES
+    bvals = params_J2_voce().values
+    bvals["plastic"]["effective stress"] = {"barlat": dict(zip(BARLAT_NAMES, [1.0] * 18 + [8.0]))}
+    bmodel = SmallElasticPlastic(Parameters(bvals), DefType.FULL_3D)
+    bmodel.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
+    with pytest.raises(NotImplementedError):                                    # Barlat: hand-derived first and second derivatives only
+        bmodel.evaluate_hessians()
 
 
 def test_jvp_objective_agrees_with_direct_adjoint():
@@ -707,3 +716,89 @@ def test_config0_uniaxial_ramp_on_the_fe_layout(golden_dir):
     np.testing.assert_allclose(d, d.transpose(1, 0, 2, 3), rtol=0, atol=1e-9)
     lam, mu = 200e3 * 0.3 / (1.3 * 0.4), 200e3 / 2.6
     assert 0.0 < d[0, 0, 0, 0] < lam + 2 * mu
+
+
+_RCCL_CHILD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+use_group = sys.argv[2] == "1"
+import torch
+import torch.distributed as dist
+if use_group:                                  # the process group comes up before anything else touches the GPU
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from cmad_amd.models import DefType, SmallElasticPlastic
+from cmad_amd.objectives import BatchedCalibrationObjective
+from cmad_amd.objectives.batched import shard_bounds
+from cmad_amd.synthetic import gauss_point_batch
+from problems import params_J2_voce
+B, K = 20000, 3
+lo, hi = shard_bounds(B, 0, 1)
+g1 = torch.from_numpy(gauss_point_batch(B, seed=5, ndims=2)[:, lo:hi]).cuda()
+ramp = torch.linspace(0.0, 1.5, K + 1, dtype=torch.float64, device="cuda")
+gh = (ramp[:, None, None] * g1[None]).contiguous()
+gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+dh = 50.0 * torch.randn((K + 1, 6, hi - lo), dtype=torch.float64, device="cuda", generator=gen)
+model = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+w = np.zeros((3, 3)); w[0, 0] = w[1, 1] = 1.0
+obj = BatchedCalibrationObjective(model, gh, dh, w)
+x = model.parameters.flat_active_values(True)
+r = obj.evaluate(x)
+if use_group:
+    t = torch.ones(13, dtype=torch.float64, device="cuda")
+    dist.all_reduce(t)                         # the collective itself: 13 doubles through RCCL
+    assert float(t.sum()) == 13.0
+    backend = dist.get_backend()
+    dist.destroy_process_group()
+else:
+    backend = "none"
+print("RESULT " + json.dumps({"J": r.J, "grad": list(map(float, r.grad)), "backend": backend}))
+'''
+
+
+def test_sharded_objective_through_rccl_process_group(tmp_path):
+    """The multi-GPU path's collective on hardware: a fresh child process brings up a 1-rank `nccl` (= RCCL) process group
+    before touching the GPU, evaluates `BatchedCalibrationObjective` on its shard -- the (1 + 12)-vector goes through
+    `dist.all_reduce` -- and must report the same objective and gradient as a child that runs without a group.
+    (The 8-GPU scaling run is the driver's; world size 2 over gloo runs in tests/test_host_logic.py.)"""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_child.py"
+    script.write_text(_RCCL_CHILD)
+    port = str(29600 + (os.getpid() % 1000))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = {}
+    for flag in ("1", "0"):
+        res = subprocess.run([sys.executable, str(script), ROOT, flag, port], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        out[flag] = json.loads(line[len("RESULT "):])
+    assert out["1"]["backend"] == "nccl"
+    assert np.isfinite(out["1"]["J"]) and out["1"]["J"] > 0.0
+    np.testing.assert_allclose(out["1"]["J"], out["0"]["J"], rtol=1e-14)
+    np.testing.assert_allclose(out["1"]["grad"], out["0"]["grad"], rtol=1e-13, atol=0.0)
+
+
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("hosford", True)])
+def test_gradient_of_extended_leaves(yield_kind, active_rotation):
+    """Objective gradients w.r.t. the Hosford exponent and the entries of the rotation matrix -- leaves the reference reaches
+    by jacrev over the params pytree (cmad/models/model.py:125-153) and the kernels by forward-mode evaluation of the whole
+    model (cm_param_blocks, cm_param_adjoint_history): adjoint == direct == central differences of the objective."""
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectObjective
+    from problems import extended_leaf_problem
+    DefType, SmallElasticPlastic = _models()
+    model, qoi, F = extended_leaf_problem(SmallElasticPlastic, yield_kind, active_rotation)
+    x = model.parameters.flat_active_values(True)
+    Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
+    Jd, gd = MPDirectObjective(qoi, F).evaluate(x)
+    assert abs(Ja - Jd) <= 1e-12 * abs(Ja)
+    np.testing.assert_allclose(ga, gd, rtol=1e-8, atol=1e-10 * np.abs(ga).max())
+    g_fd = np.zeros_like(x)
+    for k in range(x.size):
+        h = 1e-6 * max(1.0, abs(x[k]))
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        g_fd[k] = (MPAdjointObjective(qoi, F).evaluate(xp_).J - MPAdjointObjective(qoi, F).evaluate(xm_).J) / (2 * h)
+    np.testing.assert_allclose(ga, g_fd, rtol=2e-5, atol=1e-7 * np.abs(ga).max())

@@ -398,3 +398,30 @@ def test_history_second_order_vs_oracle(def_type, yield_kind, kw, rate):
     pc.check_history_second_order(lambda desc, info: HistoryEngine(DeviceEvaluator(desc, info)),
                                   lambda values, dt, mk: build_desc(values, def_type=dt, model_kind=mk),
                                   def_type, yield_kind, kw, rate=rate)
+
+
+@pytest.mark.parametrize("rate", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_extended_parameter_blocks(def_type, yield_kind, kw, rate):
+    """cm_param_blocks through the C-ABI: sensitivities w.r.t. the rotation matrix, the Hosford exponent and the native
+    parameters by forward-mode evaluation of the whole model, against the oracle's AD (reference model.py:125-153)."""
+    import gpu_api
+    pc.check_param_blocks(gpu_api.param_blocks, def_type, yield_kind, kw, rate=rate)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_extended_parameter_blocks_network(def_type, scaled):
+    """Hill coefficients (oracle AD) and network weights (finite differences of the oracle) of the hybrid surfaces."""
+    import gpu_api
+    pc.check_param_blocks_network(gpu_api.param_blocks, def_type, scaled=scaled)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_second_derivatives_network_surfaces(def_type, scaled):
+    """cm_hessians for the hybrid Hill + network yield surfaces (plain and beta-rescaled) against the oracle's nested duals
+    (reference model.py:133-147 has no restriction on the yield surface)."""
+    import gpu_api
+    pc.check_second_derivs_network(gpu_api.hessians, def_type, scaled=scaled)

@@ -122,3 +122,44 @@ def test_named_derivatives_parallel_their_inputs():
         for k in path:
             leaf = leaf[k]
         np.testing.assert_allclose(leaf, fd, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("hosford", True)])
+def test_gradient_of_extended_leaves(yield_kind, active_rotation):
+    """Objective gradients w.r.t. the Hosford exponent and entries of the rotation matrix (reference: jacrev over the params
+    pytree, cmad/models/model.py:125-153): adjoint == direct, both == central differences of the objective; and the DPARAMS
+    Jacobian block of Model.evaluate() carries the same leaves."""
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectObjective
+    from problems import extended_leaf_problem
+    model, qoi, F = extended_leaf_problem(HostSmallElasticPlastic, yield_kind, active_rotation)
+    x = model.parameters.flat_active_values(True)
+    assert len(model.extended_active()) == (1 if yield_kind == "hosford" else 0) + (9 if active_rotation else 0)
+    Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
+    Jd, gd = MPDirectObjective(qoi, F).evaluate(x)
+    assert abs(Ja - Jd) <= 1e-12 * abs(Ja)
+    np.testing.assert_allclose(ga, gd, rtol=1e-8, atol=1e-10 * np.abs(ga).max())
+    g_fd = np.zeros_like(x)
+    for k in range(x.size):
+        h = 1e-6 * max(1.0, abs(x[k]))
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        g_fd[k] = (MPAdjointObjective(qoi, F).evaluate(xp_).J - MPAdjointObjective(qoi, F).evaluate(xm_).J) / (2 * h)
+    np.testing.assert_allclose(ga, g_fd, rtol=2e-5, atol=1e-7 * np.abs(ga).max())
+    # Model.evaluate() with seed_params: residual Jacobian columns of the same leaves vs central differences
+    from cmad_amd.models import mp_U_from_F
+    model.parameters.set_active_values_from_flat(x)
+    model.set_xi_to_init_vals()
+    model.gather_global(mp_U_from_F(F[:, :, 5]), mp_U_from_F(F[:, :, 4]))
+    model._xi = [np.array([3e-4, 1e-4, 0., -2e-4, 0., -1e-4]), np.array([4e-4]), np.array([0.998])]
+    model.seed_params(); model.evaluate()
+    Jac = model.Jac().copy()
+    for k in range(x.size):
+        h = 1e-6 * max(1.0, abs(x[k]))
+        cols = []
+        for sgn in (1.0, -1.0):
+            xk = x.copy(); xk[k] += sgn * h
+            model.parameters.set_active_values_from_flat(xk)
+            model.seed_none(); model.evaluate()
+            cols.append(np.asarray(model.C()).copy())
+        np.testing.assert_allclose(Jac[:, k], (cols[0] - cols[1]) / (2 * h), rtol=2e-5, atol=1e-9)
+    model.parameters.set_active_values_from_flat(x)

@@ -9,14 +9,16 @@ import parity_cases as pc
 BACKEND = pc.HostBackend()
 
 
-@pytest.fixture(params=["structured", "dense"], autouse=True)
+@pytest.fixture(params=["structured", "dense", "passes"], autouse=True)
 def solver_variant(request):
-    """FULL_3D and PLANE_STRESS run twice: the structured (bordered) block solve the kernels use and the dense
-    LU of the same system."""
+    """FULL_3D and PLANE_STRESS run three times: the structured (bordered) block solve the kernels use, the dense LU of the
+    same system, and the resumable one-evaluation-per-pass form of the iteration (cm_pool.hpp) the work-pool kernels run."""
     import host_harness_lib as hh
     hh.set_dense(request.param == "dense")
+    hh.set_passes(request.param == "passes")
     yield request.param
     hh.set_dense(False)
+    hh.set_passes(False)
 
 
 @pytest.mark.parametrize("ls", [False, True])
@@ -76,7 +78,7 @@ def _host_primal(desc, info, gh, xi0):
 def test_history_objective_grad(def_type, yield_kind, kw, rot, rate, solver_variant):
     """cm::history_point (the body of cm_objective_grad_history): K updates forward with the state carried in
     registers, K adjoint steps backward, both model kinds."""
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("one variant: the history loop is the same code on both solver paths")
     if rate and def_type == ol.UNIAXIAL_STRESS:
         pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
@@ -90,7 +92,7 @@ def test_history_objective_grad(def_type, yield_kind, kw, rot, rate, solver_vari
 def test_direct_sensitivities(def_type, yield_kind, kw, rot, rate, solver_variant):
     """cm::direct_point (the body of cm_direct_step): forward parameter sensitivities propagated over a history."""
     import host_harness_lib as hh
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("one variant: built on the explicit blocks")
     if rate and def_type == ol.UNIAXIAL_STRESS:
         pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
@@ -245,7 +247,7 @@ def test_rate_model_explicit_blocks(def_type, yield_kind, kw, rot, solver_varian
     import host_harness_lib as hh
     from cmad_amd.models.device import build_desc, kp_to_leaf_grad
     from cmad_amd.synthetic import gauss_point_batch
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("always dense")
     rng = np.random.default_rng(3)
     values = ol.j2_voce_values(yield_kind=yield_kind, Q=pc.rand_rot(rng) if rot else None, **kw)
@@ -283,7 +285,7 @@ def test_rate_model_explicit_blocks(def_type, yield_kind, kw, rot, solver_varian
 
 @pytest.mark.parametrize("rot", [False, True])
 def test_j2_radial_line_newton_matches_general_path(rot, solver_variant):
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("specialisation of the structured path")
     pc.check_j2_radial_line(BACKEND, B=2048, rot=rot)
 
@@ -298,7 +300,7 @@ def test_edge_cases():
 def test_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_variant):
     """cm_hessians (hyper-dual evaluation of the residual in the product code, host build) vs the oracle's nested duals."""
     import host_harness_lib as hh
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("not solver dependent")
     pc.check_second_derivs(hh.hessians, hh.evaluate, def_type, yield_kind, kw, plastic)
 
@@ -309,7 +311,7 @@ def test_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_
 def test_rate_form_second_derivatives_vs_oracle(def_type, yield_kind, kw, plastic, solver_variant):
     """cm_hessians_rate (host build) vs the oracle's nested duals, both branches."""
     import host_harness_lib as hh
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("not solver dependent")
     pc.check_rate_second_derivs(hh.hessians, hh.evaluate_rate, def_type, yield_kind, kw, plastic)
 
@@ -320,7 +322,7 @@ def test_rate_form_second_derivatives_vs_oracle(def_type, yield_kind, kw, plasti
 def test_rate_form_uniaxial_by_dual_numbers(yield_kind, kw, idx, plastic, solver_variant):
     """small_rate_elastic_plastic under UNIAXIAL_STRESS (12 local dofs) by dual-number evaluation (host build)."""
     import host_harness_lib as hh
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("not solver dependent")
     pc.check_rate_uniaxial_dual(hh.hessians, yield_kind, kw, idx, plastic)
 
@@ -331,7 +333,7 @@ def test_rate_form_uniaxial_by_dual_numbers(yield_kind, kw, idx, plastic, solver
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_rate_form_tangent(def_type, yield_kind, kw, rot, solver_variant):
     import host_harness_lib as hh
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("rate form always uses the dense path")
     pc.check_rate_tangent(lambda desc, info, g, gp, xp, x: hh.tangent_rate(desc, g, gp, xp, x), def_type, yield_kind, kw, rot, B=192)
 
@@ -341,7 +343,7 @@ def test_rate_form_tangent(def_type, yield_kind, kw, rot, solver_variant):
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_rate_form_vjp(def_type, yield_kind, kw, rot, solver_variant):
     import host_harness_lib as hh
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("rate form always uses the dense path")
     pc.check_rate_vjp(lambda desc, info, g, gp, xp, x, sb: hh.vjp_rate(desc, g, gp, xp, x, sb), def_type, yield_kind, kw, rot, B=192)
 
@@ -402,8 +404,40 @@ def test_history_second_order_vs_oracle(def_type, yield_kind, kw, rate, solver_v
     oracle-assembled gradient, adjoint vectors, forward sensitivities and Hessian."""
     from cmad_amd.models.device import build_desc
     from host_facade import HostHistoryEngine
-    if solver_variant == "dense":
+    if solver_variant != "structured":
         pytest.skip("not solver dependent")
     pc.check_history_second_order(lambda desc, info: HostHistoryEngine(desc=desc, info=info),
                                   lambda values, dt, mk: build_desc(values, def_type=dt, model_kind=mk),
                                   def_type, yield_kind, kw, rate=rate)
+
+
+@pytest.mark.parametrize("rate", [False, True])
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_extended_parameter_blocks(def_type, yield_kind, kw, rate, solver_variant):
+    """cm_param_blocks (host build of cm::param_direction): rotation-matrix entries, Hosford exponent, native parameters by
+    forward-mode evaluation of the whole model against the oracle's AD; the rate form under UNIAXIAL_STRESS included."""
+    import host_harness_lib as hh
+    if solver_variant != "structured":
+        pytest.skip("not solver dependent")
+    pc.check_param_blocks(hh.param_blocks, def_type, yield_kind, kw, rate=rate)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_extended_parameter_blocks_network(def_type, scaled, solver_variant):
+    """Hill coefficients and network weights of the hybrid surfaces (plain and beta-rescaled)."""
+    import host_harness_lib as hh
+    if solver_variant != "structured":
+        pytest.skip("not solver dependent")
+    pc.check_param_blocks_network(hh.param_blocks, def_type, scaled=scaled)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_second_derivatives_network_surfaces(def_type, scaled, solver_variant):
+    """cm_hessians for the hybrid Hill + network yield surfaces (host build) against the oracle's nested duals."""
+    import host_harness_lib as hh
+    if solver_variant != "structured":
+        pytest.skip("not solver dependent")
+    pc.check_second_derivs_network(hh.hessians, def_type, scaled=scaled)
