@@ -79,6 +79,15 @@ CM_D double half_over_mu(const cm_model_desc& m) { return 0.5 / m.mu; }   // one
 constexpr double kIW[6] = {1.0, 0.5, 0.5, 1.0, 0.5, 1.0};   // 1 / w_k
 constexpr double kW[6] = {1.0, 2.0, 2.0, 1.0, 2.0, 1.0};
 constexpr bool kDiag[6] = {true, false, false, true, false, true};
+// Symmetric 6x6 matrices (the yield-surface Hessians) are built as their packed upper triangle, row-major:
+// entry (k, l), any order, sits at sym6(k, l); 21 doubles instead of 36.
+constexpr int sym6(int k, int l) { return (k <= l) ? (k * (11 - k)) / 2 + l : (l * (11 - l)) / 2 + k; }
+CM_D void sym6_expand(const double Hp[21], double Ht[6][6]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int l = 0; l < 6; ++l) Ht[k][l] = Hp[sym6(k, l)];
+}
 
 template <int DEF> struct Dims;
 // NZ: length of the per-kernel frame array `z` (see strain_z)
@@ -242,7 +251,7 @@ CM_D SoftUnit soft_unit(double a) {
     return u;
 }
 template <bool HESS>
-CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6], double& F, double G[6], double Hx[6][6]) {
+CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6], double& F, double G[6], double Hx[21]) {
     const double* W0 = w; const double* b0 = w + 6 * H; const double* Wx1 = b0 + H; const double* b1 = Wx1 + 6;
     const double* Wz = b1 + 1;
     F = 2.0 * b1[0];
@@ -250,9 +259,7 @@ CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6]
     for (int i = 0; i < 6; ++i) G[i] = 0.0;
     if constexpr (HESS) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) Hx[i][j] = 0.0;
+        for (int i = 0; i < 21; ++i) Hx[i] = 0.0;
     }
     for (int o = 0; o < H; ++o) {
         double t = 0.0;
@@ -271,22 +278,17 @@ CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6]
             for (int i = 0; i < 6; ++i) {
                 const double ci = c2 * wc[i];
 #pragma unroll
-                for (int j = i; j < 6; ++j) Hx[i][j] += ci * wc[j];
+                for (int j = i; j < 6; ++j) Hx[sym6(i, j)] += ci * wc[j];
             }
         }
-    }
-    if constexpr (HESS) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < i; ++j) Hx[i][j] = Hx[j][i];
     }
 }
 
 // NN(flat dev s) of hybrid_hill_effective_stress (cmad/models/effective_stress.py:149-163) in the 6-vector
 // basis: value, d/ds6, d2/ds6 ds6.  NN input order is [xx,yy,zz,xy,xz,yz] of the deviator.
+// value, d/ds6 and (HESS) the second derivative ADDED to the packed Hessian Hp
 template <bool HESS>
-CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val, double g6[6], double H6[6][6]) {
+CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val, double g6[6], double Hp[21]) {
     const double* __restrict__ w = m.nn_weights;
     const int H = m.nn_widths[1];
     const double* sc = w + 6 * H + H + 6 + 1 + H;             // in_scale[6], in_min[6], out_scale, out_min, f0
@@ -296,8 +298,8 @@ CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val
     double xs[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) xs[i] = sc[i] * x[i] + sc[6 + i];
-    double F, G[6], Hs[6][6];
-    icnn_symmetric<HESS>(w, H, xs, F, G, Hs);
+    double F, G[6], Hx[HESS ? 21 : 1];
+    icnn_symmetric<HESS>(w, H, xs, F, G, Hx);
     const double ios = 1.0 / sc[12];
     val = (0.5 * F - sc[14] - sc[13]) * ios;                   // (1/2 (f(x)+f(-x)) - f(0) - out_min) / out_scale
     double gx[6];
@@ -309,27 +311,27 @@ CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val
 #pragma unroll
     for (int k = 0; k < 6; ++k) g6[k] = gx[XI[k]] - (kDiag[k] ? gm : 0.0);
     if constexpr (HESS) {
-        double Hx[6][6], rm[6];
+        double rm[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) Hx[i][j] = 0.5 * Hs[i][j] * sc[i] * sc[j] * ios;
+            for (int j = i; j < 6; ++j) Hx[sym6(i, j)] *= 0.5 * sc[i] * sc[j] * ios;
         // J = d x / d s6: H6 = J^T Hx J with J_ik = delta(i, XI[k]) - (i < 3 && diag k) / 3
         double tot = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { rm[i] = (Hx[i][0] + Hx[i][1] + Hx[i][2]) * (1.0 / 3.0); }   // row means over normal cols
+        for (int i = 0; i < 6; ++i) rm[i] = (Hx[sym6(i, 0)] + Hx[sym6(i, 1)] + Hx[sym6(i, 2)]) * (1.0 / 3.0);   // row means over normal cols
 #pragma unroll
         for (int i = 0; i < 3; ++i) tot += rm[i];
         tot *= (1.0 / 3.0);
 #pragma unroll
         for (int k = 0; k < 6; ++k)
 #pragma unroll
-            for (int l = 0; l < 6; ++l) {
-                double v = Hx[XI[k]][XI[l]];
+            for (int l = k; l < 6; ++l) {
+                double v = Hx[sym6(XI[k], XI[l])];
                 if (kDiag[l]) v -= rm[XI[k]];
                 if (kDiag[k]) v -= rm[XI[l]];
                 if (kDiag[k] && kDiag[l]) v += tot;
-                H6[k][l] = v;
+                Hp[sym6(k, l)] += v;
             }
     }
 }
@@ -393,7 +395,7 @@ CM_D void barlat_pull(const double UL[3][3], double c44, double c55, double c66,
 }
 
 template <bool HESS>
-CM_D void barlat_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
+CM_D void barlat_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Hp[21]) {
     const double a = m.yc[18];
     double lam[2][3], V[2][3][3], UL[2][3][3], csh[2][3];
 #pragma unroll
@@ -469,7 +471,7 @@ CM_D void barlat_eval(const cm_model_desc& m, const double s[6], double& phi, do
 #pragma unroll
         for (int k = 0; k < 6; ++k)
 #pragma unroll
-            for (int l = 0; l < 6; ++l) Ht[k][l] = -am1 * gt[k] * gt[l];
+            for (int l = k; l < 6; ++l) Hp[sym6(k, l)] = -am1 * gt[k] * gt[l];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -481,7 +483,7 @@ CM_D void barlat_eval(const cm_model_desc& m, const double s[6], double& phi, do
 #pragma unroll
                 for (int k = 0; k < 6; ++k)
 #pragma unroll
-                    for (int l = 0; l < 6; ++l) Ht[k][l] += cf * dv[k] * dv[l];
+                    for (int l = k; l < 6; ++l) Hp[sym6(k, l)] += cf * dv[k] * dv[l];
             }
         // eigenvector rotation terms: 2 theta_ij b_ij b_ij^T, theta_ij = (phi_i - phi_j) / (l_i - l_j)
 #pragma unroll
@@ -508,14 +510,14 @@ CM_D void barlat_eval(const cm_model_desc& m, const double s[6], double& phi, do
 #pragma unroll
                     for (int k = 0; k < 6; ++k)
 #pragma unroll
-                        for (int l = 0; l < 6; ++l) Ht[k][l] += 2.0 * theta * b[k] * b[l];
+                        for (int l = k; l < 6; ++l) Hp[sym6(k, l)] += 2.0 * theta * b[k] * b[l];
                 }
         }
     }
 }
 
 template <int YK, bool HESS>
-CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]);
+CM_D void yield_eval_p(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Hp[21]);
 
 // scaled_effective_stress around the hybrid surface (cmad/models/effective_stress.py:97-108, 130-146):
 //   phi(s) = phi_h(beta s) / beta,  beta: phi_h(beta s) = Yeq  (scalar make_newton_solve started at Y / phi_J2(s),
@@ -525,11 +527,11 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 //   grad phi  = phi_h g / c
 //   hess phi  = beta M (I - tau g^T / c),   M = g g^T / c + phi_h H / c - phi_h g (H tau + g)^T / c^2
 template <bool HESS>
-CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
+CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Hp[21]) {
     double pj;
     {
         double gj[6];
-        yield_eval<CM_YIELD_J2, false>(m, s, pj, gj, Ht);
+        yield_eval_p<CM_YIELD_J2, false>(m, s, pj, gj, Hp);
     }
     if (!(fabs(pj) > 1e-14)) {                                  // jnp.isclose(phi_J2, 0., tol, tol): J2 value, normal := 0
         phi = pj;
@@ -537,9 +539,7 @@ CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& 
         for (int k = 0; k < 6; ++k) gt[k] = 0.0;
         if constexpr (HESS) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-#pragma unroll
-                for (int l = 0; l < 6; ++l) Ht[k][l] = 0.0;
+            for (int k = 0; k < 21; ++k) Hp[k] = 0.0;
         }
         return;
     }
@@ -549,7 +549,7 @@ CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& 
         double t[6], ph, g[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) t[k] = b * s[k];
-        yield_eval<CM_YIELD_HYBRID_HILL_NN, false>(m, t, ph, g, Ht);
+        yield_eval_p<CM_YIELD_HYBRID_HILL_NN, false>(m, t, ph, g, Hp);
         double gs = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) gs += g[k] * s[k];
@@ -589,10 +589,10 @@ CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& 
             }
         }
     }
-    double tau[6], ph, g[6], H[6][6];
+    double tau[6], ph, g[6], H[HESS ? 21 : 1];
 #pragma unroll
     for (int k = 0; k < 6; ++k) tau[k] = beta * s[k];
-    yield_eval<CM_YIELD_HYBRID_HILL_NN, HESS>(m, tau, ph, g, H);
+    yield_eval_p<CM_YIELD_HYBRID_HILL_NN, HESS>(m, tau, ph, g, H);
     double c = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) c += g[k] * tau[k];
@@ -606,42 +606,37 @@ CM_D void scaled_hybrid_eval(const cm_model_desc& m, const double s[6], double& 
         for (int k = 0; k < 6; ++k) {
             double a = 0.0;
 #pragma unroll
-            for (int l = 0; l < 6; ++l) a += H[k][l] * tau[l];
+            for (int l = 0; l < 6; ++l) a += H[sym6(k, l)] * tau[l];
             Ht_au[k] = a; tHt += tau[k] * a;
         }
         // M tau = g + phi_h H tau / c - phi_h g (tau . H tau + c) / c^2
         double Mt[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) Mt[k] = g[k] + ph * ic * Ht_au[k] - ph * g[k] * (tHt + c) * ic * ic;
+        // the Hessian is symmetric: the upper triangle of beta (M - M tau g^T / c) is all of it
 #pragma unroll
         for (int k = 0; k < 6; ++k)
 #pragma unroll
-            for (int l = 0; l < 6; ++l) {
-                const double Mkl = g[k] * g[l] * ic + ph * ic * H[k][l] - ph * g[k] * (Ht_au[l] + g[l]) * ic * ic;
-                Ht[k][l] = beta * (Mkl - Mt[k] * g[l] * ic);
+            for (int l = k; l < 6; ++l) {
+                const double Mkl = g[k] * g[l] * ic + ph * ic * H[sym6(k, l)] - ph * g[k] * (Ht_au[l] + g[l]) * ic * ic;
+                Hp[sym6(k, l)] = beta * (Mkl - Mt[k] * g[l] * ic);
             }
     }
 }
 
 template <int YK, bool HESS>
-CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
+CM_D void yield_eval_p(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Hp[21]) {
     if constexpr (YK == CM_YIELD_BARLAT) {
-        barlat_eval<HESS>(m, s, phi, gt, Ht);
+        barlat_eval<HESS>(m, s, phi, gt, Hp);
     } else if constexpr (YK == CM_YIELD_SCALED_HYBRID_HILL_NN) {
-        scaled_hybrid_eval<HESS>(m, s, phi, gt, Ht);
+        scaled_hybrid_eval<HESS>(m, s, phi, gt, Hp);
     } else if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
-        yield_eval<CM_YIELD_HILL, HESS>(m, s, phi, gt, Ht);
-        double v, g6[6], H6[6][6];
-        icnn_yield_term<HESS>(m, s, v, g6, H6);
+        yield_eval_p<CM_YIELD_HILL, HESS>(m, s, phi, gt, Hp);
+        double v, g6[6];
+        icnn_yield_term<HESS>(m, s, v, g6, Hp);               // adds its second derivative to Hp
         phi += v;
 #pragma unroll
         for (int k = 0; k < 6; ++k) gt[k] += g6[k];
-        if constexpr (HESS) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-#pragma unroll
-                for (int l = 0; l < 6; ++l) Ht[k][l] += H6[k][l];
-        }
     } else if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
         const QuadForm q = quad_form<YK>(m);
         double As[6];
@@ -662,12 +657,10 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 #pragma unroll
             for (int k = 0; k < 6; ++k)
 #pragma unroll
-                for (int l = 0; l < 6; ++l) Ht[k][l] = -gt[k] * gt[l] * ip;
-            Ht[0][0] += q.a00 * ip; Ht[3][3] += q.a33 * ip; Ht[5][5] += q.a55 * ip;
-            Ht[0][3] += q.a03 * ip; Ht[3][0] += q.a03 * ip;
-            Ht[0][5] += q.a05 * ip; Ht[5][0] += q.a05 * ip;
-            Ht[3][5] += q.a35 * ip; Ht[5][3] += q.a35 * ip;
-            Ht[1][1] += q.a11 * ip; Ht[2][2] += q.a22 * ip; Ht[4][4] += q.a44 * ip;
+                for (int l = k; l < 6; ++l) Hp[sym6(k, l)] = -gt[k] * gt[l] * ip;
+            Hp[sym6(0, 0)] += q.a00 * ip; Hp[sym6(3, 3)] += q.a33 * ip; Hp[sym6(5, 5)] += q.a55 * ip;
+            Hp[sym6(0, 3)] += q.a03 * ip; Hp[sym6(0, 5)] += q.a05 * ip; Hp[sym6(3, 5)] += q.a35 * ip;
+            Hp[sym6(1, 1)] += q.a11 * ip; Hp[sym6(2, 2)] += q.a22 * ip; Hp[sym6(4, 4)] += q.a44 * ip;
         }
     } else if constexpr (YK == CM_YIELD_HOSFORD) {
         // cmad/models/effective_stress.py:167-177: phi = vm (1/2 sum |d_i/vm|^a)^(1/a) with
@@ -725,9 +718,7 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
         gt[0] = p[0] - p[2]; gt[3] = p[1] - p[0]; gt[5] = p[2] - p[1];
         if constexpr (HESS) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-#pragma unroll
-                for (int l = 0; l < 6; ++l) Ht[k][l] = 0.0;
+            for (int k = 0; k < 21; ++k) Hp[k] = 0.0;
             double Hd[3][3];
             const double ip = (phi > 0.0) ? rcp(phi) : 0.0;
 #pragma unroll
@@ -741,16 +732,24 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 #pragma unroll
             for (int A = 0; A < 3; ++A)
 #pragma unroll
-                for (int Bc = 0; Bc < 3; ++Bc) {
+                for (int Bc = A; Bc < 3; ++Bc) {
                     double sH = 0.0;
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 3; ++j) sH += D[i][A] * Hd[i][j] * D[j][Bc];
-                    Ht[IDX[A]][IDX[Bc]] = sH;
+                    Hp[sym6(IDX[A], IDX[Bc])] = sH;
                 }
         }
     }
+}
+
+// the same with the Hessian as a full 6x6 array (dense Jacobian assembly: UNIAXIAL_STRESS, the rate form)
+template <int YK, bool HESS>
+CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, double gt[6], double Ht[6][6]) {
+    double Hp[HESS ? 21 : 1];
+    yield_eval_p<YK, HESS>(m, s, phi, gt, Hp);
+    if constexpr (HESS) sym6_expand(Hp, Ht);
 }
 
 // ---- hardening  cmad/models/hardening.py:9-34 --------------------------------------------------

@@ -404,12 +404,12 @@ constexpr int nx_of() { return (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM
 // on-axis entry dU from the caller, the off-axis normal entries from the stretch unknowns x[7:9] - xp[7:9] and the
 // shear entries x[9:12] themselves; every off-axis entry of the global stress increment must vanish.
 template <int YK, class T>
-CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, double dU,
+CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, const T& dU,
                                    const T* x, const T* xp, T* C, T s[6]) {
     const int on = m.uniaxial_idx, ia = (on == 0) ? 1 : 0, ib = (on == 2) ? 1 : 2;
     T eg[3][3];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) eg[i][j] = T{0.0};
-    eg[on][on] = T{dU};
+    eg[on][on] = dU;
     eg[ia][ia] = x[7] - xp[7];
     eg[ib][ib] = x[8] - xp[8];
     eg[0][1] = eg[1][0] = x[9]; eg[0][2] = eg[2][0] = x[10]; eg[1][2] = eg[2][1] = x[11];
@@ -493,7 +493,7 @@ template <int DEF, int YK, int MK, class T>
 CM_D void model_eval_T(const cm_model_desc& m, const MatT<T>& p, const double* G, const T* x, const T* xp, T* C, T sg[6]) {
     T s[6];
     if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS) {
-        residual_rate_uniaxial_T<YK, T>(m, p, G[0], x, xp, C, s);
+        residual_rate_uniaxial_T<YK, T>(m, p, t_const<T>(G[0]), x, xp, C, s);
     } else {
         T eg[6], z[Dims<DEF>::NZ];
         kinematics_T<DEF, T>(m, p, G, eg, z);

@@ -25,6 +25,7 @@
 // same factors.
 #pragma once
 #include "cm_device.hpp"
+#include "cm_rate_uniaxial.hpp"
 
 namespace cm {
 
@@ -38,8 +39,7 @@ struct YieldS {
     double gt[6];
     double Sst[QUAD ? 1 : (DENSE ? 21 : 6)];   // Hosford: S00,S03,S05,S33,S35,S55; dense surfaces: upper triangle of Ht, row-major
 };
-// position of Ht[k][l] (any order of k, l) in the packed upper triangle
-CM_D constexpr int sym6(int k, int l) { return (k <= l) ? (k * (11 - k)) / 2 + l : (l * (11 - l)) / 2 + k; }
+
 
 // S (3x3 on slots 0,3,5: S00,S03,S05,S33,S35,S55) and t (shear slots 1,2,4)
 template <int YK>
@@ -76,19 +76,14 @@ CM_D void yield_eval_s(const cm_model_desc& m, const double s[6], YieldS<YK>& y)
         for (int k = 0; k < 6; ++k) y.gt[k] = As[k] * ip;
         y.rho = ip;
     } else if constexpr (YieldS<YK>::DENSE) {
-        double Ht[6][6];
-        yield_eval<YK, true>(m, s, y.phi, y.gt, Ht);
+        yield_eval_p<YK, true>(m, s, y.phi, y.gt, y.Sst);      // built packed, kept packed
         y.rho = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int l = k; l < 6; ++l) y.Sst[sym6(k, l)] = Ht[k][l];
     } else {
-        double Ht[6][6];
-        yield_eval<YK, true>(m, s, y.phi, y.gt, Ht);          // Hosford: Ht lives on the normal block only
+        double Hp[21];
+        yield_eval_p<YK, true>(m, s, y.phi, y.gt, Hp);         // Hosford: the Hessian lives on the normal block only
         y.rho = 0.0;
-        y.Sst[0] = Ht[0][0]; y.Sst[1] = Ht[0][3]; y.Sst[2] = Ht[0][5];
-        y.Sst[3] = Ht[3][3]; y.Sst[4] = Ht[3][5]; y.Sst[5] = Ht[5][5];
+        y.Sst[0] = Hp[sym6(0, 0)]; y.Sst[1] = Hp[sym6(0, 3)]; y.Sst[2] = Hp[sym6(0, 5)];
+        y.Sst[3] = Hp[sym6(3, 3)]; y.Sst[4] = Hp[sym6(3, 5)]; y.Sst[5] = Hp[sym6(5, 5)];
     }
 }
 
@@ -737,7 +732,8 @@ CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z
 template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false, class IO>
 CM_D void primal_history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* xi0, double* xi_hist,
                                double* sigma_hist, uint32_t* status_hist, bool valid, LaneStage stage, const IO& io) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU;
+    constexpr bool RU = (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS);
     double x[NX], xp[NX], z[Dims<DEF>::NZ];
     strain_z<DEF, ROT>(m, z);
     io.template load<NX>(xi0, 0, x);
@@ -746,7 +742,13 @@ CM_D void primal_history_point(const cm_model_desc& m, int K, const double* grad
         io.template load<NU>(gradu_hist, (int64_t)k * NU, G);
         uint32_t st = CM_STATUS_CONVERGED;
         if (k > 0) {
-            if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) {
+            if constexpr (RU) {
+                double Gp[NU];
+                io.template load<NU>(gradu_hist, (int64_t)(k - 1) * NU, Gp);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xp[i] = x[i];
+                st = ru_newton<YK, LS>(m, G[0] - Gp[0], xp, x, valid);
+            } else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) {
                 double Gp[NU], dG[NU], deg[6];
                 io.template load<NU>(gradu_hist, (int64_t)(k - 1) * NU, Gp);
 #pragma unroll
@@ -802,11 +804,13 @@ template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false, class IO>
 CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* data_hist, const double wsq[6],
                         const double* xi0, double* xi_hist, bool valid, LaneStage stage, const IO& io, double* red,
                         HistoryCotangents hc = HistoryCotangents{nullptr, nullptr, nullptr}) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU;
+    constexpr bool RU = (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS);
     double x[NX], xp[NX], z[Dims<DEF>::NZ];
     strain_z<DEF, ROT>(m, z);
     io.template load<NX>(xi0, 0, x);
     if (valid) io.template store<NX>(xi_hist, 0, x);
+    // eg: the material strain (increment); under RU only eg[0] is used and holds the scalar increment of grad u
     auto strain_at = [&](int k, double eg[6]) {
         double G[NU];
         io.template load<NU>(gradu_hist, (int64_t)k * NU, G);
@@ -816,14 +820,16 @@ CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist,
 #pragma unroll
             for (int i = 0; i < NU; ++i) G[i] -= Gp[i];
         }
-        strain_from_gradu<DEF, ROT>(m, G, eg);
+        if constexpr (RU) eg[0] = G[0];
+        else strain_from_gradu<DEF, ROT>(m, G, eg);
     };
     for (int k = 1; k <= K; ++k) {
         double eg[6];
         strain_at(k, eg);
 #pragma unroll
         for (int i = 0; i < NX; ++i) xp[i] = x[i];
-        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) newton<DEF, YK, MK, LS>(m, eg, z, xp, x, valid);
+        if constexpr (RU) ru_newton<YK, LS>(m, eg[0], xp, x, valid);
+        else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) newton<DEF, YK, MK, LS>(m, eg, z, xp, x, valid);
         else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, stage);
         if (valid) io.template store<NX>(xi_hist, (int64_t)k * NX, x);
     }
@@ -860,7 +866,8 @@ CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist,
             for (int i = 0; i < NX; ++i) xin[i] += xb[i];
         }
         cotangent_to_material<ROT>(m, sb, sbm);
-        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) reverse_point_rate<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
+        if constexpr (RU) ru_reverse<YK>(m, eg[0], x, xp, sb, xin, pbar, xpbar, nullptr, lam);
+        else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) reverse_point_rate<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
         else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
         if (hc.lam_hist && valid) io.template store<NX>(hc.lam_hist, (int64_t)k * NX, lam);
         red[0] += J;
@@ -880,7 +887,8 @@ template <int DEF, int YK, bool ROT, int MK, class IO>
 CM_D void direct_history_point(const cm_model_desc& m, int K, const double* gradu_hist, const double* xi_hist,
                                const double* sbar_hist, const double* xibar_hist, double* dx_dp_hist, double* ds_dp_hist,
                                const IO& io, double* g) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    constexpr bool RU = (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS);
     double G[NU], Gp[NU], xp[NX], x[NX], din[NX * NP_], dout[NX * NP_], dsig[6 * NP_];
     for (int j = 0; j < NP_; ++j) g[j] = 0.0;
     for (int i = 0; i < NX * NP_; ++i) din[i] = 0.0;
@@ -890,7 +898,8 @@ CM_D void direct_history_point(const cm_model_desc& m, int K, const double* grad
         // both configurations and both states are read per step (nothing but the sensitivity block is carried)
         for (int k = 0; k < NU; ++k) { G[k] = io.get(gradu_hist, (int64_t)step * NU + k); Gp[k] = io.get(gradu_hist, (int64_t)(step - 1) * NU + k); }
         for (int k = 0; k < NX; ++k) { x[k] = io.get(xi_hist, (int64_t)step * NX + k); xp[k] = io.get(xi_hist, (int64_t)(step - 1) * NX + k); }
-        direct_point<MK, DEF, YK, ROT>(m, G, Gp, x, xp, step > 1 ? din : nullptr, dout, dsig);
+        if constexpr (RU) ru_direct<YK>(m, G[0] - Gp[0], x, xp, step > 1 ? din : nullptr, dout, dsig);
+        else direct_point<MK, DEF, YK, ROT>(m, G, Gp, x, xp, step > 1 ? din : nullptr, dout, dsig);
         if (dx_dp_hist) for (int i = 0; i < NX * NP_; ++i) io.put(dx_dp_hist, (int64_t)step * NX * NP_ + i, dout[i]);
         if (ds_dp_hist) for (int i = 0; i < 6 * NP_; ++i) io.put(ds_dp_hist, (int64_t)step * 6 * NP_ + i, dsig[i]);
         if (sbar_hist) {

@@ -48,6 +48,10 @@ using namespace cm;
 #ifndef CM_NONTEMPORAL
 #define CM_NONTEMPORAL 1
 #endif
+// workgroups of look-ahead of the input-row prefetch in the fused kernels (0 = off); experiment knob, see k_reverse
+#ifndef CM_PREFETCH_DIST
+#define CM_PREFETCH_DIST 0
+#endif
 typedef const __attribute__((address_space(1))) char* cm_gcptr;
 typedef __attribute__((address_space(1))) char* cm_gptr;
 template <int N, bool NT = (CM_NONTEMPORAL != 0)>
@@ -181,18 +185,24 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>()))
 // finished theirs (or nothing is left to hand out), those lanes store their results and take the next consecutive points
 // of the wavefront's chunk, so a refill reads and writes contiguous runs of every SoA row.  Used for the iteration-bound
 // configurations (everything but J2 / FULL_3D): a lockstep wavefront runs max(iterations) over its 64 points there.
+#ifndef CM_POOL_WAVES_HOSFORD
+#define CM_POOL_WAVES_HOSFORD 1
+#endif
+#ifndef CM_POOL_WAVES_NN
+#define CM_POOL_WAVES_NN 2
+#endif
 #ifndef CM_POOL_REFILL
 #define CM_POOL_REFILL 16
 #endif
 constexpr int kPoolRefill = CM_POOL_REFILL;
 
 template <int DEF, int YK>
-constexpr int min_waves_pool() { return is_dense_yield(YK) ? 2 : 1; }
+constexpr int min_waves_pool() { return is_dense_yield(YK) ? CM_POOL_WAVES_NN : CM_POOL_WAVES_HOSFORD; }
 // Where the pool pays (measured, profiles/r02_pool_ab.txt): a pass must cost much more than the retire / refill bookkeeping and
-// the per-lane addressing -- the dense surfaces (network, Barlat: 1.6-1.8x) and Hosford under the line search (a = 100 with
-// the notch deck's settings: 2.1x).  J2 / Hill on the structured solve lose 10-30 % and stay in lockstep.
+// the per-lane addressing -- the network surfaces (1.3x on top of the structured 6x6 solve) and Hosford under the line search
+// (a = 100 with the notch deck's settings: 2.2x).  J2 / Hill lose 5-30 %, Barlat (spills in the pool kernel) 10 %: lockstep.
 template <int YK, bool LS>
-constexpr bool pool_pays() { return is_dense_yield(YK) || (YK == CM_YIELD_HOSFORD && LS); }
+constexpr bool pool_pays() { return is_nn_yield(YK) || (YK == CM_YIELD_HOSFORD && LS); }
 
 template <int DEF, int YK, bool ROT, bool LS>
 __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int kPoolChunk,
@@ -278,7 +288,8 @@ template <int DEF, int YK, bool ROT, bool LS, bool TANGENT = false>
 __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
+    constexpr bool RU = (DEF == CM_UNIAXIAL_STRESS);             // 12 local dofs, derivative blocks by forward-mode evaluation
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
     const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
@@ -292,9 +303,13 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
     load_soa<NX>(xi_prev, B, b, xp);
 #pragma unroll
     for (int k = 0; k < NU; ++k) G[k] -= Gp[k];                  // eps - eps_prev is linear in grad u
-    strain_from_gradu<DEF, ROT>(m, G, deg);
-    strain_z<DEF, ROT>(m, z);
-    uint32_t st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
+    uint32_t st;
+    if constexpr (RU) st = ru_newton<YK, LS>(m, G[0], xp, x, valid);
+    else {
+        strain_from_gradu<DEF, ROT>(m, G, deg);
+        strain_z<DEF, ROT>(m, z);
+        st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
+    }
     double sg[6];
     to_global<ROT>(m, x, sg);                                    // small_rate_elastic_plastic.py:351-359
     if (status) {
@@ -310,8 +325,18 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
     }
     if constexpr (TANGENT) {
         // d sig_g / d G_c = Rg T Rm dE/dG_c (and minus that w.r.t. grad u_prev): the same chain as k_update
+        if constexpr (RU) {
+            double ds[6];
+            const bool okr = ru_tangent<YK>(m, G[0], x, xp, ds);
+            if (!okr && valid && status) status[b] = st | CM_STATUS_SINGULAR;
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) (dsig + (int64_t)r * B)[b] = ds[r];
+            }
+            return;
+        }
         double T[6][6];
-        const bool ok = tangent_point_rate<DEF, YK>(m, deg, z, x, xp, T);
+        const bool ok = tangent_point_rate<RU ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, T);
         if (!ok && valid && status) status[b] = st | CM_STATUS_SINGULAR;
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
@@ -464,6 +489,29 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
     if constexpr (MODE == 0 || MODE == 2) load_soa<6>(sbar_or_data, B, b, sd);
+#if CM_PREFETCH_DIST > 0
+    unsigned touched[2] = {0u, 0u};                              // landing registers of the prefetch loads: reserved until the wait below
+    if constexpr (MODE == 1 || MODE == 3) {
+        // Touch the input rows of the workgroup CM_PREFETCH_DIST ahead (one dword per 128-byte line: this wavefront's 64 points
+        // are 4 lines of each of the NU + NX + 6 rows), so that they sit in L2 / the memory-side cache when that workgroup
+        // starts: its first loads then return at cache latency and the solve overlaps other workgroups' HBM reads.
+        const int64_t ahead = (int64_t)CM_PREFETCH_DIST * kBlock;
+        if (blk0 + ahead + kBlock <= B) {
+            const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+            constexpr int NROWS = NU + NX + 6;
+#pragma unroll
+            for (int r0 = 0; r0 < NROWS; r0 += 16) {
+                const int r = r0 + (int)(lane >> 2);
+                if (r < NROWS) {
+                    const double* row = (r < NU) ? gradu + (int64_t)r * B
+                                                 : ((r < NU + NX) ? xi_prev + (int64_t)(r - NU) * B : sbar_or_data + (int64_t)(r - NU - NX) * B);
+                    const double* pa = row + ahead + wv * 64 + (lane & 3u) * 16;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(touched[r0 / 16]) : "v"(pa) : "memory");
+                }
+            }
+        }
+    }
+#endif
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
     // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
@@ -479,6 +527,9 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
+#if CM_PREFETCH_DIST > 0
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched[0]), "+v"(touched[1]) : : "memory");   // the prefetch loads have landed
+#endif
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
@@ -565,7 +616,8 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
         const double* __restrict__ xi_in, const double* __restrict__ sbar_or_data, Wsq wsq,
         const double* hist_in /* may alias xpbar_out */, double* __restrict__ xi_out, double* __restrict__ sigma_out,
         double* xpbar_out, double* __restrict__ gbar_out, double* __restrict__ partials) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
+    constexpr bool RU = (DEF == CM_UNIAXIAL_STRESS);
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
     const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
@@ -583,10 +635,13 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
     load_soa<NX>(xi_prev, B, b, xp);
 #pragma unroll
     for (int k = 0; k < NU; ++k) G[k] -= Gp[k];
-    strain_from_gradu<DEF, ROT>(m, G, deg);
-    strain_z<DEF, ROT>(m, z);
+    if constexpr (!RU) {
+        strain_from_gradu<DEF, ROT>(m, G, deg);
+        strain_z<DEF, ROT>(m, z);
+    }
     if constexpr (MODE == 1 || MODE == 3) {
-        newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
+        if constexpr (RU) ru_newton<YK, LS>(m, G[0], xp, x, valid);
+        else newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
     } else {
         load_soa<NX>(xi_in, B, b, x);
@@ -624,8 +679,14 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
         }
     }
     constexpr bool BARS = (MODE == 0 || MODE == 2);
-    reverse_point_rate<DEF, YK>(m, deg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
-                                BARS ? degbar : nullptr);
+    if constexpr (RU) {
+        double ubar = 0.0;
+        ru_reverse<YK>(m, G[0], x, xp, sb, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr, BARS ? &ubar : nullptr);
+        degbar[0] = ubar;                                        // the one grad-u entry: its cotangent, stored below
+    } else {
+        reverse_point_rate<RU ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
+                                                     BARS ? degbar : nullptr);
+    }
     if (BARS && xpbar_out && valid) {
         if constexpr (MODE == 2) {
 #pragma unroll
@@ -634,13 +695,17 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
         store_soa<NX>(xpbar_out, B, b, xpbar);
     }
     if (BARS && gbar_out) {
+        if constexpr (RU) {
+            if (valid) gbar_out[b] = degbar[0];
+        } else {
 #pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            double Gd[NU], dm[6];
+            for (int c = 0; c < NU; ++c) {
+                double Gd[NU], dm[6];
 #pragma unroll
-            for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
-            strain_from_gradu<DEF, ROT>(m, Gd, dm);
-            if (valid) (gbar_out + (int64_t)c * B)[b] = dot<6>(degbar, dm);
+                for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+                strain_from_gradu<DEF, ROT>(m, Gd, dm);
+                if (valid) (gbar_out + (int64_t)c * B)[b] = dot<6>(degbar, dm);
+            }
         }
     }
     if (!valid) {
@@ -737,12 +802,16 @@ __global__ __launch_bounds__(64) void k_evaluate_rate(cm_model_desc m, int64_t B
         const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
         const double* __restrict__ xi, double* __restrict__ C_out, double* __restrict__ J_out,
         double* __restrict__ s_out, double* __restrict__ S_out) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     double G[NU], Gp[NU], xp[NX], x[NX], C[NX], sg[6], J[NX * CM_NUM_PARAMS], S[6 * CM_NUM_PARAMS];
     for (int k = 0; k < NU; ++k) { G[k] = gradu[(int64_t)k * B + b]; Gp[k] = gradu_prev[(int64_t)k * B + b]; }
     for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + b]; x[k] = xi[(int64_t)k * B + b]; }
+    if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+        ru_eval<YK>(m, G[0] - Gp[0], x, xp, C, sg);
+        if (which != CM_W_NONE) ru_block<YK>(m, G[0] - Gp[0], x, xp, which, J_out ? J : nullptr, S_out ? S : nullptr);
+    } else
     evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, which, C, J_out ? J : nullptr, sg, S_out ? S : nullptr);
     const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
     if (C_out) for (int k = 0; k < NX; ++k) C_out[(int64_t)k * B + b] = C[k];
@@ -758,13 +827,16 @@ template <int DEF, int YK, bool ROT, int MK>
 __global__ __launch_bounds__(64) void k_direct_step(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
         const double* __restrict__ xi, const double* __restrict__ dxp_dp, double* __restrict__ dx_dp, double* __restrict__ ds_dp) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     double G[NU], Gp[NU], xp[NX], x[NX], din[NX * NP_], dout[NX * NP_], dsig[6 * NP_];
     for (int k = 0; k < NU; ++k) { G[k] = gradu[(int64_t)k * B + b]; Gp[k] = gradu_prev ? gradu_prev[(int64_t)k * B + b] : 0.0; }
     for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + b]; x[k] = xi[(int64_t)k * B + b]; }
     if (dxp_dp) for (int i = 0; i < NX * NP_; ++i) din[i] = dxp_dp[(int64_t)i * B + b];
+    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS)
+        ru_direct<YK>(m, G[0] - Gp[0], x, xp, dxp_dp ? din : nullptr, dout, ds_dp ? dsig : nullptr);
+    else
     direct_point<MK, DEF, YK, ROT>(m, G, Gp, x, xp, dxp_dp ? din : nullptr, dout, ds_dp ? dsig : nullptr);
     for (int i = 0; i < NX * NP_; ++i) dx_dp[(int64_t)i * B + b] = dout[i];
     if (ds_dp) for (int i = 0; i < 6 * NP_; ++i) ds_dp[(int64_t)i * B + b] = dsig[i];
@@ -981,13 +1053,24 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
 // calls F.template operator()<DEF, YK, ROT>() for the runtime (def_type, yield_kind, rotation) triple
 // returns false when no specialisation exists (the caller reports CM_ERR_UNSUPPORTED -- never a silent no-op)
 // UNIAXIAL_STRESS is built for the total-form entries and cm_hessians_rate (`UNI` = the caller has those specialisations)
-template <bool UNI = false, class F>
+// ROTP: which (def_type, yield) pairs get a Q = I specialisation at all.  0: all of them; 1: the memory- and issue-bound ones
+// only (J2 / Hill / Hosford under FULL_3D / PLANE_STRESS) -- the dense surfaces and UNIAXIAL_STRESS always run the rotation
+// products; 2: none (the rate form, whose dense LU dwarfs them).  With Q = I the rotation products reproduce the plain
+// result exactly (products with 1, sums with 0), so this only trades a few instructions for a smaller library.
+template <int ROTP, int D, int Y>
+constexpr bool always_rotates() { return ROTP == 2 || (ROTP == 1 && (is_dense_yield(Y) || D == CM_UNIAXIAL_STRESS)); }
+
+template <bool UNI = false, int ROTP = 0, class F>
 inline bool dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity, ls = m->ls_max_evals > 0;
 #define CM_CASE(D, Y) \
     if (m->def_type == D && m->yield_kind == Y) { \
-        if (rot) { if (ls) f.template operator()<D, Y, true, true>(); else f.template operator()<D, Y, true, false>(); } \
-        else { if (ls) f.template operator()<D, Y, false, true>(); else f.template operator()<D, Y, false, false>(); } \
+        if constexpr (always_rotates<ROTP, D, Y>()) { \
+            if (ls) f.template operator()<D, Y, true, true>(); else f.template operator()<D, Y, true, false>(); \
+        } else { \
+            if (rot) { if (ls) f.template operator()<D, Y, true, true>(); else f.template operator()<D, Y, true, false>(); } \
+            else { if (ls) f.template operator()<D, Y, false, true>(); else f.template operator()<D, Y, false, false>(); } \
+        } \
         return true; }
     CM_CASE(CM_FULL_3D, CM_YIELD_J2)
     CM_CASE(CM_FULL_3D, CM_YIELD_HILL)
@@ -1046,7 +1129,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
-    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
@@ -1092,7 +1175,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         const dim3 grid((unsigned)nb), block(kBlock);
         // CM_DEBUG_DYN_LDS=<bytes>: occupancy experiments only (extra dynamic LDS per block limits blocks per CU)
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-        const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+        const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && (MODE == 1 || MODE == 3)) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_reverse<D, Y, R, LS, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
@@ -1131,7 +1214,7 @@ int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, 
     (void)hipGetLastError();
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
-        const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+        const bool found = dispatch<true, 2>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (!is_dense_yield(Y))
                 hipLaunchKernelGGL((k_reverse_rate<D, Y, R, (MODE == 1 || MODE == 3) ? LS : false, MODE>), grid, block, 0, s, md, B,
                                    gradu, gradu_prev, xi_prev, xi_in, sd, w, hist_in, xi_out, sigma_out, xpbar, gbar, partials);
@@ -1162,14 +1245,14 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
     (void)hipGetLastError();
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
-        const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+        const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && D == CM_FULL_3D && Y == CM_YIELD_J2) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
                     return;
                 }
             }
-            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
                 hipLaunchKernelGGL((k_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
         });
         if (!found) return CM_ERR_UNSUPPORTED;
@@ -1192,14 +1275,14 @@ int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double
     (void)hipGetLastError();
     const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
-    const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && D == CM_FULL_3D && Y == CM_YIELD_J2) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
                 return;
             }
         }
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
             hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1210,7 +1293,7 @@ template <int MK>
 int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                        const double* xi, const double* dxp_dp, double* dx_dp, double* ds_dp, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (m->def_type == CM_UNIAXIAL_STRESS || is_dense_yield(m->yield_kind))))
+    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind)))
         return CM_ERR_UNSUPPORTED;                  // never a silent no-op: the dispatch below has no such specialisation
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi || !dx_dp || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
@@ -1218,8 +1301,8 @@ int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, c
     (void)hipGetLastError();
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
             hipLaunchKernelGGL((k_direct_step<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1231,7 +1314,7 @@ int launch_direct_history(const cm_model_desc* m, int64_t B, int K, const double
                           const double* sbar_hist, const double* xibar_hist, double* dx_dp_hist, double* ds_dp_hist,
                           double* grad_p, void* workspace, int64_t wbytes, void* stream) {
     if (!m || B < 0 || K < 1) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (m->def_type == CM_UNIAXIAL_STRESS || is_dense_yield(m->yield_kind))))
+    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind)))
         return CM_ERR_UNSUPPORTED;
     if (grad_p && (!sbar_hist || !workspace)) return CM_ERR_BAD_ARG;
     if (grad_p && wbytes < cm_direct_workspace_bytes(B)) return CM_ERR_WORKSPACE;
@@ -1243,8 +1326,8 @@ int launch_direct_history(const cm_model_desc* m, int64_t B, int K, const double
     double* rows = grad_p ? (double*)workspace : nullptr;
     if (B > 0) {
         const dim3 grid((unsigned)((B + 63) / 64)), block(64);
-        const bool found = dispatch<MK == CM_SMALL_ELASTIC_PLASTIC>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (!is_dense_yield(Y) && D != CM_UNIAXIAL_STRESS))
+        const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
                 hipLaunchKernelGGL((k_direct_history<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist,
                                    sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist, rows);
         });
@@ -1289,7 +1372,7 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
                            double* out, void* workspace, int64_t wbytes, void* stream) {
     if (!m || B < 0 || K < 1 || !out || !workspace || !hss6) return CM_ERR_BAD_ARG;
     if (!supported(m, MK) || !has_generic_eval(m->yield_kind) ||
-        (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (m->def_type == CM_UNIAXIAL_STRESS || is_dense_yield(m->yield_kind))))
+        (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind)))
         return CM_ERR_UNSUPPORTED;
     if (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !dx_dp_hist || !sbar_hist)) return CM_ERR_BAD_ARG;
     if (wbytes < cm_hessian_workspace_bytes(m, B, K)) return CM_ERR_WORKSPACE;
@@ -1306,10 +1389,10 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
         const int64_t nthreads = nps * (int64_t)(nq * (nq + 1) / 2);
         const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && (D == CM_UNIAXIAL_STRESS || is_dense_yield(Y)))) {
+            if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y))) {
                 hipLaunchKernelGGL((k_hessian_weights<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist, lam_hist,
                                    sbar_hist, h, W);
-                hipLaunchKernelGGL((k_hessian_quadform<Dims<D>::NX>), dim3((unsigned)nps), dim3(192), 0, s, B, K, W, dx_dp_hist, part);
+                hipLaunchKernelGGL((k_hessian_quadform<nx_of<D, MK>()>), dim3((unsigned)nps), dim3(192), 0, s, B, K, W, dx_dp_hist, part);
             }
         });
         if (!found) return CM_ERR_UNSUPPORTED;
@@ -1428,7 +1511,8 @@ int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();
-    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<true, 2>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y)))
         hipLaunchKernelGGL((k_update_rate<D, Y, R, LS, false>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma, nullptr, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1448,7 +1532,8 @@ int cm_update_rate_tangent(const cm_model_desc* m, int64_t B, const double* grad
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();
-    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<true, 2>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y)))
         hipLaunchKernelGGL((k_update_rate<D, Y, R, LS, true>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma,
                            dsigma_dgradu, status);
     });
@@ -1596,7 +1681,8 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
     (void)hipGetLastError();
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    const bool found = dispatch(m, [&]<int D, int Y, bool R, bool LS>() {
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y)))
         hipLaunchKernelGGL((k_evaluate_rate<D, Y, kColdRot>), grid, block, 0, s, md, B, which, gradu, gradu_prev, xi_prev, xi,
                            C, jac, sigma, dsigma);
     });

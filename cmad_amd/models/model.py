@@ -126,25 +126,6 @@ class Model(ABC):
         J = torch.empty((nx * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
         S = torch.empty((6 * ncols, 1), dtype=torch.float64, device=dev) if want_jac else None
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        if self._model_kind == 1 and self._def_type == DefType.UNIAXIAL_STRESS:
-            # 12-dof variant: residual, stress and first-derivative blocks by dual-number evaluation (cm_hessians_rate)
-            if int(which) in (int(DerivType.DU), int(DerivType.DU_PREV)):
-                raise NotImplementedError("d/dU of the rate form under UNIAXIAL_STRESS is not available in the HIP path")
-            Gp = np.zeros_like(G) if U_prev is None else np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
-            gp = t(Gp)
-            nq = 2 * nx + _lib.CM_NUM_PARAMS
-            need = want_jac and which != DerivType.DNONE
-            dC = torch.empty((nx, nq), dtype=torch.float64, device=dev) if need else None
-            dS = torch.empty((6, nq), dtype=torch.float64, device=dev) if need else None
-            C0 = torch.empty((1, nx), dtype=torch.float64, device=dev)
-            S0 = torch.empty((1, 6), dtype=torch.float64, device=dev)
-            rc = L.cm_hessians_rate(C.byref(desc), 1, _ptr(g), _ptr(gp), _ptr(x0), _ptr(x1), None, None,
-                                    _ptr(dC), _ptr(dS), _ptr(C0), _ptr(S0), stream)
-            _lib.check(rc, "cm_hessians_rate")
-            cols = {0: slice(0, nx), 1: slice(nx, 2 * nx), 2: slice(2 * nx, nq)}.get(int(which))
-            out_J = dC.cpu().numpy()[:, cols] if need else None
-            out_S = dS.cpu().numpy()[:, cols] if need else None
-            return C0.cpu().numpy()[0], out_J, S0.cpu().numpy()[0], out_S, info
         if self._model_kind == 1:
             Gp = np.zeros_like(G) if U_prev is None else np.asarray(U_prev.grad_fields["u"], dtype=np.float64).reshape(nu, 1)
             gp = t(Gp)                                    # named: must outlive the launch

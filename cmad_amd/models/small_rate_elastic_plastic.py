@@ -3,15 +3,14 @@ material Cauchy stress.  Host mirror of /root/reference/cmad/models/small_rate_e
 (constructor contract and state layout: "cauchy" sym tensor, "alpha", plane-stress stretch); the residual
 (:249-346) runs in `cm_update_rate`.
 
-Built on the device for FULL_3D and PLANE_STRESS: the stress update (`cm_update_rate`) and the stateful
-evaluate surface (`cm_evaluate_rate`: residual, every Jacobian block including d/dU_prev, Sigma, dSigma), so
-the material-point objectives run on it unchanged; second derivatives through `cm_hessians_rate`.
-UNIAXIAL_STRESS (12 local dofs, :171-196) is served by `cm_hessians_rate` alone -- residual, stress, first and
-second derivatives by dual-number evaluation -- with the Newton loop of `newton_solve` on the host.
-The batched forward tangent is `cm_update_rate_tangent` (`DeviceEvaluator.update_rate(tangent=True)`); the batched
-reverse sweep is `cm_update_rate_vjp` / `cm_update_rate_and_vjp` / `cm_objective_grad_rate` /
-`cm_adjoint_step_rate` (the `gradu_prev=` keyword of the `DeviceEvaluator` methods), which is what
-`BatchedCalibrationObjective` runs on this model."""
+Built on the device for all three deformation types: the stress update (`cm_update_rate`) and the stateful evaluate
+surface (`cm_evaluate_rate`: residual, every Jacobian block including d/dU_prev, Sigma, dSigma), so the material-point
+objectives run on it unchanged; second derivatives through `cm_hessians_rate`.  FULL_3D and PLANE_STRESS use hand-derived
+blocks; UNIAXIAL_STRESS (12 local dofs, :171-196) gets its blocks by forward-mode evaluation of the residual inside the
+same kernels (cmad_amd/csrc/cm_rate_uniaxial.hpp).  The batched forward tangent is `cm_update_rate_tangent`
+(`DeviceEvaluator.update_rate(tangent=True)`); the batched reverse sweep is `cm_update_rate_vjp` /
+`cm_update_rate_and_vjp` / `cm_objective_grad_rate` / `cm_adjoint_step_rate` (the `gradu_prev=` keyword of the
+`DeviceEvaluator` methods), which is what `BatchedCalibrationObjective` runs on this model."""
 from __future__ import annotations
 
 from typing import ClassVar
@@ -90,9 +89,9 @@ class SmallRateElasticPlastic(Model):
 
     @property
     def has_device_newton(self) -> bool:
-        """UNIAXIAL_STRESS (12 local dofs) is served by dual-number evaluation only (cm_hessians_rate): its Newton
-        loop runs in `newton_solve` on the host with the device-evaluated residual and Jacobian."""
-        return self._def_type != DefType.UNIAXIAL_STRESS
+        """Every deformation type has a batched Newton kernel (UNIAXIAL_STRESS: 12 local dofs, Jacobian by forward-mode
+        evaluation in the kernel, cm_rate_uniaxial.hpp)."""
+        return True
 
     def device_newton(self, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search=None):
         import torch

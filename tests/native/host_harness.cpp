@@ -107,7 +107,7 @@ static void run_vjp(const cm_model_desc& m, int64_t B, const double* gradu, cons
 template <int DEF, int YK, bool ROT>
 static void run_vjp_rate(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                          const double* xi, const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
     for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] = 0.0;
     if constexpr (!is_dense_yield(YK)) {
         for (int64_t b = 0; b < B; ++b) {
@@ -115,10 +115,18 @@ static void run_vjp_rate(const cm_model_desc& m, int64_t B, const double* gradu,
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
             for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; if (xin) xi_in[k] = xin[k * B + b]; }
             for (int k = 0; k < 6; ++k) sb[k] = sbar[k * B + b];
+            if constexpr (DEF == CM_UNIAXIAL_STRESS) {           // 12 dofs: blocks by forward-mode evaluation (cm_rate_uniaxial.hpp)
+                double ubar = 0.0;
+                ru_reverse<YK>(m, G[0], x, xp, sb, xin ? xi_in : nullptr, pb, xb, &ubar);
+                for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
+                if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
+                if (gbar) gbar[b] = ubar;
+                continue;
+            }
             strain_from_gradu<DEF, ROT>(m, G, deg);
             strain_z<DEF, ROT>(m, z);
             cotangent_to_material<ROT>(m, sb, sbm);
-            reverse_point_rate<DEF, YK>(m, deg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+            reverse_point_rate<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
             for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
             if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
             if (gbar) for (int c = 0; c < NU; ++c) {
@@ -153,20 +161,28 @@ static void run_evaluate(const cm_model_desc& m, int64_t B, int which, const dou
 template <int DEF, int YK, bool ROT>
 static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev,
                             const double* xi_prev, double* xi, double* sigma, uint32_t* status) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
     for (int64_t b = 0; b < B; ++b) {
         double G[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], sg[6];
         for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+            const uint32_t stu = (m.ls_max_evals > 0) ? ru_newton<YK, true>(m, G[0], xp, x, true) : ru_newton<YK, false>(m, G[0], xp, x, true);
+            to_global<ROT>(m, x, sg);
+            for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
+            for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
+            status[b] = stu;
+            continue;
+        }
         strain_from_gradu<DEF, ROT>(m, G, deg);
         strain_z<DEF, ROT>(m, z);
         double parked[2 * 9];
         const LaneStage stage{parked, 1};
         uint32_t st;
-        if (hh_g_passes) st = (m.ls_max_evals > 0) ? newton_by_passes<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, stage)
-                                                   : newton_by_passes<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, stage);
-        else st = (m.ls_max_evals > 0) ? newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, true)
-                                       : newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, true);
+        if (hh_g_passes) st = (m.ls_max_evals > 0) ? newton_by_passes<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, stage)
+                                                   : newton_by_passes<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, stage);
+        else st = (m.ls_max_evals > 0) ? newton<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, true)
+                                       : newton<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, true);
         to_global<ROT>(m, x, sg);
         for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
         for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
@@ -178,14 +194,20 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
 template <int DEF, int YK, bool ROT>
 static void run_tangent_rate(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev,
                              const double* xi_prev, const double* xi, double* dsig) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
     for (int64_t b = 0; b < B; ++b) {
         double G[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], T[6][6];
         for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
         for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; }
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+            double ds[6];
+            ru_tangent<YK>(m, G[0], x, xp, ds);
+            for (int r = 0; r < 6; ++r) dsig[(int64_t)r * B + b] = ds[r];
+            continue;
+        }
         strain_from_gradu<DEF, ROT>(m, G, deg);
         strain_z<DEF, ROT>(m, z);
-        tangent_point_rate<DEF, YK>(m, deg, z, x, xp, T);
+        tangent_point_rate<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, T);
         for (int c = 0; c < NU; ++c) {
             double Gd[NU], dm[6], t[6], tg[6];
             for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
@@ -200,12 +222,16 @@ static void run_tangent_rate(const cm_model_desc& m, int64_t B, const double* gr
 template <int DEF, int YK, bool ROT>
 static void run_evaluate_rate(const cm_model_desc& m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                               const double* xi_prev, const double* xi, double* C_out, double* J_out, double* s_out, double* S_out) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
     const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
     for (int64_t b = 0; b < B; ++b) {
         double G[NU], Gp[NU], xp[NX], x[NX], C[NX], sg[6], J[NX * CM_NUM_PARAMS], S[6 * CM_NUM_PARAMS];
         for (int k = 0; k < NU; ++k) { G[k] = gradu[k * B + b]; Gp[k] = gradu_prev[k * B + b]; }
         for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; }
+        if constexpr (DEF == CM_UNIAXIAL_STRESS) {
+            ru_eval<YK>(m, G[0] - Gp[0], x, xp, C, sg);
+            if (which != CM_W_NONE) ru_block<YK>(m, G[0] - Gp[0], x, xp, which, J, S);
+        } else
         evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, which, C, J, sg, S);
         for (int k = 0; k < NX; ++k) C_out[k * B + b] = C[k];
         for (int k = 0; k < 6; ++k) s_out[k * B + b] = sg[k];
@@ -350,25 +376,25 @@ int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double*
 #if HH_HAS(2)
 int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status) {
-    return dispatch(m, [&]<int D, int Y, bool R>() { run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y))) run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
 }
 #endif
 #if HH_HAS(2)
 int hh_vjp_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                 const double* xi, const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
-    return dispatch(m, [&]<int D, int Y, bool R>() { run_vjp_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_vjp_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sbar, xin, grad, xpbar, gbar); });
 }
 #endif
 #if HH_HAS(2)
 int hh_tangent_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
                     const double* xi_prev, const double* xi, double* dsig) {
-    return dispatch(m, [&]<int D, int Y, bool R>() { run_tangent_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, dsig); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y))) run_tangent_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, dsig); });
 }
 #endif
 #if HH_HAS(2)
 int hh_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                      const double* xi_prev, const double* xi, double* C, double* J, double* s, double* S) {
-    return dispatch(m, [&]<int D, int Y, bool R>() { run_evaluate_rate<D, Y, R>(*m, B, which, gradu, gradu_prev, xi_prev, xi, C, J, s, S); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y))) run_evaluate_rate<D, Y, R>(*m, B, which, gradu, gradu_prev, xi_prev, xi, C, J, s, S); });
 }
 #endif
 #if HH_HAS(4)
@@ -394,7 +420,7 @@ int hh_evaluate(const cm_model_desc* m, int64_t B, int which, const double* grad
 int hh_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* data_hist,
                const double* wsq6, const double* xi0, double* xi_hist, double* out) {
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch(m, [&]<int D, int Y, bool R>() {
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() {
             if constexpr (!is_dense_yield(Y)) run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() {
         run_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
@@ -404,7 +430,7 @@ int hh_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_his
 int hh_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi0,
                       double* xi_hist, double* sigma_hist, uint32_t* status_hist) {
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch(m, [&]<int D, int Y, bool R>() {
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() {
             if constexpr (!is_dense_yield(Y)) run_primal_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() {
         run_primal_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
@@ -414,19 +440,21 @@ int hh_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gr
 int hh_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    const double* xi, const double* dxp_dp, double* dx_dp, double* ds_dp) {
     auto body = [&]<int D, int Y, bool R, int MK>() {
-        constexpr int NX = Dims<D>::NX, NU = Dims<D>::NU, NP_ = CM_NUM_PARAMS;
+        constexpr int NX = nx_of<D, MK>(), NU = Dims<D>::NU, NP_ = CM_NUM_PARAMS;
         for (int64_t b = 0; b < B; ++b) {
             double G[NU], Gp[NU], xp[NX], x[NX], din[NX * NP_], dout[NX * NP_], dsig[6 * NP_];
             for (int k = 0; k < NU; ++k) { G[k] = gradu[k * B + b]; Gp[k] = gradu_prev ? gradu_prev[k * B + b] : 0.0; }
             for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; }
             if (dxp_dp) for (int i = 0; i < NX * NP_; ++i) din[i] = dxp_dp[(int64_t)i * B + b];
+            if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS) ru_direct<Y>(*m, G[0] - Gp[0], x, xp, dxp_dp ? din : nullptr, dout, dsig);
+            else
             direct_point<MK, D, Y, R>(*m, G, Gp, x, xp, dxp_dp ? din : nullptr, dout, dsig);
             for (int i = 0; i < NX * NP_; ++i) dx_dp[(int64_t)i * B + b] = dout[i];
             for (int i = 0; i < 6 * NP_; ++i) ds_dp[(int64_t)i * B + b] = dsig[i];
         }
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
@@ -439,7 +467,7 @@ int hh_adjoint_history(const cm_model_desc* m, int64_t B, int K, const double* g
     const HistoryCotangents hc{sbar_hist, xibar_hist, lam_hist};
     int rc;
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        rc = dispatch(m, [&]<int D, int Y, bool R>() {
+        rc = dispatch<true>(m, [&]<int D, int Y, bool R>() {
             if constexpr (!is_dense_yield(Y)) run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, nullptr, wsq0, xi0, xi_hist, out, hc); });
     else
         rc = dispatch<true>(m, [&]<int D, int Y, bool R>() {
@@ -461,7 +489,7 @@ int hh_direct_history(const cm_model_desc* m, int64_t B, int K, const double* gr
         }
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
@@ -491,7 +519,7 @@ int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* g
         }
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (Y != CM_YIELD_BARLAT) body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif

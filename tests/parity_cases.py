@@ -261,10 +261,10 @@ def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed
     from cmad_amd.synthetic import gauss_point_batch
     rng = np.random.default_rng(seed)
     values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
-    nd = 3 if def_type == ol.FULL_3D else 2
+    nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
     st_o, st_d = settings_pair(ls)
-    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
-    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=1)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d, uniaxial_stress_idx=1)
     g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
     g_prev = np.zeros_like(g0)
     xp = np.tile(mat.init_xi()[:, None], (1, B))
@@ -292,10 +292,10 @@ def check_rate_tangent(tangent_rate, def_type, yield_kind, kw, rot, B=512, seed=
     from cmad_amd.synthetic import gauss_point_batch
     rng = np.random.default_rng(seed)
     values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
-    nd = 3 if def_type == ol.FULL_3D else 2
+    nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
     st_o, st_d = settings_pair(False)
-    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
-    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=1)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d, uniaxial_stress_idx=1)
     g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
     xp = np.tile(mat.init_xi()[:, None], (1, B))
     x1, _, _, cv1 = mat.update_batch(st_o, 0.9 * g0, xp, gradu_prev=np.zeros_like(g0))
@@ -314,10 +314,10 @@ def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
     from cmad_amd.synthetic import gauss_point_batch
     rng = np.random.default_rng(seed)
     values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
-    nd = 3 if def_type == ol.FULL_3D else 2
+    nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
     st_o, st_d = settings_pair(False)
-    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP)
-    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d)
+    mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=1)
+    desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d, uniaxial_stress_idx=1)
     g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
     xp = np.tile(mat.init_xi()[:, None], (1, B))
     x1, _, _, cv1 = mat.update_batch(st_o, 0.9 * g0, xp, gradu_prev=np.zeros_like(g0))
@@ -329,7 +329,8 @@ def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
     np.testing.assert_allclose(xb_d, xb_o, rtol=1e-9, atol=1e-9 * np.abs(xb_o).max())
     np.testing.assert_allclose(ub_d, ub_o, rtol=1e-9, atol=1e-9 * np.abs(ub_o).max())
     got, ref = leaf_grads(g_d, info, mat, yield_kind, g_o)
-    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+    # (12-dof UNIAXIAL_STRESS form: both sides difference O(1) terms of the pivoted 12 x 12 solves -> 1e-10 of the largest entry)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=(1e-9 if def_type == ol.UNIAXIAL_STRESS else 1e-12) * np.abs(ref).max())
 
 
 def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, K=5, B=256, seed=22, uniaxial_idx=0,

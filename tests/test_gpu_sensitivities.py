@@ -100,7 +100,7 @@ def test_adjoint_history(backend, def_type, yield_kind, kw):
 
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
-@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_rate_form_tangent(def_type, yield_kind, kw, rot):
     """cm_update_rate_tangent: the update reproduces the oracle's state and the tangent its IFT Jacobian."""
     import torch
@@ -130,7 +130,7 @@ def _rate_case(def_type, yield_kind, kw, rot, B, seed=22):
 
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
-@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_rate_form_vjp_and_fused(def_type, yield_kind, kw, rot):
     """cm_update_rate_vjp vs the oracle's reverse sweep; cm_update_rate_and_vjp gives the same numbers from
     xi_prev alone (cmad/models/small_rate_elastic_plastic.py under cmad/objectives/mp_objective.py:95-147)."""
@@ -261,8 +261,6 @@ def test_history_objective_grad(def_type, yield_kind, kw, rot, rate):
     """cm_objective_grad_history: the whole K-step history per point in one launch vs the oracle's adjoint
     (cmad/objectives/mp_objective.py:95-147), and cm_update_history (the forward pass alone: states, stresses, iteration
     counts per step); block tail (B not a multiple of the block) included."""
-    if rate and def_type == ol.UNIAXIAL_STRESS:
-        pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
     # (the 7-step path ends with a large reversal that the rate form's plain Newton does not survive at every point)
     pc.check_history(_gpu_history, def_type, yield_kind, kw, rot, rate=rate, B=1000, K=5 if rate else 7, uniaxial_idx=2,
                      primal=_gpu_primal)
@@ -344,8 +342,6 @@ def test_direct_sensitivities(def_type, yield_kind, kw, rot, rate):
     oracle's adjoint."""
     import torch
     from cmad_amd.models.device import DeviceEvaluator
-    if rate and def_type == ol.UNIAXIAL_STRESS:
-        pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
     def direct(desc, info, g, gp, xp, x, dxp):

@@ -126,7 +126,7 @@ def test_hybrid_through_the_facade():
 
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
-@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_rate_model_update(def_type, yield_kind, kw, ls):
     """small_rate_elastic_plastic (cm_update_rate) vs the oracle, three load steps."""
     import torch
@@ -510,8 +510,6 @@ def test_j2_voce_analytical_golden(golden_dir, model_kind, def_type, yield_kind)
     J2-equivalent Hill and Hosford (a = 2 equivalent settings of tests/support/test_problems.py) reproduce the same fields."""
     import torch
     from cmad_amd.models.device import DeviceEvaluator, build_desc
-    if model_kind == 1 and def_type == ol.UNIAXIAL_STRESS:
-        pytest.skip("rate form under UNIAXIAL_STRESS: dual-number blocks + host Newton (test_gpu_facade.py)")
     g = np.load(os.path.join(golden_dir, "j2_voce_analytical.npz"))
     nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
     V6 = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]

@@ -80,8 +80,6 @@ def test_history_objective_grad(def_type, yield_kind, kw, rot, rate, solver_vari
     registers, K adjoint steps backward, both model kinds."""
     if solver_variant != "structured":
         pytest.skip("one variant: the history loop is the same code on both solver paths")
-    if rate and def_type == ol.UNIAXIAL_STRESS:
-        pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
     pc.check_history(_host_history, def_type, yield_kind, kw, rot, rate=rate, B=96, uniaxial_idx=1, primal=_host_primal)
 
 
@@ -94,8 +92,6 @@ def test_direct_sensitivities(def_type, yield_kind, kw, rot, rate, solver_varian
     import host_harness_lib as hh
     if solver_variant != "structured":
         pytest.skip("one variant: built on the explicit blocks")
-    if rate and def_type == ol.UNIAXIAL_STRESS:
-        pytest.skip("rate form under UNIAXIAL_STRESS has no batched kernels")
     pc.check_direct(lambda desc, info, g, gp, xp, x, dxp: hh.direct_step(desc, g, xp, x, dxp, gradu_prev=gp),
                     def_type, yield_kind, kw, rot, rate=rate, B=64, uniaxial_idx=1)
 
@@ -182,12 +178,12 @@ def test_scaled_hybrid_hill_icnn(def_type, rot):
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
-@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_rate_model_update(def_type, yield_kind, kw, rot, ls, solver_variant):
     import host_harness_lib as hh
     if hh.lib() and solver_variant == "dense":
         pytest.skip("rate form always uses the dense path")
-    pc.check_rate_model(lambda desc, info, g, gp, xp: hh.update_rate(desc, g, gp, xp, desc.def_type == 2 and 8 or 7),
+    pc.check_rate_model(lambda desc, info, g, gp, xp: hh.update_rate(desc, g, gp, xp, {0: 7, 2: 8, 3: 12}[desc.def_type]),
                         def_type, yield_kind, kw, rot, ls, B=256)
 
 
@@ -330,7 +326,7 @@ def test_rate_form_uniaxial_by_dual_numbers(yield_kind, kw, idx, plastic, solver
 
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
-@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_rate_form_tangent(def_type, yield_kind, kw, rot, solver_variant):
     import host_harness_lib as hh
     if solver_variant != "structured":
@@ -340,7 +336,7 @@ def test_rate_form_tangent(def_type, yield_kind, kw, rot, solver_variant):
 
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS[:3])
-@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_rate_form_vjp(def_type, yield_kind, kw, rot, solver_variant):
     import host_harness_lib as hh
     if solver_variant != "structured":

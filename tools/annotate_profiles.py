@@ -1,0 +1,88 @@
+"""Condense the rocprofv3 summaries of tools/profile_sides.sh (gpurun_out/prof_<tag>_*/summary_*.json) into the files kept
+under profiles/: per workload the dominant kernel with its average duration (kernel trace), the register / scratch / LDS
+numbers of the CODE OBJECT (tools/kernel_resources.py -- the VGPR_Count column of the rocprofv3 trace reports allocation
+granules, not registers), HBM traffic (FETCH_SIZE x 2 x 32 B... see below), SQ wave-cycle split and the fp64 instruction mix.
+
+    python tools/annotate_profiles.py r02 [libcmad_hip.so]  ->  profiles/<tag>_rocprof_summary.json, profiles/<tag>_side_kernels.txt
+
+Units: FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3); on gfx950 FETCH_SIZE counts half of a wide coalesced read
+(/opt/skills/guides/MI355X_MICROARCH.md), so HBM bytes = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024.  SQ_* cycle counters are
+quad-cycles summed over waves; fractions are taken against SQ_WAVE_CYCLES.  fp64 VALU peak = 78.6 TFLOP/s (half of the
+157.3 TFLOP/s fp32 vector rate of the guide); flops = (2 FMA + MUL + ADD) x 64 lanes x mean active-lane fraction.
+"""
+import glob
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_resources as kr  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+so = sys.argv[2] if len(sys.argv) > 2 else "cmad_amd/csrc/libcmad_hip.so"
+def short(n):
+    """kernel name without its argument list"""
+    m = re.search(r"\((cm_model_desc|long|double|int|unsigned)", n)
+    return (n[:m.start()] if m else n).strip()
+
+
+res = {}
+for r in kr.kernels(so):
+    res[short(r[0])] = {"vgpr": r[1], "agpr": r[5], "sgpr": r[2], "scratch_bytes": r[3], "lds_bytes": r[4]}
+
+out, lines = {}, []
+for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
+    d = json.load(open(f))
+    wl = d["tag"][len(tag) + 1:]
+    bench = d.get("bench_trace.json", {})
+    kernels = {k: v for k, v in d["kernels"].items() if "reduce" not in k and "sum_rows" not in k}
+    # the workload's own kernel: the one with the most time that is not the 65536-point self-check launch
+    main = max(kernels, key=lambda k: (kernels[k]["calls"], kernels[k]["avg_us"]))
+    kv = kernels[main]
+    name = short(main)
+    entry = {"kernel": name, "calls": kv["calls"], "avg_us": kv["avg_us"], "min_us": kv["min_us"], "max_us": kv["max_us"],
+             "code_object": res.get(name), "workload": bench.get("config", {}).get("workload") if isinstance(bench, dict) else None}
+    pts = bench.get("config", {}).get("points_per_gpu") if isinstance(bench, dict) else None
+    bpu = bench.get("roofline", {}).get("algorithmic_bytes_per_update") if isinstance(bench, dict) else None
+    if pts and bpu:
+        entry["algorithmic_GBs_at_kernel_time"] = bpu * pts / (kv["avg_us"] * 1e-6) / 1e9
+        entry["hbm_roof_frac_kernel_only"] = entry["algorithmic_GBs_at_kernel_time"] / 8000.0
+        entry["bench_under_trace"] = {k: bench.get(k) for k in ("value", "ms_per_step")}
+    c = {}
+    for sec in ("pmc_sq", "pmc_mix", "pmc_fetch", "pmc_write"):
+        for k, v in d.get(sec, {}).items():
+            if short(k) == name:
+                c.update({cn: cv["mean"] for cn, cv in v.items()})
+    if c:
+        entry["counters_mean_per_launch"] = c
+        wc = c.get("SQ_WAVE_CYCLES")
+        if wc:
+            entry["wave_cycle_split"] = {"valu_active": c.get("SQ_ACTIVE_INST_VALU", 0) / wc, "wait_any": c.get("SQ_WAIT_ANY", 0) / wc,
+                                         "wait_inst_any": c.get("SQ_WAIT_INST_ANY", 0) / wc}
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
+            entry["active_lane_fraction"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            entry["hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+            if pts:
+                entry["hbm_bytes_per_point"] = entry["hbm_bytes_per_launch"] / pts
+        if "SQ_INSTS_VALU_FMA_F64" in c:
+            lanes = entry.get("active_lane_fraction", 1.0)
+            flops = (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * lanes
+            entry["fp64_tflops"] = flops / (kv["avg_us"] * 1e-6) / 1e12
+            entry["fp64_valu_roof_frac"] = entry["fp64_tflops"] / 78.6
+            if c.get("SQ_WAVES"):
+                entry["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"]
+    out[wl] = entry
+    co = entry["code_object"] or {}
+    lines.append(f"{wl:16s} {name[len('void (anonymous namespace)::'):][:52]:52s} avg {kv['avg_us']:8.1f} us x{kv['calls']:3d} | "
+                 f"{co.get('vgpr', '?')} vgpr ({co.get('agpr', '?')} acc) {co.get('scratch_bytes', '?')} B scratch {co.get('lds_bytes', '?')} B lds | "
+                 f"hbm roof {entry.get('hbm_roof_frac_kernel_only', float('nan')):.3f} | fp64 valu roof {entry.get('fp64_valu_roof_frac', float('nan')):.3f} | "
+                 f"valu/wait/stall {entry.get('wave_cycle_split', {}).get('valu_active', float('nan')):.2f}/"
+                 f"{entry.get('wave_cycle_split', {}).get('wait_any', float('nan')):.2f}/"
+                 f"{entry.get('wave_cycle_split', {}).get('wait_inst_any', float('nan')):.2f} | lanes {entry.get('active_lane_fraction', float('nan')):.2f} | "
+                 f"traffic {entry.get('hbm_bytes_per_point', float('nan')):.1f} B/pt")
+os.makedirs("profiles", exist_ok=True)
+json.dump(out, open(f"profiles/{tag}_rocprof_summary.json", "w"), indent=1)
+open(f"profiles/{tag}_side_kernels.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))

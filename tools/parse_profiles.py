@@ -52,6 +52,7 @@ def pmc(sub):
 summary["pmc_fetch"] = pmc("pmc_fetch")
 summary["pmc_write"] = pmc("pmc_write")
 summary["pmc_sq"] = pmc("pmc_sq")
+summary["pmc_mix"] = pmc("pmc_mix")
 for name in ("bench_trace.json", "bench_fetch.json"):
     try:
         with open(os.path.join(out_dir, name)) as fh:
