@@ -286,7 +286,7 @@ CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6]
 
 // NN(flat dev s) of hybrid_hill_effective_stress (cmad/models/effective_stress.py:149-163) in the 6-vector
 // basis: value, d/ds6, d2/ds6 ds6.  NN input order is [xx,yy,zz,xy,xz,yz] of the deviator.
-// value, d/ds6 and (HESS) the second derivative ADDED to the packed Hessian Hp
+// value, d/ds6 and (HESS) the second derivative written to the packed Hessian Hp
 template <bool HESS>
 CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val, double g6[6], double Hp[21]) {
     const double* __restrict__ w = m.nn_weights;
@@ -331,7 +331,7 @@ CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val
                 if (kDiag[l]) v -= rm[XI[k]];
                 if (kDiag[k]) v -= rm[XI[l]];
                 if (kDiag[k] && kDiag[l]) v += tot;
-                Hp[sym6(k, l)] += v;
+                Hp[sym6(k, l)] = v;
             }
     }
 }
@@ -631,12 +631,34 @@ CM_D void yield_eval_p(const cm_model_desc& m, const double s[6], double& phi, d
     } else if constexpr (YK == CM_YIELD_SCALED_HYBRID_HILL_NN) {
         scaled_hybrid_eval<HESS>(m, s, phi, gt, Hp);
     } else if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
-        yield_eval_p<CM_YIELD_HILL, HESS>(m, s, phi, gt, Hp);
-        double v, g6[6];
-        icnn_yield_term<HESS>(m, s, v, g6, Hp);               // adds its second derivative to Hp
-        phi += v;
+        // the network term first (its loop over the hidden units carries 28 accumulators), the Hill quadratic form added after it,
+        // so that the Hill Hessian is not live across that loop
+        double v;
+        icnn_yield_term<HESS>(m, s, v, gt, Hp);
+        const QuadForm q = quad_form<CM_YIELD_HILL>(m);
+        double As[6];
+        As[0] = q.a00 * s[0] + q.a03 * s[3] + q.a05 * s[5];
+        As[3] = q.a03 * s[0] + q.a33 * s[3] + q.a35 * s[5];
+        As[5] = q.a05 * s[0] + q.a35 * s[3] + q.a55 * s[5];
+        As[1] = q.a11 * s[1]; As[2] = q.a22 * s[2]; As[4] = q.a44 * s[4];
+        double qq = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) gt[k] += g6[k];
+        for (int k = 0; k < 6; ++k) qq += s[k] * As[k];
+        const double ph = sqrt(qq), ip = (qq > 0.0) ? rcp(ph) : 0.0;
+        phi = ph + v;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) As[k] *= ip;               // Hill gradient
+        if constexpr (HESS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int l = k; l < 6; ++l) Hp[sym6(k, l)] -= As[k] * As[l] * ip;
+            Hp[sym6(0, 0)] += q.a00 * ip; Hp[sym6(3, 3)] += q.a33 * ip; Hp[sym6(5, 5)] += q.a55 * ip;
+            Hp[sym6(0, 3)] += q.a03 * ip; Hp[sym6(0, 5)] += q.a05 * ip; Hp[sym6(3, 5)] += q.a35 * ip;
+            Hp[sym6(1, 1)] += q.a11 * ip; Hp[sym6(2, 2)] += q.a22 * ip; Hp[sym6(4, 4)] += q.a44 * ip;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gt[k] += As[k];
     } else if constexpr (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) {
         const QuadForm q = quad_form<YK>(m);
         double As[6];

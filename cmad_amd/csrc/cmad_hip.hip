@@ -48,10 +48,6 @@ using namespace cm;
 #ifndef CM_NONTEMPORAL
 #define CM_NONTEMPORAL 1
 #endif
-// workgroups of look-ahead of the input-row prefetch in the fused kernels (0 = off); experiment knob, see k_reverse
-#ifndef CM_PREFETCH_DIST
-#define CM_PREFETCH_DIST 0
-#endif
 typedef const __attribute__((address_space(1))) char* cm_gcptr;
 typedef __attribute__((address_space(1))) char* cm_gptr;
 template <int N, bool NT = (CM_NONTEMPORAL != 0)>
@@ -92,7 +88,7 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #define CM_OCC_UPD_HOSFORD_LS 1
 #endif
 #ifndef CM_OCC_UPD_HYBRID
-#define CM_OCC_UPD_HYBRID 2         // 268-276 -> 256 VGPRs: two waves per SIMD for the exp/log-bound network kernels
+#define CM_OCC_UPD_HYBRID 1         // lockstep fallback (B < 256 or CM_SOLVER_LOCKSTEP): registers instead of scratch; the pool kernel is the fast path
 #endif
 #ifndef CM_OCC_UPD_BARLAT
 #define CM_OCC_UPD_BARLAT 1
@@ -489,29 +485,6 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
     if constexpr (MODE == 0 || MODE == 2) load_soa<6>(sbar_or_data, B, b, sd);
-#if CM_PREFETCH_DIST > 0
-    unsigned touched[2] = {0u, 0u};                              // landing registers of the prefetch loads: reserved until the wait below
-    if constexpr (MODE == 1 || MODE == 3) {
-        // Touch the input rows of the workgroup CM_PREFETCH_DIST ahead (one dword per 128-byte line: this wavefront's 64 points
-        // are 4 lines of each of the NU + NX + 6 rows), so that they sit in L2 / the memory-side cache when that workgroup
-        // starts: its first loads then return at cache latency and the solve overlaps other workgroups' HBM reads.
-        const int64_t ahead = (int64_t)CM_PREFETCH_DIST * kBlock;
-        if (blk0 + ahead + kBlock <= B) {
-            const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-            constexpr int NROWS = NU + NX + 6;
-#pragma unroll
-            for (int r0 = 0; r0 < NROWS; r0 += 16) {
-                const int r = r0 + (int)(lane >> 2);
-                if (r < NROWS) {
-                    const double* row = (r < NU) ? gradu + (int64_t)r * B
-                                                 : ((r < NU + NX) ? xi_prev + (int64_t)(r - NU) * B : sbar_or_data + (int64_t)(r - NU - NX) * B);
-                    const double* pa = row + ahead + wv * 64 + (lane & 3u) * 16;
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(touched[r0 / 16]) : "v"(pa) : "memory");
-                }
-            }
-        }
-    }
-#endif
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
     // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
@@ -527,9 +500,6 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
-#if CM_PREFETCH_DIST > 0
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched[0]), "+v"(touched[1]) : : "memory");   // the prefetch loads have landed
-#endif
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
