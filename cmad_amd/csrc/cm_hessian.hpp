@@ -172,10 +172,102 @@ CM_D void icnn_yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T
     for (int k = 0; k < 6; ++k) { g6[k] = gx[XI[k]]; if (kDiag[k]) g6[k] = g6[k] - gm; }
 }
 
+// ---- Barlat Yld2004-18p in arithmetic T (cm::barlat_eval: value and d/ds6) ---------------------------------------------
+// cyclic Jacobi on a symmetric 3x3 of type T (cm::eig_sym3); rotations are decided on the values.  Where an off-diagonal
+// entry is already negligible against the eigenvalue gap the rotation angle is taken from first-order perturbation theory
+// (t = a_pq / (a_qq - a_pp)), which stays finite when the VALUE of a_pq is exactly zero but its derivative part is not
+// (stresses aligned with the material axes).  Repeated eigenvalues have no differentiable eigenvectors: derivative parts are
+// then not meaningful (the reference's eigh rule divides by zero there as well).
+template <class T>
+CM_D void eig_sym3_T(const T s[6], T lam[3], T V[3][3]) {
+    T a00 = s[0], a01 = s[1], a02 = s[2], a11 = s[3], a12 = s[4], a22 = s[5];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = t_const<T>((i == j) ? 1.0 : 0.0);
+    auto rotate = [&](T& app, T& aqq, T& apq, T& apr, T& aqr, int P, int Q) {
+        const double gap = t_val(aqq) - t_val(app), off = t_val(apq);
+        T t;
+        if (fabs(off) < 1e-9 * fabs(gap)) t = apq / (aqq - app);
+        else if (off == 0.0) return;                              // nothing to rotate (and no gap to define a direction)
+        else {
+            const T theta = (aqq - app) / (2.0 * apq);
+            const double sg = (t_val(theta) >= 0.0) ? 1.0 : -1.0;
+            t = sg / (sg * theta + t_sqrt(theta * theta + 1.0));
+        }
+        const T c = 1.0 / t_sqrt(t * t + 1.0), sn = t * c;
+        app = app - t * apq; aqq = aqq + t * apq; apq = t_const<T>(0.0);
+        const T xr = apr, yr = aqr;
+        apr = c * xr - sn * yr; aqr = sn * xr + c * yr;
+        for (int k = 0; k < 3; ++k) {
+            const T vp = V[k][P], vq = V[k][Q];
+            V[k][P] = c * vp - sn * vq; V[k][Q] = sn * vp + c * vq;
+        }
+    };
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        rotate(a00, a11, a01, a02, a12, 0, 1);
+        rotate(a00, a22, a02, a01, a12, 0, 2);
+        rotate(a11, a22, a12, a01, a02, 1, 2);
+    }
+    lam[0] = a00; lam[1] = a11; lam[2] = a22;
+}
+
+template <class T>
+CM_D void barlat_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& phi, T gt[6]) {
+    const T& a = p.yc[18];
+    T lam[2][3], V[2][3][3], UL[2][3][3], csh[2][3];
+    for (int set = 0; set < 2; ++set) {
+        const T* q = p.yc + 9 * set;                             // c12, c13, c21, c23, c31, c32, c44, c55, c66
+        const double t3 = 1.0 / 3.0;
+        UL[set][0][0] = t3 * (q[0] + q[1]); UL[set][0][1] = t3 * (q[1] - 2.0 * q[0]); UL[set][0][2] = t3 * (q[0] - 2.0 * q[1]);
+        UL[set][1][0] = t3 * (q[3] - 2.0 * q[2]); UL[set][1][1] = t3 * (q[2] + q[3]); UL[set][1][2] = t3 * (q[2] - 2.0 * q[3]);
+        UL[set][2][0] = t3 * (q[5] - 2.0 * q[4]); UL[set][2][1] = t3 * (q[4] - 2.0 * q[5]); UL[set][2][2] = t3 * (q[4] + q[5]);
+        csh[set][0] = q[6]; csh[set][1] = q[7]; csh[set][2] = q[8];
+        T S6[6];
+        S6[0] = UL[set][0][0] * s[0] + UL[set][0][1] * s[3] + UL[set][0][2] * s[5];
+        S6[3] = UL[set][1][0] * s[0] + UL[set][1][1] * s[3] + UL[set][1][2] * s[5];
+        S6[5] = UL[set][2][0] * s[0] + UL[set][2][1] * s[3] + UL[set][2][2] * s[5];
+        S6[1] = q[6] * s[1]; S6[4] = q[7] * s[4]; S6[2] = q[8] * s[2];     // xy: c44, yz: c55, zx: c66
+        eig_sym3_T<T>(S6, lam[set], V[set]);
+    }
+    T Dm[3][3], u[3][3], ua[3][3], Ssum = t_const<T>(0.0);
+    double mx = 0.0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Dm[i][j] = lam[0][i] - lam[1][j]; mx = fmax(mx, fabs(t_val(Dm[i][j]))); }
+    const double imx = (mx > 0.0) ? 1.0 / mx : 0.0;             // a constant scale (no derivative parts): cancels analytically
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        u[i][j] = imx * t_abs(Dm[i][j]);
+        ua[i][j] = (t_val(u[i][j]) > 0.0) ? t_exp(a * t_log(u[i][j])) : t_const<T>(0.0);
+        Ssum = Ssum + ua[i][j];
+    }
+    Ssum = 0.25 * Ssum;
+    const T Sr = t_exp(t_log(Ssum) / a);
+    phi = mx * Sr;
+    // d phi / d lambda'_i = 1/4 sum_j sign r_ij^(a-1), r = u / Sr ; d phi / d lambda''_j = -(same, summed over i)
+    T f1[3] = {t_const<T>(0.0), t_const<T>(0.0), t_const<T>(0.0)}, f2[3] = {t_const<T>(0.0), t_const<T>(0.0), t_const<T>(0.0)};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        if (!(t_val(u[i][j]) > 0.0)) continue;
+        const double sg = (t_val(Dm[i][j]) > 0.0) ? 1.0 : -1.0;
+        const T qij = (0.25 * sg) * t_exp((a - 1.0) * (t_log(u[i][j]) - t_log(Sr)));
+        f1[i] = f1[i] + qij; f2[j] = f2[j] - qij;
+    }
+    for (int k = 0; k < 6; ++k) gt[k] = t_const<T>(0.0);
+    for (int set = 0; set < 2; ++set)
+        for (int i = 0; i < 3; ++i) {
+            const T* fx = set ? f2 : f1;
+            const T v0 = V[set][0][i], v1 = V[set][1][i], v2 = V[set][2][i];
+            const T mxx = v0 * v0, myy = v1 * v1, mzz = v2 * v2;     // gradient of lambda_i: L^T (w o V(v v^T)) (cm::barlat_pull)
+            gt[0] = gt[0] + fx[i] * (UL[set][0][0] * mxx + UL[set][1][0] * myy + UL[set][2][0] * mzz);
+            gt[3] = gt[3] + fx[i] * (UL[set][0][1] * mxx + UL[set][1][1] * myy + UL[set][2][1] * mzz);
+            gt[5] = gt[5] + fx[i] * (UL[set][0][2] * mxx + UL[set][1][2] * myy + UL[set][2][2] * mzz);
+            gt[1] = gt[1] + fx[i] * (csh[set][0] * (2.0 * (v0 * v1)));
+            gt[2] = gt[2] + fx[i] * (csh[set][2] * (2.0 * (v0 * v2)));
+            gt[4] = gt[4] + fx[i] * (csh[set][1] * (2.0 * (v1 * v2)));
+        }
+}
+
 // effective stress value and 6-vector gradient gt in arithmetic T (the closed forms of yield_eval)
 template <int YK, class T>
 CM_D void yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& phi, T gt[6]) {
-    if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
+    if constexpr (YK == CM_YIELD_BARLAT) {
+        barlat_T<T>(m, p, s, phi, gt);
+    } else if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
         yield_T<CM_YIELD_HILL, T>(m, p, s, phi, gt);
         T v, g6[6];
         icnn_yield_T<T>(m, p, s, v, g6);

@@ -96,6 +96,9 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_REV_HILL
 #define CM_OCC_REV_HILL 1
 #endif
+#ifndef CM_OCC_OBJ
+#define CM_OCC_OBJ 4
+#endif
 #ifndef CM_OCC_REV_J2_LS
 #define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
@@ -459,6 +462,7 @@ template <int DEF, int YK, bool LS, int MODE>
 constexpr int min_waves() {
     if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && LS) return CM_OCC_REV_J2_LS;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_HILL && !LS) return CM_OCC_REV_HILL;
+    if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && MODE == 1) return CM_OCC_OBJ;
     return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1;
 }
 
@@ -951,8 +955,8 @@ __global__ __launch_bounds__(256) void k_sum_rows(const double* __restrict__ par
 }
 
 // ---- extended parameter sensitivities: forward-mode evaluation of the whole model (cm::param_direction) ----------------
-// surfaces the arithmetic-T model (cm_hessian.hpp) covers: everything but Barlat (its eigen-decomposition is hand-derived only)
-constexpr bool has_generic_eval(int yk) { return yk != CM_YIELD_BARLAT; }
+// surfaces the arithmetic-T model (cm_hessian.hpp) covers: all of them (Barlat through a Jacobi eigen-decomposition in arithmetic T)
+constexpr bool has_generic_eval(int) { return true; }
 
 // cm_param_blocks: one thread per (point, requested parameter): dC/dp_e [n_xi] and d sigma/dp_e [6]
 template <int DEF, int YK, int MK>

@@ -235,7 +235,8 @@ def leaf_ep_index(path, info):
     if parent == "hill" and info.get("yield_type") == "hybrid":
         return _lib.P_YC0 + HILL_NAMES.index(names[-1])
     if parent == "barlat":
-        raise NotImplementedError("sensitivities w.r.t. the Barlat coefficients are not available in the HIP path")
+        i = BARLAT_NAMES.index(names[-1])                          # cm_model_desc.yc slot: 0..5 native slots, 6..18 extended
+        return _lib.P_YC0 + i if i < 6 else EP_YC6 + (i - 6)
     return None
 
 

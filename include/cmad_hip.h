@@ -251,7 +251,7 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which,
  * q = [xi (n_xi), xi_prev (n_xi), p (CM_NUM_PARAMS, KP order, native lambda/mu)], n_q = 2 n_xi + CM_NUM_PARAMS.
  * Replaces Model.evaluate_hessians() (cmad/models/model.py:133-147, 245-270: jax.hessian / jacrev(jacfwd) of
  * the residual) and the stress part of QoI.evaluate_hessians() (cmad/qois/qoi.py:160-188), total-form model,
- * J2 / Hill / Hosford.  Outputs are point-major (array of structures; B is small for this call), row-major:
+ * every yield surface (hyper-dual evaluation of the arithmetic-T model, one pair of variables per thread).  Outputs are point-major (array of structures; B is small for this call), row-major:
  *   d2C[B][n_xi][n_q][n_q], d2S[B][6][n_q][n_q], dC[B][n_xi][n_q], dS[B][6][n_q]      (any may be NULL)
  * dC / dS are the first derivatives produced by the same pass (for cross-checks against cm_evaluate).
  */
@@ -260,7 +260,7 @@ int cm_hessians(const cm_model_desc* m, int64_t B,
                 double* d2C, double* d2S, double* dC, double* dS, void* stream);
 
 /*
- * Reverse-mode entry points of the rate-form model (FULL_3D, PLANE_STRESS; J2 / Hill / Hosford): cm_update_vjp,
+ * Reverse-mode entry points of the rate-form model (FULL_3D, PLANE_STRESS, UNIAXIAL_STRESS; J2 / Hill / Hosford): cm_update_vjp,
  * cm_update_and_vjp, cm_objective_grad and cm_adjoint_step with the additional input gradu_prev[n_gradu][B].
  * Same outputs and conventions; gradu_bar is the cotangent of grad u, the one of grad u_prev is its negative
  * (the residual sees grad u - grad u_prev only).  They replace the same reference lines as their total-form
@@ -288,10 +288,10 @@ int cm_adjoint_step_rate(const cm_model_desc* m, int64_t B,
 /*
  * cm_hessians_rate: cm_hessians for the rate-form model (small_rate_elastic_plastic.py:249-359), whose residual
  * also takes the previous grad u -- what the reference's Hessian checks run on SmallRateElasticPlastic
- * (tests/objectives/test_J2_fd_checks.py:303-392).  All three deformation types; under UNIAXIAL_STRESS the rate
- * form has 12 local dofs (stress 6, alpha, two off-axis stretches, three off-axis strain increments, :171-196) and
- * this entry point -- residual values, first and second derivatives by dual-number evaluation -- is how that
- * variant is served (the hand-derived kernels cm_update_rate / cm_evaluate_rate cover FULL_3D and PLANE_STRESS).
+ * (tests/objectives/test_J2_fd_checks.py:303-392).  All three deformation types (J2 / Hill / Hosford); under
+ * UNIAXIAL_STRESS the rate form has 12 local dofs (stress 6, alpha, two off-axis stretches, three off-axis strain
+ * increments, :171-196).  The other rate-form entry points serve that variant too: their derivative blocks come from
+ * forward-mode evaluation of the same residual inside the kernels (cmad_amd/csrc/cm_rate_uniaxial.hpp).
  *   out (all optional): d2C, d2S, dC, dS as cm_hessians; C0[B][n_xi] residual values, sigma0[B][6] global stress.
  */
 int cm_hessians_rate(const cm_model_desc* m, int64_t B,
@@ -392,7 +392,7 @@ int cm_direct_history(const cm_model_desc* m, int64_t B, int32_t K,
  *   in : gradu_hist, xi_hist (converged), lam_hist (cm_adjoint_history), dxi_dp_hist (cm_direct_history), sigma_bar_hist
  *   out: hess_pp[CM_NUM_PARAMS * CM_NUM_PARAMS] row-major, KP order
  *   workspace: cm_hessian_workspace_bytes(m, B, K)
- * J2 / Hill / Hosford and the network surfaces; both model kinds (rate form: FULL_3D, PLANE_STRESS, J2 / Hill / Hosford).
+ * Every yield surface; both model kinds (rate form: FULL_3D, PLANE_STRESS, J2 / Hill / Hosford).
  */
 int64_t cm_hessian_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K);
 int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K,
@@ -403,11 +403,11 @@ int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K,
 /*
  * Extended parameter sensitivities.  The hand-derived kernels differentiate w.r.t. the 12 native parameters of
  * cm_param_index; the reference differentiates w.r.t. EVERY leaf of the params pytree (jacrev in cmad/models/model.py:125-153,
- * flattened by cmad/parameters/parameters.py:368-377).  The remaining leaves -- rotation matrix, Hosford exponent, Hill
- * coefficients of the network surfaces, network weights -- are served by forward-mode evaluation of the whole model
+ * flattened by cmad/parameters/parameters.py:368-377).  The remaining leaves -- rotation matrix, Hosford exponent, Barlat
+ * coefficients, Hill coefficients of the network surfaces, network weights -- are served by forward-mode evaluation of the whole model
  * (residual, kinematics with the rotation matrix, global stress) in dual-number arithmetic, one direction per thread.
  * Extended parameter ("EP") index: 0..11 = cm_param_index; 12..24 = yc[6..18]; 25..33 = Q[0..8] (row-major);
- * 34 + i = packed network weight i (W0[6][H], b0[H], Wx1[6], b1, Wz[H]).  All surfaces but Barlat; both model kinds
+ * 34 + i = packed network weight i (W0[6][H], b0[H], Wx1[6], b1, Wz[H]).  Every yield surface (Barlat through a Jacobi eigen-decomposition in dual arithmetic); both model kinds
  * (the rate form under UNIAXIAL_STRESS included).
  *
  * cm_param_blocks: dC/dp_e and d sigma/dp_e at given states (the DPARAMS blocks of Model.evaluate / evaluate_cauchy,

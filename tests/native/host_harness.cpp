@@ -246,7 +246,7 @@ template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                          double* d2C, double* d2S, double* dC, double* dS, double* C0 = nullptr, double* S0 = nullptr) {
     constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
-    if constexpr (YK != CM_YIELD_BARLAT && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(YK))) {
+    if constexpr (!(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(YK))) {
         for (int64_t pt = 0; pt < B; ++pt) {
             double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6], oC0[NX], oS0[6];
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt] - (gradu_prev ? gradu_prev[k * B + pt] : 0.0);
@@ -520,7 +520,7 @@ int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* g
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
-    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (Y != CM_YIELD_BARLAT) body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
 #if HH_HAS(5)
@@ -540,7 +540,7 @@ int hh_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* 
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
-    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (Y != CM_YIELD_BARLAT) body.template operator()<D, Y, CM_SMALL_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
 #if HH_HAS(0)

@@ -900,3 +900,58 @@ def check_second_derivs_network(hessians, def_type=ol.FULL_3D, scaled=False, see
     for which, lo in ((ol.W_XI, 0), (ol.W_XI_PREV, nx)):
         Jo = mat.jacobian(which, xi, xp, U)
         np.testing.assert_allclose(dC[0][:, lo:lo + nx], Jo, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Jo).max()))
+
+
+def check_barlat_generic(hessians, param_blocks, def_type=ol.FULL_3D, seed=4):
+    """Barlat Yld2004-18p through the arithmetic-T model (Jacobi eigen-decomposition in dual arithmetic): `cm_hessians` against
+    the oracle's nested duals (its eigh derivative rule), `cm_param_blocks` w.r.t. all 19 coefficients against central
+    differences of the oracle's residual (the oracle keeps them outside its differentiable vector) and w.r.t. the rotation
+    matrix against the oracle's AD."""
+    from cmad_amd.models.device import BARLAT_NAMES, build_desc
+    rng = np.random.default_rng(seed)
+    coeffs = np.asarray(AL7079_BARLAT, dtype=float)
+    values = _lame_values(rng, "barlat", {"barlat": coeffs})
+
+    def material(c):
+        v = {**values, "plastic": {**values["plastic"], "effective stress": {"barlat": dict(zip(BARLAT_NAMES, [float(x) for x in c]))}}}
+        return ol.Material(v, def_type=def_type, uniaxial_idx=1)
+    mat = material(coeffs)
+    desc, info = build_desc(values, def_type=def_type, uniaxial_stress_idx=1)
+    nx, nu = mat.nx, mat.nu
+    Y, mu = values["plastic"]["flow stress"]["initial yield"]["Y"], values["elastic"]["mu"]
+    for _ in range(200):
+        U = rng.normal(size=nu) * 1.5 * Y / (2 * mu)
+        xp = np.r_[np.zeros(6), 0.0, np.ones(nx - 7)]
+        xi = xp.copy(); xi[:6] = rng.normal(size=6) * 2e-4; xi[6] = abs(rng.normal()) * 2e-4
+        if mat.yield_state(xi, U)[1] > 1e-5:
+            break
+    else:
+        raise AssertionError("no plastic state")
+    d2C, d2S, dC, dS = hessians(desc, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    oC, oS = mat.second_derivs(xi, xp, U)
+    # q = [xi, xi_prev, lambda, mu, Y, S, D, K]: the yc slots of KP hold the first six Barlat coefficients (oracle: outside p)
+    keep = list(range(2 * nx + 6))
+    qmap = list(range(2 * nx)) + [2 * nx + j for j in KP2O[:6]]
+    refC = oC[:, qmap][:, :, qmap]
+    refS = oS[_V6_OF_9][:, qmap][:, :, qmap]
+    sel = np.ix_(range(nx), keep, keep)
+    np.testing.assert_allclose(d2C[0][sel], refC, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(refC).max()))
+    sel6 = np.ix_(range(6), keep, keep)
+    np.testing.assert_allclose(d2S[0][sel6], refS, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(refS).max()))
+    for which, lo in ((ol.W_XI, 0), (ol.W_XI_PREV, nx)):
+        Jo = mat.jacobian(which, xi, xp, U)
+        np.testing.assert_allclose(dC[0][:, lo:lo + nx], Jo, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Jo).max()))
+    # first-order: the 19 coefficients (EP 6..11, 12..24) by central differences, the rotation matrix by the oracle's AD
+    ep = [6 + i for i in range(6)] + [12 + i for i in range(13)] + [EP_Q0 + i for i in range(9)]
+    dCp, dSp = param_blocks(desc, ep, U.reshape(-1, 1), xp.reshape(-1, 1), xi.reshape(-1, 1), nx)
+    for i in range(19):
+        h = 1e-6 * max(1.0, abs(coeffs[i]))
+        cp, cm_ = coeffs.copy(), coeffs.copy()
+        cp[i] += h; cm_[i] -= h
+        fd = (material(cp).residual(xi, xp, U) - material(cm_).residual(xi, xp, U)) / (2 * h)
+        np.testing.assert_allclose(dCp[i, :, 0], fd, rtol=2e-5, atol=1e-9 * max(1.0, np.abs(fd).max()))
+    oc = [ol.P_Q + i for i in range(9)]
+    Jq = mat.jacobian(ol.W_PARAMS, xi, xp, U)[:, oc]
+    Sq = mat.dcauchy(ol.W_PARAMS, xi, xp, U)[_V6_OF_9][:, oc]
+    np.testing.assert_allclose(dCp[19:, :, 0].T, Jq, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Jq).max()))
+    np.testing.assert_allclose(dSp[19:, :, 0].T, Sq, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Sq).max()))

@@ -567,8 +567,9 @@ def test_evaluate_hessians_shapes_and_errors():
     bvals["plastic"]["effective stress"] = {"barlat": dict(zip(BARLAT_NAMES, [1.0] * 18 + [8.0]))}
     bmodel = SmallElasticPlastic(Parameters(bvals), DefType.FULL_3D)
     bmodel.gather_global(mp_U_from_F(np.eye(3) + G), mp_U_from_F(np.eye(3)))
-    with pytest.raises(NotImplementedError):                                    # Barlat: hand-derived first and second derivatives only
-        bmodel.evaluate_hessians()
+    bmodel.set_scalar_xi(1, np.array([2e-4]))
+    bmodel.evaluate_hessians()                                                  # Barlat: Jacobi eigen-decomposition in arithmetic T
+    assert bmodel.d2C_dxi2.shape == (7, 7, 7) and np.isfinite(bmodel.d2C_dxi2).all()     # values: test_barlat_second_derivatives_...
 
 
 def test_jvp_objective_agrees_with_direct_adjoint():

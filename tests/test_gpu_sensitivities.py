@@ -421,3 +421,11 @@ def test_second_derivatives_network_surfaces(def_type, scaled):
     (reference model.py:133-147 has no restriction on the yield surface)."""
     import gpu_api
     pc.check_second_derivs_network(gpu_api.hessians, def_type, scaled=scaled)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_barlat_second_derivatives_and_coefficient_sensitivities(def_type):
+    """Barlat Yld2004-18p through the arithmetic-T model on the GPU: `cm_hessians` against the oracle's nested duals,
+    `cm_param_blocks` w.r.t. its 19 coefficients (central differences of the oracle) and the rotation matrix (oracle AD)."""
+    import gpu_api
+    pc.check_barlat_generic(gpu_api.hessians, gpu_api.param_blocks, def_type)

@@ -437,3 +437,12 @@ def test_second_derivatives_network_surfaces(def_type, scaled, solver_variant):
     if solver_variant != "structured":
         pytest.skip("not solver dependent")
     pc.check_second_derivs_network(hh.hessians, def_type, scaled=scaled)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_barlat_second_derivatives_and_coefficient_sensitivities(def_type, solver_variant):
+    """Barlat Yld2004-18p in the arithmetic-T model (host build): Hessians vs the oracle, coefficient sensitivities vs FD."""
+    import host_harness_lib as hh
+    if solver_variant != "structured":
+        pytest.skip("not solver dependent")
+    pc.check_barlat_generic(hh.hessians, hh.param_blocks, def_type)
