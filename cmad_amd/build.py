@@ -6,7 +6,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcmad_hip.so")
 SOURCES = ["cmad_hip.hip"]
-HEADERS = ["cm_device.hpp", "cm_structured.hpp", "cm_hessian.hpp", os.path.join("..", "..", "include", "cmad_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "cmad_hip.h")]
 
 
 def hipcc_path():

@@ -96,9 +96,6 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_REV_HILL
 #define CM_OCC_REV_HILL 1
 #endif
-#ifndef CM_OCC_OBJ
-#define CM_OCC_OBJ 4
-#endif
 #ifndef CM_OCC_REV_J2_LS
 #define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
@@ -462,7 +459,6 @@ template <int DEF, int YK, bool LS, int MODE>
 constexpr int min_waves() {
     if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && LS) return CM_OCC_REV_J2_LS;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_HILL && !LS) return CM_OCC_REV_HILL;
-    if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && MODE == 1) return CM_OCC_OBJ;
     return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1;
 }
 

@@ -1,0 +1,126 @@
+// HBM streaming ceilings for the SoA access patterns of the cmad kernels (no arithmetic beyond a sum): what fraction of the
+// 8 TB/s peak a kernel with this layout, block size and per-lane load width can reach at all on this card.
+//   hipcc -O3 --offload-arch=gfx950 tools/microbench/hbm_stream.hip -o tools/microbench/hbm_stream && tools/microbench/hbm_stream [points]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ inline double ldnt(const double* p) { return __builtin_nontemporal_load(p); }
+
+// one point per lane, NR rows read at stride B, NW rows written at stride B (the layout of k_reverse / k_update)
+template <int NR, int NW, bool NT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void soa_rows(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ sink, int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    double v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = NT ? ldnt(in + r * B + b) : in[r * B + b];
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s += v[r];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (NT) __builtin_nontemporal_store(s + w, out + w * B + b); else out[w * B + b] = s + w;
+    }
+    if (NW == 0 && s == 1.2345e301) sink[0] = s;
+}
+
+// two points per lane (16-byte loads), same rows
+template <int NR, int NW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void soa_rows_x2(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ sink, int64_t B) {
+    const int64_t b = 2 * ((int64_t)blockIdx.x * BLOCK + threadIdx.x);
+    if (b + 1 >= B) return;
+    d2 v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = __builtin_nontemporal_load((const d2*)(in + r * B + b));
+    d2 s = {0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { s.x += v[r].x; s.y += v[r].y; }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { d2 o = {s.x + w, s.y + w}; __builtin_nontemporal_store(o, (d2*)(out + w * B + b)); }
+    if (NW == 0 && s.x + s.y == 1.2345e301) sink[0] = s.x;
+}
+
+// persistent grid-stride version of soa_rows (tiles of BLOCK points)
+template <int NR, int NW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void soa_rows_persistent(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ sink, int64_t B) {
+    double acc = 0.0;
+    for (int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x; b < B; b += (int64_t)gridDim.x * BLOCK) {
+        double v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[r] = ldnt(in + r * B + b);
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) s += v[r];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) __builtin_nontemporal_store(s + w, out + w * B + b);
+        acc += s;
+    }
+    if (NW == 0 && acc == 1.2345e301) sink[0] = acc;
+}
+
+// flat read of n doubles, 16 B per lane per load, grid-stride
+__global__ __launch_bounds__(256) void flat_read(const d2* __restrict__ in, double* __restrict__ sink, int64_t n2) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        d2 v = __builtin_nontemporal_load(in + i);
+        acc += v.x + v.y;
+    }
+    if (acc == 1.2345e301) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void flat_copy(const d2* __restrict__ in, d2* __restrict__ out, int64_t n2) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
+template <class F>
+double time_us(F&& launch, int reps = 20) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0, 0)); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms[i], e0, e1));
+    }
+    CK(hipGetLastError());
+    double s = 0; for (float m : ms) s += m;
+    return 1e3 * s / reps;
+}
+
+int main(int argc, char** argv) {
+    const int64_t B = argc > 1 ? atoll(argv[1]) : 10000000;
+    constexpr int NRMAX = 22, NWMAX = 13;
+    double *in, *out, *sink;
+    CK(hipMalloc(&in, sizeof(double) * NRMAX * B)); CK(hipMalloc(&out, sizeof(double) * NWMAX * B)); CK(hipMalloc(&sink, 64));
+    CK(hipMemset(in, 0, sizeof(double) * NRMAX * B)); CK(hipMemset(out, 0, sizeof(double) * NWMAX * B));
+    auto report = [&](const char* name, double bytes, double us) { printf("%-58s %8.1f us  %7.1f GB/s  %.3f of 8 TB/s\n", name, us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0); };
+    const int64_t nb128 = (B + 127) / 128, nb256 = (B + 255) / 256, nb64 = (B + 63) / 64;
+    report("objective layout: 22 rows read, 1 pt/lane, block 128, nt", 176.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 0, true, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
+    report("objective layout: 22 rows read, 1 pt/lane, block 128", 176.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 0, false, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
+    report("objective layout: 22 rows read, 1 pt/lane, block 256, nt", 176.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 0, true, 256>), dim3(nb256), dim3(256), 0, 0, in, out, sink, B); }));
+    report("objective layout: 22 rows read, 1 pt/lane, block 64, nt", 176.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 0, true, 64>), dim3(nb64), dim3(64), 0, 0, in, out, sink, B); }));
+    report("objective layout: 22 rows read, 2 pt/lane (16 B loads)", 176.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_x2<22, 0, 128>), dim3((B / 2 + 127) / 128), dim3(128), 0, 0, in, out, sink, B); }));
+    for (int g : {256 * 4, 256 * 8, 256 * 16, 256 * 32})  {
+        char nm[96]; snprintf(nm, sizeof nm, "objective layout: persistent, %d blocks of 128", g);
+        report(nm, 176.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_persistent<22, 0, 128>), dim3(g), dim3(128), 0, 0, in, out, sink, B); }));
+    }
+    report("headline layout: 22 rows read + 13 written, block 128, nt", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 13, true, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
+    report("headline layout: 22 rows read + 13 written, block 128", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 13, false, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
+    report("headline layout: 2 pt/lane (16 B accesses)", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_x2<22, 13, 128>), dim3((B / 2 + 127) / 128), dim3(128), 0, 0, in, out, sink, B); }));
+    report("headline layout: persistent, 4096 blocks of 128", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_persistent<22, 13, 128>), dim3(4096), dim3(128), 0, 0, in, out, sink, B); }));
+    report("update layout: 16 rows read + 13 written, block 128, nt", 232.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<16, 13, true, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
+    const int64_t n2 = (int64_t)NRMAX * B / 2;
+    for (int g : {256 * 8, 256 * 32, 256 * 128}) {
+        char nm[96]; snprintf(nm, sizeof nm, "flat read, 16 B/lane, %d blocks of 256", g);
+        report(nm, 16.0 * n2, time_us([&] { hipLaunchKernelGGL(flat_read, dim3(g), dim3(256), 0, 0, (const d2*)in, sink, n2); }));
+    }
+    const int64_t c2 = (int64_t)NWMAX * B / 2;
+    report("flat copy, 16 B/lane, 8192 blocks of 256", 32.0 * c2, time_us([&] { hipLaunchKernelGGL(flat_copy, dim3(8192), dim3(256), 0, 0, (const d2*)in, (d2*)out, c2); }));
+    return 0;
+}
