@@ -27,6 +27,11 @@ BYTES_PER_UPDATE = 280           # read gradu 72 + xi_prev 56 + 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+# GB/s of a kernel that only reads / writes the same SoA rows (profiles/r02_hbm_stream_ceilings.txt, 10^7 points)
+LAYOUT_CEILING_GBS = {("j2_update_vjp", "full_3d"): 6331.0, ("j2_objective_grad", "full_3d"): 6919.0,
+                      ("j2_update", "full_3d"): 6464.0}
+
+
 def effective_cores():
     """Host cores this process can really use: the affinity mask, capped by the cgroup CPU quota (a GPU box exposes
     all of the host's hardware threads in the mask but grants the job only a share of them)."""
@@ -205,8 +210,8 @@ def main():
     ap.add_argument("--def-type", default="full_3d", choices=["full_3d", "plane_stress"],
                     help="J2 workloads: plane_stress is a side measurement (the reference's material-point tests' type)")
     ap.add_argument("--workload", default="j2_update_vjp",
-                    choices=["j2_update_vjp", "j2_update", "j2_objective_grad", "hosford_update", "hybrid_update",
-                             "ps_calibration_history"],
+                    choices=["j2_update_vjp", "j2_update", "j2_update_tangent", "j2_objective_grad", "hosford_update",
+                             "hybrid_update", "ps_calibration_history"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
     args = ap.parse_args()
 
@@ -275,12 +280,16 @@ def main():
         newton = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})
     if wl in ("j2_update", "hosford_update", "hybrid_update"):
         bytes_per_update = 232                     # read gradu 72 + xi_prev 56, write xi 56 + sigma 48
+    elif wl == "j2_update_tangent":                # the FE caller's per-integration-point kernel
+        bytes_per_update = 232 + 6 * 9 * 8         # + d sigma / d grad u, 54 rows written
     elif wl == "j2_objective_grad":
         bytes_per_update = 176                     # read gradu 72 + xi_prev 56 + data 48, no per-point writes
     ps = args.def_type == "plane_stress"
     if ps:
         assert wl.startswith("j2_"), "--def-type plane_stress applies to the J2 workloads"
         bytes_per_update += 8 * (-5 - 5 + 1 + 1)   # grad u 9 -> 4 doubles, xi / xi_prev 7 -> 8 doubles
+        if wl == "j2_update_tangent":
+            bytes_per_update -= 8 * 6 * 5          # d sigma / d grad u: 6 x 4 rows
         if wl == "j2_objective_grad":
             bytes_per_update -= 8                  # no xi written
     from cmad_amd.models.deformation_types import DefType
@@ -305,6 +314,8 @@ def main():
     out = {"xi": torch.empty((nxi, B), dtype=torch.float64, device=dev),
            "sigma": torch.empty((6, B), dtype=torch.float64, device=dev),
            "grad": torch.empty(12, dtype=torch.float64, device=dev)}
+    if wl == "j2_update_tangent":
+        out["dsigma"] = torch.empty((6 * (4 if ps else 9), B), dtype=torch.float64, device=dev)
 
     # two result buffers: the all-reduce of step k (RCCL's own stream) overlaps the kernel of step k+1
     grads = [torch.empty(12, dtype=torch.float64, device=dev) for _ in range(2)]
@@ -324,7 +335,7 @@ def main():
         if wl == "j2_objective_grad":              # sigma_bar doubles as the "measured stress" array
             ev.objective_grad(gradu, xi_prev, sigma_bar, wsq6, out=res13[i])
             return res13[i]
-        ev.update(gradu, xi_prev, want_status=False, out=out)
+        ev.update(gradu, xi_prev, want_status=False, out=out, tangent=(wl == "j2_update_tangent"))
         return None
 
     def reduce_async(k, r):
@@ -433,6 +444,8 @@ def main():
                 "workload": {"j2_update_vjp": "J2 isotropic-hardening (Voce) stress update + vjp w.r.t. parameters, FULL_3D, "
                                               "synthetic Gauss points fp64 (BASELINE.json configs[1])",
                              "j2_update": "J2 + Voce stress update only, FULL_3D (side measurement)",
+                             "j2_update_tangent": "J2 + Voce stress update + consistent tangent d sigma / d grad u (the FE "
+                                                  "caller's per-integration-point call; side measurement)",
                              "j2_objective_grad": "fused J2 calibration objective + gradient, single step (configs[4] per GPU)",
                              "hosford_update": "Hosford a=100 stress update, notch_hosford.yaml material (configs[2])",
                              "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])"}[wl],
@@ -454,6 +467,8 @@ def main():
                                     "k_reverse<J2,noROT,fused update+vjp>",
                                     "j2_objective_grad": "k_reverse<FULL_3D,J2,noROT,fused objective+grad>"}.get(wl, "k_update"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_update": bytes_per_update,
+                         # what the same rows stream at with no arithmetic (tools/microbench/hbm_stream.hip)
+                         "layout_streaming_ceiling": LAYOUT_CEILING_GBS.get((wl, args.def_type)),
                          "interval": "ms_per_step (same wall-clock interval as value)",
                          "kernel_only": {"ms": kernel_ms, "achieved": achieved_kernel, "frac": achieved_kernel / HBM_PEAK_GBS,
                                          "how": "mean HIP-event duration of one step on the launch stream"}},

@@ -325,7 +325,8 @@ class DeviceEvaluator:
         status = (o.get("status") if o.get("status") is not None else
                   torch.empty((B,), dtype=torch.int32, device=dev)) if want_status else None
         if tangent:
-            ds = torch.empty((6 * self.nu, B), dtype=torch.float64, device=dev)
+            ds = o.get("dsigma") if o.get("dsigma") is not None else torch.empty((6 * self.nu, B), dtype=torch.float64, device=dev)
+            _check_soa(ds, 6 * self.nu, B, "dsigma")
             rc = self.L.cm_update_tangent(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma),
                                           _ptr(ds), _ptr(status), self._stream())
             _lib.check(rc, "cm_update_tangent")

@@ -18,9 +18,8 @@ NPARTS = 7          # host_harness.cpp compiles in independent pieces selected b
 
 def build(force=False, sanitize=False):
     src = os.path.join(_DIR, "host_harness.cpp")
-    deps = [src, os.path.join(_ROOT, "cmad_amd", "csrc", "cm_device.hpp"), os.path.join(_ROOT, "cmad_amd", "csrc", "cm_structured.hpp"),
-            os.path.join(_ROOT, "cmad_amd", "csrc", "cm_hessian.hpp"), os.path.join(_ROOT, "cmad_amd", "csrc", "cm_pool.hpp"),
-            os.path.join(_ROOT, "include", "cmad_hip.h")]
+    csrc = os.path.join(_ROOT, "cmad_amd", "csrc")
+    deps = [src, os.path.join(_ROOT, "include", "cmad_hip.h")] + [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hpp")]
     out = _SO if not sanitize else os.path.join(_DIR, "libhost_harness_asan.so")
     stale = (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
     if force or stale:
