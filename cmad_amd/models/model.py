@@ -338,11 +338,13 @@ class Model(ABC):
 
     def dC_dp(self, xi, xi_prev, params, U, U_prev):
         """d C / d params as a tree parallel to `params` (reference model.py:316-374: jacrev w.r.t. the params
-        pytree): leaf shape (n_xi,) + leaf.shape.  Leaves the kernels have no sensitivity for (rotation matrix,
-        Hosford exponent, Barlat coefficients, network weights, Hill coefficients of the network surfaces) come
-        back filled with NaN rather than with a silent zero."""
+        pytree): leaf shape (n_xi,) + leaf.shape.  The 12 native kernel parameters come from `cm_evaluate`'s hand-derived
+        block; rotation-matrix entries, the Hosford exponent, Barlat coefficients, Hill coefficients of the network surfaces
+        and network weights from one `cm_param_blocks` launch (forward-mode evaluation of the model).  A leaf neither covers
+        (none in the reference's models) comes back filled with NaN rather than with a silent zero."""
         _, J, _, _, info = self._point_evaluate(DerivType.DPARAMS, xi, xi_prev, params, U, U_prev=U_prev)
         n = self.num_dofs
+        pending = []                                              # (output array, flat element, EP index)
 
         def walk(node, path):
             if isinstance(node, dict):
@@ -352,10 +354,24 @@ class Model(ABC):
             shape = np.shape(node)
             try:
                 col = np.asarray(kp_to_leaf_grad(path, J.T, info), dtype=np.float64)
+                return np.broadcast_to(col.reshape((n,) + (1,) * len(shape)), (n,) + shape).copy()
             except (NotImplementedError, KeyError):
-                return np.full((n,) + shape, np.nan)
-            return np.broadcast_to(col.reshape((n,) + (1,) * len(shape)), (n,) + shape).copy()
-        return walk(params, ())
+                pass
+            out = np.full((n,) + shape, np.nan)
+            size = int(np.prod(shape)) if shape else 1
+            try:
+                eps = [leaf_ep_index(path + ((e,) if shape else ()), info) for e in range(size)]
+            except (NotImplementedError, KeyError, ValueError, IndexError):
+                return out
+            if all(e is not None for e in eps):
+                pending.extend((out, e, ep) for e, ep in enumerate(eps))
+            return out
+        tree = walk(params, ())
+        if pending:
+            dC, _ = self._extended_blocks([ep for _, _, ep in pending], xi, xi_prev, params, U, U_prev)
+            for i, (out, e, _) in enumerate(pending):
+                out.reshape(n, -1)[:, e] = dC[i]
+        return tree
 
     def dC_dU(self, xi, xi_prev, params, U, U_prev):
         J = self._point_evaluate(DerivType.DU, xi, xi_prev, params, U, U_prev=U_prev)[1]

@@ -209,6 +209,15 @@ def test_local_equilibrium_and_ift_tangent_vs_fd():
     np.testing.assert_allclose(ds, fd, rtol=1e-5, atol=1e-7 * np.abs(fd).max())
 
 
+def test_named_derivatives_parallel_their_inputs():
+    """The reference's tests/models/test_abc_contract.py:31-65 through the HIP library: dC_dxi / dC_dxi_prev / dC_dp / dC_dU /
+    dC_dU_prev are trees parallel to their inputs; dC_dp covers the native leaves (cm_evaluate) and the rotation matrix
+    (cm_param_blocks), both against central differences of the residual."""
+    from cmad_amd.models import SmallElasticPlastic
+    from problems import check_named_derivatives
+    check_named_derivatives(SmallElasticPlastic)
+
+
 def test_facade_error_behaviour():
     from cmad_amd.models import DefType, SmallElasticPlastic
     with pytest.raises(NotImplementedError):

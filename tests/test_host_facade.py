@@ -78,50 +78,9 @@ def test_gradients_and_hessian(active_elastic):
     np.testing.assert_allclose(ga, g_fd, rtol=1e-5, atol=1e-7 * np.abs(ga).max())
 
 
-def _same_structure(a, b):
-    if isinstance(a, dict):
-        return isinstance(b, dict) and list(a) == list(b) and all(_same_structure(a[k], b[k]) for k in a)
-    if isinstance(a, (list, tuple)):
-        return isinstance(b, (list, tuple)) and len(a) == len(b) and all(_same_structure(x, y) for x, y in zip(a, b))
-    return not isinstance(b, (dict, list, tuple))
-
-
 def test_named_derivatives_parallel_their_inputs():
-    """The reference's tests/models/test_abc_contract.py:31-65: dC_dxi / dC_dxi_prev / dC_dp / dC_dU / dC_dU_prev
-    return trees parallel to xi / xi_prev / params / U / U_prev -- plus the values against finite differences."""
-    from cmad_amd.models import DefType, mp_U_from_F
-    model = HostSmallElasticPlastic(params_J2_voce(), DefType.FULL_3D)
-    model.set_xi_to_init_vals()
-    F = np.eye(3) + 0.004 * np.diag([1.0, -0.4, -0.3])                     # plastic step
-    model.gather_global(mp_U_from_F(F), mp_U_from_F(np.eye(3)))
-    xi, xi_prev, params, U, U_prev = model.variables()
-    xi = [xi[0] + 1e-4 * np.array([1.0, 0.2, 0.0, -0.5, 0.1, -0.5]), xi[1] + 1e-3]
-    assert _same_structure(model.dC_dxi(xi, xi_prev, params, U, U_prev), xi)
-    assert _same_structure(model.dC_dxi_prev(xi, xi_prev, params, U, U_prev), xi_prev)
-    dU = model.dC_dU(xi, xi_prev, params, U, U_prev)
-    assert set(dU.fields) == set(U.fields) and set(dU.grad_fields) == set(U.grad_fields)
-    dUp = model.dC_dU_prev(xi, xi_prev, params, U, U_prev)
-    assert dUp.grad_fields["u"].shape == (7, 3, 3) and not dUp.grad_fields["u"].any()
-    dp = model.dC_dp(xi, xi_prev, params, U, U_prev)
-    assert _same_structure(dp, params)
-    assert dp["rotation matrix"].shape == (7, 3, 3) and np.isnan(dp["rotation matrix"]).all()
-    assert dp["plastic"]["effective stress"]["J2"].shape == (7,) and not dp["plastic"]["effective stress"]["J2"].any()
-    # d C / d Y and d C / d E against central differences of the residual
-    import copy
-    for path, h in ((("plastic", "flow stress", "initial yield", "Y"), 1e-4), (("elastic", "E"), 1e-1)):
-        def C_at(delta):
-            p2 = copy.deepcopy(params)
-            node = p2
-            for k in path[:-1]:
-                node = node[k]
-            node[path[-1]] = node[path[-1]] + delta
-            r = model._residual(xi, xi_prev, p2, U, U_prev)
-            return np.concatenate([np.atleast_1d(b) for b in r]) if isinstance(r, (list, tuple)) else np.asarray(r)
-        fd = (C_at(h) - C_at(-h)) / (2 * h)
-        leaf = dp
-        for k in path:
-            leaf = leaf[k]
-        np.testing.assert_allclose(leaf, fd, rtol=1e-6, atol=1e-12)
+    from problems import check_named_derivatives
+    check_named_derivatives(HostSmallElasticPlastic)
 
 
 @pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("hosford", True)])

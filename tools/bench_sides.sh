@@ -4,6 +4,8 @@ run() { python bench.py --no-cpu-baseline --steps 10 "$@" 2>/dev/null | python3 
 run --workload j2_update_vjp
 run --workload j2_update_vjp --ls-evals 4
 run --workload j2_update
+run --workload j2_update_tangent
+run --workload j2_update_tangent --def-type plane_stress
 run --workload j2_update --ls-evals 4
 run --workload j2_objective_grad
 run --workload j2_objective_grad --ls-evals 4
