@@ -448,12 +448,17 @@ def main():
                                                   "caller's per-integration-point call; side measurement)",
                              "j2_objective_grad": "fused J2 calibration objective + gradient, single step (configs[4] per GPU)",
                              "hosford_update": "Hosford a=100 stress update, notch_hosford.yaml material (configs[2])",
-                             "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])"}[wl],
+                             "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])"}[wl]
+                            .replace("FULL_3D", "PLANE_STRESS (side measurement)" if ps else "FULL_3D")
+                            .replace(" (BASELINE.json configs[1])", "" if (ps or args.yield_surface != "j2") else " (BASELINE.json configs[1])"),
                 "def_type": args.def_type, "yield_surface": args.yield_surface, "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
                 "point_order": "sorted by deviatoric strain (coherent wavefronts)" if args.coherent else "uncorrelated",
                 "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
                            "line_search_max_evals": newton.line_search["max evals"],
-                           "solver": ("general 7-dof Newton, structured block solve"
+                           "solver": ("8-dof Newton in the coordinates of the J2 plane it never leaves (identical iterates and "
+                                      "iteration counts; CM_SOLVER_GENERAL_NEWTON turns it off)"
+                                      if (ps and args.yield_surface == "j2" and wl.startswith("j2_") and not (args.general_newton or args.ls_evals > 0)) else
+                                      "general 7-dof Newton, structured block solve"
                                       if (args.general_newton or args.ls_evals > 0 or ps or not wl.startswith("j2_")) else
                                       "7-dof Newton restricted to the J2 radial line it never leaves (identical iterates "
                                       "and iteration counts; CM_SOLVER_GENERAL_NEWTON turns it off)")},
@@ -461,7 +466,7 @@ def main():
                                "step, double-buffered so it overlaps the next step's kernel",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(B) if wl == "j2_update_vjp" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(B) if (wl == "j2_update_vjp" and not ps and args.yield_surface == "j2") else None,
                          "kernel": {"j2_update_vjp": "k_reverse<FULL_3D,J2,noROT,noLS,fused update+vjp,radial-line>"
                                     if not (args.general_newton or args.ls_evals > 0 or ps) else
                                     "k_reverse<J2,noROT,fused update+vjp>",

@@ -39,6 +39,18 @@ CM_D double rcp(double a) {
 #endif
 }
 
+// 1/sqrt(a) for a well-scaled a > 0: v_rsq_f64 + two Newton steps (~1 ulp); one result gives sqrt(a) = a r, 1/a = r^2
+CM_D double rsqrt_pos(double a) {
+#if defined(CM_HOST_BUILD)
+    return 1.0 / std::sqrt(a);
+#else
+    double r = __builtin_amdgcn_rsq(a);
+    r = __builtin_fma(0.5 * r, __builtin_fma(-a * r, r, 1.0), r);
+    r = __builtin_fma(0.5 * r, __builtin_fma(-a * r, r, 1.0), r);
+    return r;
+#endif
+}
+
 // A literal that stays in a scalar register pair: the fma that consumes it reads it as its one scalar operand, instead
 // of the v_mov_b32 pair + v_fmac_f64 the compiler emits for a literal addend (two VALU instructions per coefficient).
 #if defined(CM_HOST_BUILD)

@@ -473,6 +473,14 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
     }
 }
 
+#if defined(CM_HOST_BUILD)
+// host build only (tests): how many points left newton_j2_line / newton_j2_plane for the general path
+inline long long& subspace_fallbacks() { static long long n = 0; return n; }
+#define CM_COUNT_FALLBACK() (++subspace_fallbacks())
+#else
+#define CM_COUNT_FALLBACK() ((void)0)
+#endif
+
 // ---- J2, FULL_3D, plain Newton: the same iteration restricted to its invariant subspace ---------------------
 // Default for J2 / FULL_3D (cm_model_desc.solver_flags & CM_SOLVER_GENERAL_NEWTON turns it off).  For J2 the 7-dof Newton iterates started at
 // x_prev never leave the radial line v = v_prev + dgam n_trial: C[0:6] vanishes on it, dC/dx maps it to itself,
@@ -526,20 +534,165 @@ CM_D uint32_t newton_j2_line(const cm_model_desc& m, const double eg[6], const d
     for (int k = 0; k < 6; ++k) x[k] = xp[k] + dgam * ev.y.gt[k] * kIW[k];
     x[6] = alpha;
     uint32_t st = flags | (uint32_t)it;
-    // evaluation at the returned state: the reverse sweep needs it, and convergence is confirmed on the full
-    // residual there -- the scalar f of the line and the 7-dof residual differ by round-off, and a lane that stopped
-    // within that distance of the tolerance must behave exactly like the general path (e.g. re-applying the same
-    // strain to the returned state is a 0-iteration step).  Such a lane (about one in 10^6) takes the general path.
-    // ev.hd is hardening(x[6]) already: from the last step of the loop, or from the trial evaluation when no step was taken
-    residual_s<CM_YIELD_J2, CM_FULL_3D, true>(m, eg, nullptr, x, xp, ev, C);
-    if (flags & CM_STATUS_CONVERGED) {
-        const double nsq = dot<7>(C, C);
-        if (!((nsq < rel2) || (nsq < abs2))) fallback = true;
+    // The evaluation at the returned state, which the reverse sweep needs, follows from the trial evaluation: the normal is
+    // the trial normal, e and s move along it, phi = phi_trial - 3 mu dgam; ev.hd is hardening(x[6]) already (from the last
+    // step of the loop, or from the trial evaluation when no step was taken).  The scalar f of the line and the 7-dof residual
+    // at the rounded state differ by round-off (~1e-18 against tolerances of 1e-14), and a lane that stopped within that
+    // distance of the tolerance must behave exactly like the general path (e.g. re-applying the same strain to the returned
+    // state is a 0-iteration step): a lane within 1 % of the tolerance (a few in 10^4) takes the general path.
+    if (ev.plastic) {
+        const double twomu_dg = 2.0 * m.mu * dgam;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double nk = ev.y.gt[k] * kIW[k];
+            ev.e[k] -= dgam * nk;
+            ev.s[k] -= twomu_dg * nk;
+        }
+        ev.y.phi = phi_tr - three_mu * dgam;
+        ev.y.rho = rcp(ev.y.phi);
+        ev.f = f;
+        ev.dgam = dgam;
+        if ((flags & CM_STATUS_CONVERGED) && !((f * f < 0.99 * rel2) || (f * f < 0.99 * abs2))) fallback = true;
     }
     if (__any(fallback)) {
-        if (fallback) st = newton_s<CM_YIELD_J2, LS>(m, eg, xp, x, lane_valid, ev, stage);
+        if (fallback) { CM_COUNT_FALLBACK(); st = newton_s<CM_YIELD_J2, LS>(m, eg, xp, x, lane_valid, ev, stage); }
     }
     return st;
+}
+
+// ---- J2, PLANE_STRESS: the same Newton iteration in the coordinates of the plane it never leaves ---------------------
+// Default for J2 / PLANE_STRESS (CM_SOLVER_GENERAL_NEWTON turns it off).  With a = dev(eg - v_prev),
+// b = dev z (z = V(q3 q3^T), the direction F33 acts in) and t = F33 - 1 the deviatoric elastic strain is
+// a + t b - (v - v_prev), the J2 normal is parallel to it, and dC/dx maps span{a, b} x (alpha, F33) to itself: the 8-dof Newton
+// iterates started at x_prev are  v = v_prev + c_a a + c_b b  for all iterations, and the step is *exactly* the Newton step
+// of the four residuals in u = (c_a, c_b, alpha, t).  With p = 1 - c_a, q = t - c_b, P = |p a + q b|^2, phi = mu sqrt(6 P),
+// g = dgam 3 mu / phi (0 on the elastic side of the branch select):
+//     r_a = c_a - g p ,  r_b = c_b - g q ,  C6 = f or dgam ,  C7 = z : sigma / 2mu = p (z:a) + q (z:b) + K tr(z) (tr0 + t tr z) / 2mu
+//     ||C||^2 = r_a^2 (a.a) + 2 r_a r_b (a.b) + r_b^2 (b.b) + C6^2 + C7^2      ((.) = sums over the 6 stored entries)
+// The 2x2 block d r_c / d c = (1 + g) I - (g / P) w v^T  (w = (p, q), v = (p a:a + q a:b, p a:b + q b:b), v.w = P) has the
+// closed-form inverse (I + (g / P) w v^T) / (1 + g); (alpha, t) follow from its 2x2 Schur complement.  Same iterates, iteration
+// counts and convergence test as newton_s<J2, false, PLANE_STRESS>; ~150 instead of ~320 instructions per iteration.  A lane that
+// stops within round-off of the tolerance takes the general path (see the end of the function).
+// LS: the full step is the first trial of the reference's search and is accepted when it passes the Armijo test on ||C||^2 / 2;
+// a lane whose full step fails it leaves for the general line-search path (as in newton_j2_line<true>).
+template <bool LS = false>
+CM_D uint32_t newton_j2_plane(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
+                              bool lane_valid, EvalS<CM_YIELD_J2>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
+    double a[6], b[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = eg[k] - xp[k];
+    const double tr0 = a[0] + a[3] + a[5], trz = z[0] + z[3] + z[5];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (kDiag[k]) a[k] -= tr0 * (1.0 / 3.0);
+        b[k] = z[k] - (kDiag[k] ? trz * (1.0 / 3.0) : 0.0);
+    }
+    double aa = 0.0, ab = 0.0, bb = 0.0, A2 = 0.0, AB2 = 0.0, B2 = 0.0, za = 0.0, zb = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        aa += kW[k] * a[k] * a[k]; ab += kW[k] * a[k] * b[k]; bb += kW[k] * b[k] * b[k];
+        A2 += a[k] * a[k]; AB2 += a[k] * b[k]; B2 += b[k] * b[k];
+        za += kW[k] * z[k] * a[k]; zb += kW[k] * z[k] * b[k];
+    }
+    const double i2mu = half_over_mu(m), sqrt6mu = 2.449489742783178 * m.mu;
+    const double Kz = (m.lambda + (2.0 / 3.0) * m.mu) * i2mu * trz, d77 = zb + Kz * trz;
+    const double alpha_p = xp[6], abs2 = m.abs_tol * m.abs_tol;
+    double ca = 0.0, cb = 0.0, alpha = alpha_p, t = xp[7] - 1.0, rel2 = 0.0, nsq_from = 0.0;
+    int it = 0;
+    bool running = lane_valid, fallback = false, first = true;
+    uint32_t flags = 0;
+    Hard hd;
+    double p, q, rP, phi, f, nsq;          // the evaluation at the current u: read after the loop (a stopped lane re-evaluates its unchanged u)
+    bool plastic;
+    for (;;) {
+        // evaluation at u (every lane, as in newton_s)
+        p = 1.0 - ca; q = t - cb;
+        const double vp = p * aa + q * ab, vq = p * ab + q * bb, P = p * vp + q * vq;
+        rP = (P > 0.0) ? rsqrt_pos(P) : 0.0;                            // 1 / sqrt(P): phi, 3 mu / phi and 1 / P from one rsq
+        phi = sqrt6mu * (P * rP);
+        hd = hardening(m, alpha);
+        f = (phi - (m.Y + hd.H)) * i2mu;
+        const double dgam = alpha - alpha_p;
+        plastic = (f > m.yield_tol) || (fabs(f) < m.yield_tol);
+        const double h = plastic ? 1.224744871391589 * rP : 0.0, g = dgam * h;        // 3 mu / phi = (3 / sqrt 6) / sqrt P
+        const double ra = ca - g * p, rb = cb - g * q, c6 = plastic ? f : dgam;
+        const double c7 = p * za + q * zb + Kz * (tr0 + t * trz);
+        nsq = ra * ra * A2 + 2.0 * ra * rb * AB2 + rb * rb * B2 + c6 * c6 + c7 * c7;
+        if (first) { rel2 = m.rel_tol * m.rel_tol * nsq; first = false; }      // ||C(x_prev)||^2: the relative tolerance's reference
+        if (running && !isfinite(nsq)) { running = false; fallback = true; }
+        if constexpr (LS) {
+            // the full step is the search's first trial (alpha = 1): phi(1) <= phi(0) + c1 phi'(0), phi = ||C||^2 / 2, phi'(0) = -||C||^2
+            if (running && it > 0 && !(0.5 * nsq <= 0.5 * nsq_from + m.ls_c1 * -nsq_from)) { running = false; fallback = true; }
+        }
+        const bool conv = (nsq < rel2) || (nsq < abs2);
+        if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
+        if (running && it >= m.max_iters) running = false;
+        if (!__any(running)) break;
+        if (running) {
+            // B = d r_c / d c = (1 + g) I - (g / P) w v^T has B w = w, and v . (d r_c / d t) = 0:
+            //   B^-1 (d r_c / d alpha) = -h w ,  B^-1 (d r_c / d t) = ((g / P) v_q w - g e_b) / (1 + g) ,  v . B^-1 r = v . r ,
+            // so the Schur complement on (alpha, t) is  [ -(3 mu + H') / 2mu , h v_q ; -h (z:a p + z:b q) , d77 + z . ut ]
+            // (first row [1, 0] on the elastic side) -- its (0,0) entry is the radial-return denominator.
+            const double gP = g * rP * rP, i1g = rcp(1.0 + g);
+            const double vr = vp * ra + vq * rb, sg = gP * vr;
+            const double br0 = (ra + p * sg) * i1g, br1 = (rb + q * sg) * i1g;                  // B^-1 r_c
+            const double ut0 = gP * vq * p * i1g, ut1 = (gP * vq * q - g) * i1g;               // B^-1 d r_c / d t
+            const double s00 = plastic ? -(hd.dH * i2mu + h * h * P) : 1.0, s01 = h * vq;
+            const double s10 = -h * (za * p + zb * q), s11 = d77 + (za * ut0 + zb * ut1);
+            const double r0 = c6 + h * vr, r1 = c7 + (za * br0 + zb * br1);
+            const double det = s00 * s11 - s01 * s10;
+            if (!(fabs(det) > 1e-300)) flags |= CM_STATUS_SINGULAR;
+            const double idet = rcp(det);
+            const double dal = (r0 * s11 - s01 * r1) * idet, dt = (s00 * r1 - s10 * r0) * idet;
+            ca -= br0 + h * p * dal - ut0 * dt;
+            cb -= br1 + h * q * dal - ut1 * dt;
+            alpha -= dal;
+            t -= dt;
+            nsq_from = nsq;
+            ++it;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = xp[k] + ca * a[k] + cb * b[k];
+    x[6] = alpha;
+    x[7] = 1.0 + t;
+    uint32_t st = flags | (uint32_t)it;
+    // The evaluation at the returned state, which the reverse sweep needs, in plane coordinates (the values of the last loop
+    // evaluation): e_dev = p a + q b, s = 2 mu e_dev + K tr(e) I, gt_k = 3 mu w_k e_dev_k / phi.  The plane's ||C|| and the
+    // 8-dof residual norm at the rounded state differ by round-off (the latter subtracts x - x_prev in the full strain's
+    // precision: up to ~1e-4 relative at norms near 1e-14), and a lane that stopped within that distance of the tolerance must
+    // behave exactly like the general path (e.g. re-applying the same strain to the returned state is a 0-iteration step):
+    // a lane within 1 % of the tolerance (a few in 10^4) takes the general path.
+    const double tre = tr0 + t * trz, twomu = 2.0 * m.mu, Ktre = (m.lambda + (2.0 / 3.0) * m.mu) * tre;
+    const double rho = rP * rcp(sqrt6mu);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double ed = p * a[k] + q * b[k];
+        ev.e[k] = ed + (kDiag[k] ? tre * (1.0 / 3.0) : 0.0);
+        ev.s[k] = twomu * ed + (kDiag[k] ? Ktre : 0.0);
+        ev.y.gt[k] = (3.0 * m.mu * rho) * (kW[k] * ed);
+    }
+    ev.tr = tre; ev.f = f; ev.dgam = alpha - alpha_p; ev.plastic = plastic; ev.hd = hd;
+    ev.y.phi = phi; ev.y.rho = rho;
+    if ((flags & CM_STATUS_CONVERGED) && !((nsq < 0.99 * rel2) || (nsq < 0.99 * abs2))) fallback = true;
+    if (__any(fallback)) {
+        if (fallback) { CM_COUNT_FALLBACK(); st = newton_s<CM_YIELD_J2, LS, CM_PLANE_STRESS>(m, eg, xp, x, lane_valid, ev, stage, z); }
+    }
+    return st;
+}
+
+// which (def_type, yield, line search) combinations have a Newton iteration restricted to its invariant subspace
+// (newton_j2_line, newton_j2_plane): the launchers pick the RL = true kernel variants for them unless CM_SOLVER_GENERAL_NEWTON
+template <int DEF, int YK, bool LS>
+constexpr bool has_j2_subspace() {
+    return YK == CM_YIELD_J2 && (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS);
+}
+template <int DEF, bool LS>
+CM_D uint32_t newton_j2_sub(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
+                            bool lane_valid, EvalS<CM_YIELD_J2>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
+    static_assert(has_j2_subspace<DEF, CM_YIELD_J2, LS>(), "J2 subspace Newton: FULL_3D and PLANE_STRESS");
+    if constexpr (DEF == CM_FULL_3D) return newton_j2_line<LS>(m, eg, xp, x, lane_valid, ev, stage);
+    else return newton_j2_plane<LS>(m, eg, z, xp, x, lane_valid, ev, stage);
 }
 
 // ---- reverse sweep, structured (same contract as cm::reverse_point; FULL_3D and PLANE_STRESS) ---------------
@@ -701,10 +854,7 @@ CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const doubl
                          LaneStage stage = LaneStage{nullptr, 0}) {
     if constexpr (STRUCT && has_structured<DEF, YK>()) {
         EvalS<YK> ev;
-        if constexpr (RL) {
-            static_assert(DEF == CM_FULL_3D && YK == CM_YIELD_J2, "radial line: J2, FULL_3D only");
-            return newton_j2_line<LS>(m, eg, xp, x, valid, ev, stage);
-        }
+        if constexpr (RL) return newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, ev, stage);
         else return newton_s<YK, LS, DEF>(m, eg, xp, x, valid, ev, stage, z);
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, valid);

@@ -96,13 +96,20 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_REV_HILL
 #define CM_OCC_REV_HILL 1
 #endif
+#ifndef CM_OCC_PS_J2_PLANE
+#define CM_OCC_PS_J2_PLANE 1       // J2 / PLANE_STRESS kernels on the plane iteration (newton_j2_plane), plain Newton
+#endif
+#ifndef CM_OCC_PS_J2_PLANE_LS
+#define CM_OCC_PS_J2_PLANE_LS 3    // ... with the line search: 182 -> 168 VGPRs (40 B scratch), 0.76 instead of 0.79 ms per 1e7 points (update + vjp)
+#endif
 #ifndef CM_OCC_REV_J2_LS
 #define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
 constexpr int kLsSlots = 2 * 8;         // line search: parked iterate and direction per lane, 2 * max NX (cm_structured.hpp)
 
-template <int DEF, int YK, bool LS, bool TANGENT>
+template <int DEF, int YK, bool LS, bool TANGENT, bool RL = false>
 constexpr int min_waves_update() {
+    if (DEF == CM_PLANE_STRESS && YK == CM_YIELD_J2 && RL && !TANGENT) return LS ? CM_OCC_PS_J2_PLANE_LS : CM_OCC_PS_J2_PLANE;
     if (DEF != CM_FULL_3D) return 1;
     if (YK == CM_YIELD_J2) return LS ? CM_OCC_UPD_J2_LS : CM_OCC_UPD_J2;
     if (YK == CM_YIELD_HOSFORD) return LS ? CM_OCC_UPD_HOSFORD_LS : CM_OCC_UPD_HOSFORD;
@@ -113,7 +120,7 @@ constexpr int min_waves_update() {
 
 // ---- cm_update / cm_update_tangent ----------------------------------------------------------------
 template <int DEF, int YK, bool ROT, bool LS, bool TANGENT, bool RL = false>
-__global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT>())) void k_update(cm_model_desc m, int64_t B,
+__global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>())) void k_update(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, double* __restrict__ dsig, uint32_t* __restrict__ status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
@@ -455,15 +462,16 @@ struct Wsq { double w[6]; };
 
 // minimum waves per SIMD requested from the register allocator: the J2 FULL_3D plain-Newton variants sit at
 // ~130 VGPRs, two above the 4-wave limit (128); every other variant is left unconstrained.
-template <int DEF, int YK, bool LS, int MODE>
+template <int DEF, int YK, bool LS, int MODE, bool RL = false>
 constexpr int min_waves() {
+    if (DEF == CM_PLANE_STRESS && YK == CM_YIELD_J2 && RL) return LS ? CM_OCC_PS_J2_PLANE_LS : CM_OCC_PS_J2_PLANE;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && LS) return CM_OCC_REV_J2_LS;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_HILL && !LS) return CM_OCC_REV_HILL;
     return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1;
 }
 
 template <int DEF, int YK, bool ROT, bool LS, int MODE, bool RL = false>
-__global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_reverse(cm_model_desc m, int64_t B,
+__global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void k_reverse(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev, const double* __restrict__ xi_in,
         const double* __restrict__ sbar_or_data, Wsq wsq, const double* hist_in,
         double* __restrict__ xi_out, double* __restrict__ sigma_out, double* xpbar_out,
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE>())) void k_re
     double* const ls_stage = lds_buf;
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
-            if constexpr (RL) newton_j2_line<LS>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
+            if constexpr (RL) newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
@@ -1100,7 +1108,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
     const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2) {
+        if constexpr (has_j2_subspace<D, Y, LS>()) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
                 return;
@@ -1146,7 +1154,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         // CM_DEBUG_DYN_LDS=<bytes>: occupancy experiments only (extra dynamic LDS per block limits blocks per CU)
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
         const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (D == CM_FULL_3D && Y == CM_YIELD_J2 && (MODE == 1 || MODE == 3)) {
+            if constexpr (has_j2_subspace<D, Y, LS>() && (MODE == 1 || MODE == 3)) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_reverse<D, Y, R, LS, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                        hist_in, xi_out, sigma_out, xpbar, gbar, partials);
@@ -1216,7 +1224,7 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
         const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && D == CM_FULL_3D && Y == CM_YIELD_J2) {
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<D, Y, LS>()) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
                     return;
@@ -1246,7 +1254,7 @@ int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double
     const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && D == CM_FULL_3D && Y == CM_YIELD_J2) {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<D, Y, LS>()) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
                 return;

@@ -40,9 +40,10 @@ class NewtonSettings:
     abs_tol: float = 1e-14
     rel_tol: float = 1e-14
     line_search: dict = field(default_factory=lambda: {**DEFAULT_LINE_SEARCH_SETTINGS, "max evals": 0})
-    # J2 / FULL_3D / no line search: the kernels run the Newton iteration restricted to the radial line it never
-    # leaves (same iterates and counts).  False forces the general 7-dof iteration
-    # (include/cmad_hip.h CM_SOLVER_GENERAL_NEWTON).  Ignored for every other configuration.
+    # J2: the kernels run the Newton iteration restricted to the subspace it never leaves -- the radial line under FULL_3D,
+    # the plane span{dev(eps - eps_p_prev), dev z} x (alpha, F33) under PLANE_STRESS (same iterates and
+    # counts).  False forces the general 7 / 8-dof iteration (include/cmad_hip.h CM_SOLVER_GENERAL_NEWTON).  Ignored for
+    # every other configuration.
     j2_radial_line: bool = True
     # cm_update runs the iteration-bound configurations on a work pool (a lane that has finished its point takes the next
     # one, include/cmad_hip.h CM_SOLVER_LOCKSTEP); True keeps one point per lane for the whole kernel (A/B measurements).

@@ -56,7 +56,9 @@ enum cm_param_index {
 /* solver_flags.  For J2 in FULL_3D without line search the Newton iteration started at x_prev never leaves the
  * radial line v = v_prev + dgam n_trial, so the kernels run the same iteration restricted to that line (identical
  * iterates and iteration counts, scalar linear algebra; a lane whose iterate would cross to the elastic branch
- * falls back to the general path).  CM_SOLVER_GENERAL_NEWTON switches every such specialisation off;
+ * falls back to the general path).  For J2 in PLANE_STRESS the iterates stay in
+ * v = v_prev + c_a dev(eps - v_prev) + c_b dev(z) and the kernels iterate on (c_a, c_b, alpha, F33): the same Newton
+ * step in the coordinates of that plane.  CM_SOLVER_GENERAL_NEWTON switches every such specialisation off;
  * CM_SOLVER_J2_RADIAL_LINE is accepted for compatibility (the restriction is the default). */
 #define CM_SOLVER_J2_RADIAL_LINE 1
 #define CM_SOLVER_GENERAL_NEWTON 2

@@ -21,21 +21,27 @@ def build(force=False, sanitize=False):
     csrc = os.path.join(_ROOT, "cmad_amd", "csrc")
     deps = [src, os.path.join(_ROOT, "include", "cmad_hip.h")] + [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hpp")]
     out = _SO if not sanitize else os.path.join(_DIR, "libhost_harness_asan.so")
-    stale = (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
-    if force or stale:
-        flags = ["-O1", "-g", "-std=c++20", "-fPIC", "-ffp-contract=off"]
-        if sanitize:
-            flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
-        tag = "asan" if sanitize else "host"
-        objs = [os.path.join(_DIR, f"hh_{tag}_part{k}.o") for k in range(NPARTS)]
-        procs = [subprocess.Popen(["g++"] + flags + [f"-DHH_PART={k}", "-c", src, "-o", objs[k]],
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in range(NPARTS)]
-        logs = [p.communicate()[0] for p in procs]
-        if any(p.returncode != 0 for p in procs):
-            raise RuntimeError("g++ failed on tests/native/host_harness.cpp:\n" + "\n".join(logs))
-        subprocess.run(["g++"] + flags + ["-shared", "-o", out] + objs, check=True, capture_output=True)
-        for o in objs:
-            os.remove(o)
+    is_stale = lambda: (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+    if not (force or is_stale()):
+        return out
+    import fcntl
+    with open(out + ".lock", "w") as lock:                      # pytest-xdist workers: one builds, the others wait and reuse
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or is_stale():
+            flags = ["-O1", "-g", "-std=c++20", "-fPIC", "-ffp-contract=off"]
+            if sanitize:
+                flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+            tag = ("asan" if sanitize else "host") + f"_{os.getpid()}"
+            objs = [os.path.join(_DIR, f"hh_{tag}_part{k}.o") for k in range(NPARTS)]
+            procs = [subprocess.Popen(["g++"] + flags + [f"-DHH_PART={k}", "-c", src, "-o", objs[k]],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in range(NPARTS)]
+            logs = [p.communicate()[0] for p in procs]
+            if any(p.returncode != 0 for p in procs):
+                raise RuntimeError("g++ failed on tests/native/host_harness.cpp:\n" + "\n".join(logs))
+            subprocess.run(["g++"] + flags + ["-shared", "-o", out + ".tmp"] + objs, check=True, capture_output=True)
+            os.replace(out + ".tmp", out)
+            for o in objs:
+                os.remove(o)
     return out
 
 
@@ -50,6 +56,13 @@ def lib():
 def set_dense(flag):
     """Force the dense 7x7 path also for FULL_3D (the kernels use the structured solve there)."""
     lib().hh_set_dense(int(bool(flag)))
+
+
+def subspace_fallbacks(reset=True):
+    """Points that left the J2 line / plane Newton iterations for the general path since the last reset."""
+    L = lib()
+    L.hh_subspace_fallbacks.restype = C.c_longlong
+    return int(L.hh_subspace_fallbacks(int(bool(reset))))
 
 
 def set_passes(flag):

@@ -45,7 +45,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
                     : newton_by_passes<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, false>(m, eg, z, xp, x, stage);
             done = true;
         }
-        if constexpr (DEF == CM_FULL_3D && YK == CM_YIELD_J2) {     // same choice as launch_update (cmad_hip.hip)
+        if constexpr (has_j2_subspace<DEF, YK, false>()) {          // same choice as launch_update (cmad_hip.hip)
             if (!done && !g_dense && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 st = ls ? newton_any<DEF, YK, true, true, true>(m, eg, z, xp, x, true, stage)
                         : newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
@@ -292,7 +292,7 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
         const LaneStage stage{parked, 1};
         const HostRowsIO io{B, b};
         bool done = false;
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && DEF == CM_FULL_3D && YK == CM_YIELD_J2) {   // same choice as launch_history
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<DEF, YK, false>()) {   // same choice as launch_history
             if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 if (ls) history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
                 else history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
@@ -315,7 +315,7 @@ static void run_primal_history(const cm_model_desc& m, int64_t B, int K, const d
         const LaneStage stage{parked, 1};
         const HostRowsIO io{B, b};
         bool done = false;
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && DEF == CM_FULL_3D && YK == CM_YIELD_J2) {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<DEF, YK, false>()) {
             if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 if (ls) primal_history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
                 else primal_history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
@@ -555,6 +555,8 @@ void hh_exp_s(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n
 #if HH_HAS(0)
 void hh_set_dense(int d) { g_dense = d; }
 void hh_set_passes(int d) { hh_g_passes = d; }
+// points that left the J2 subspace iterations for the general path since the last reset (cm::subspace_fallbacks)
+long long hh_subspace_fallbacks(int reset) { const long long n = cm::subspace_fallbacks(); if (reset) cm::subspace_fallbacks() = 0; return n; }
 #endif
 #if HH_HAS(0)
 int hh_sizeof_desc(void) { return (int)sizeof(cm_model_desc); }

@@ -462,13 +462,14 @@ def check_direct(direct, def_type, yield_kind, kw, rot, rate=False, K=3, B=128, 
     np.testing.assert_allclose(got, ref, rtol=1e-7, atol=(1e-9 if def_type == ol.UNIAXIAL_STRESS else 1e-10) * np.abs(ref).max())
 
 
-def check_j2_radial_line(backend, B=4096, rot=False):
-    """J2 / FULL_3D (plain Newton, and the traced Newton whose full steps pass the Armijo test): the default kernels
-    restrict the iteration to the radial line it never leaves;
-    CM_SOLVER_GENERAL_NEWTON (solver_flags = 2) forces the general 7-dof iteration.  Both must give the same
-    states, stresses AND iteration counts as the oracle's general Newton, two load steps from a hardened state."""
+def check_j2_radial_line(backend, B=4096, rot=False, def_type=ol.FULL_3D):
+    """J2 (plain Newton, and the traced Newton whose full steps pass the Armijo test): the default kernels
+    restrict the iteration to the invariant subspace it never leaves -- the radial line under FULL_3D, the plane
+    span{dev(eps - eps_p_prev), dev z} x (alpha, F33) under PLANE_STRESS; CM_SOLVER_GENERAL_NEWTON (solver_flags = 2) forces
+    the general 7 / 8-dof iteration.  Both must give the same states, stresses AND iteration counts as the oracle's general
+    Newton, two load steps from a hardened state."""
     for flags, ls in ((0, False), (2, False), (0, True), (2, True)):
-        sc = Scenario(ol.FULL_3D, "J2", {}, rot, ls, B=B)
+        sc = Scenario(def_type, "J2", {}, rot, ls, B=B)
         sc.desc.solver_flags = flags
         check_update(backend, sc)
         for gradu, xp, it_o in ((sc.gradu0, sc.xi0, sc.it1), (sc.gradu, sc.xi1, sc.it2)):

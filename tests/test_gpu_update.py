@@ -140,20 +140,37 @@ def test_rate_model_update(def_type, yield_kind, kw, ls):
 
 
 @pytest.mark.parametrize("rot", [False, True])
-def test_j2_radial_line_newton_matches_general_path(backend, rot):
-    pc.check_j2_radial_line(backend, B=8192, rot=rot)
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_j2_radial_line_newton_matches_general_path(backend, def_type, rot):
+    pc.check_j2_radial_line(backend, B=8192, rot=rot, def_type=def_type)
     # the fused kernel gives the same state and gradient with the restriction (default) and without it
     import torch
+    from cmad_amd.models.deformation_types import DefType
     from cmad_amd.models.device import DeviceEvaluator, NewtonSettings, build_desc
     from cmad_amd.synthetic import gauss_point_batch, j2_voce_values
-    B = 4096
-    g = torch.from_numpy(gauss_point_batch(B)).cuda(); xp = torch.zeros((7, B), dtype=torch.float64, device="cuda")
+    B = 4099
+    ps = def_type == ol.PLANE_STRESS
+    dt = DefType.PLANE_STRESS if ps else DefType.FULL_3D
+    g = torch.from_numpy(gauss_point_batch(B, ndims=2 if ps else 3)).cuda()
+    xp = torch.zeros((8 if ps else 7, B), dtype=torch.float64, device="cuda")
+    if ps:
+        xp[7] = 1.0
     sb = torch.randn((6, B), dtype=torch.float64, device="cuda")
-    a = DeviceEvaluator(*build_desc(j2_voce_values(), newton=NewtonSettings(j2_radial_line=False))).update_and_vjp(g, xp, sb)
-    b = DeviceEvaluator(*build_desc(j2_voce_values(), newton=NewtonSettings())).update_and_vjp(g, xp, sb)
+    a = DeviceEvaluator(*build_desc(j2_voce_values(), def_type=dt, newton=NewtonSettings(j2_radial_line=False))).update_and_vjp(g, xp, sb)
+    b = DeviceEvaluator(*build_desc(j2_voce_values(), def_type=dt, newton=NewtonSettings())).update_and_vjp(g, xp, sb)
     np.testing.assert_allclose(b[0].cpu().numpy(), a[0].cpu().numpy(), rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(b[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-10, atol=1e-8)
     np.testing.assert_allclose(b[2].cpu().numpy(), a[2].cpu().numpy(), rtol=1e-9, atol=1e-9 * a[2].abs().max().item())
+    # ... and over a load history (state carried from step to step): objective + gradient of the whole history
+    if ps:
+        K = 6
+        gh = torch.from_numpy(np.stack([gauss_point_batch(B, ndims=2, seed=40) * (k / K) for k in range(K + 1)])).cuda()
+        dh = 50.0 * torch.randn((K + 1, 6, B), dtype=torch.float64, device="cuda")
+        outs = []
+        for radial in (False, True):
+            ev = DeviceEvaluator(*build_desc(j2_voce_values(), def_type=dt, newton=NewtonSettings(j2_radial_line=radial)))
+            outs.append(ev.objective_grad_history(gh, dh, [1., 1., 0., 1., 0., 0.], xp)[0].cpu().numpy())
+        np.testing.assert_allclose(outs[1], outs[0], rtol=1e-9, atol=1e-9 * np.abs(outs[0]).max())
 
 
 def test_edge_cases(backend):

@@ -280,10 +280,16 @@ def test_rate_model_explicit_blocks(def_type, yield_kind, kw, rot, solver_varian
 
 
 @pytest.mark.parametrize("rot", [False, True])
-def test_j2_radial_line_newton_matches_general_path(rot, solver_variant):
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_j2_radial_line_newton_matches_general_path(def_type, rot, solver_variant):
     if solver_variant != "structured":
         pytest.skip("specialisation of the structured path")
-    pc.check_j2_radial_line(BACKEND, B=2048, rot=rot)
+    import host_harness_lib as hh
+    hh.subspace_fallbacks()
+    pc.check_j2_radial_line(BACKEND, B=2048, rot=rot, def_type=def_type)
+    # the restricted iteration carried (nearly) every point: a handful per 10^4 may leave for the general path when the
+    # reduced and the full residual norm straddle the tolerance
+    assert hh.subspace_fallbacks() <= 20
 
 
 def test_edge_cases():
