@@ -267,7 +267,7 @@ def main():
     newton = NewtonSettings(j2_radial_line=not args.general_newton)   # newton_solve defaults: 10 iters, 1e-14, no line search
     if args.ls_evals > 0:                          # make_newton_solve: same tolerances + Armijo line search
         newton = NewtonSettings.traced(line_search_settings={"max evals": args.ls_evals})
-    eps_y, hybrid, bytes_per_update = 1e-3, None, BYTES_PER_UPDATE
+    eps_y, hybrid = 1e-3, None
     if wl == "hosford_update":                     # configs[2]: notch_hosford.yaml material + solver settings
         from cmad_amd.synthetic import hosford_values
         values, eps_y = hosford_values(), 2e-3
@@ -278,20 +278,15 @@ def main():
         icnn, values = al7079_hybrid_setup()
         hybrid, eps_y = HybridHillEffectiveStress(icnn), 525.0 / 70.2e3
         newton = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})
-    if wl in ("j2_update", "hosford_update", "hybrid_update"):
-        bytes_per_update = 232                     # read gradu 72 + xi_prev 56, write xi 56 + sigma 48
-    elif wl == "j2_update_tangent":                # the FE caller's per-integration-point kernel
-        bytes_per_update = 232 + 6 * 9 * 8         # + d sigma / d grad u, 54 rows written
-    elif wl == "j2_objective_grad":
-        bytes_per_update = 176                     # read gradu 72 + xi_prev 56 + data 48, no per-point writes
+    # algorithmic bytes per point: rows of 8 bytes read (grad u, xi_prev, sigma_bar / data) and written (xi, sigma,
+    # tangent); FULL_3D n_gradu = 9, n_xi = 7 -> 232 / 280 / 176 / 664; PLANE_STRESS n_gradu = 4, n_xi = 8 -> 208 / 256 / 144 / 400
     ps = args.def_type == "plane_stress"
     if ps:
         assert wl.startswith("j2_"), "--def-type plane_stress applies to the J2 workloads"
-        bytes_per_update += 8 * (-5 - 5 + 1 + 1)   # grad u 9 -> 4 doubles, xi / xi_prev 7 -> 8 doubles
-        if wl == "j2_update_tangent":
-            bytes_per_update -= 8 * 6 * 5          # d sigma / d grad u: 6 x 4 rows
-        if wl == "j2_objective_grad":
-            bytes_per_update -= 8                  # no xi written
+    n_gradu, n_xi = (4, 8) if ps else (9, 7)
+    reads = n_gradu + n_xi + (6 if wl in ("j2_update_vjp", "j2_objective_grad") else 0)
+    writes = 0 if wl == "j2_objective_grad" else n_xi + 6 + (6 * n_gradu if wl == "j2_update_tangent" else 0)
+    bytes_per_update = 8 * (reads + writes)
     from cmad_amd.models.deformation_types import DefType
     newton.lockstep = bool(args.lockstep)
     desc, info = build_desc(values, def_type=DefType.PLANE_STRESS if ps else DefType.FULL_3D, newton=newton, hybrid=hybrid)

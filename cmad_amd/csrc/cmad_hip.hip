@@ -102,6 +102,9 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_PS_J2_PLANE_LS
 #define CM_OCC_PS_J2_PLANE_LS 3    // ... with the line search: 182 -> 168 VGPRs (40 B scratch), 0.76 instead of 0.79 ms per 1e7 points (update + vjp)
 #endif
+#ifndef CM_OCC_REV_J2
+#define CM_OCC_REV_J2 4             // fused J2 / FULL_3D plain-Newton kernels (headline, objective)
+#endif
 #ifndef CM_OCC_REV_J2_LS
 #define CM_OCC_REV_J2_LS 3          // 172 -> 168 VGPRs (16 B scratch): 0.85 ms instead of 0.90 ms per 1e7 points
 #endif
@@ -467,7 +470,7 @@ constexpr int min_waves() {
     if (DEF == CM_PLANE_STRESS && YK == CM_YIELD_J2 && RL) return LS ? CM_OCC_PS_J2_PLANE_LS : CM_OCC_PS_J2_PLANE;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && LS) return CM_OCC_REV_J2_LS;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_HILL && !LS) return CM_OCC_REV_HILL;
-    return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? 4 : 1;
+    return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? CM_OCC_REV_J2 : 1;
 }
 
 template <int DEF, int YK, bool ROT, bool LS, int MODE, bool RL = false>

@@ -73,6 +73,10 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
             entry["fp64_valu_roof_frac"] = entry["fp64_tflops"] / 78.6
             if c.get("SQ_WAVES"):
                 entry["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"]
+        if c.get("GRBM_GUI_ACTIVE"):
+            # busy cycles summed over the 8 XCDs during the launch -> mean engine clock while the kernel ran (approximate: the
+            # counter pass and the kernel-trace pass are different runs)
+            entry["approx_engine_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (kv["avg_us"] * 1e3)
     out[wl] = entry
     co = entry["code_object"] or {}
     lines.append(f"{wl:16s} {name[len('void (anonymous namespace)::'):][:52]:52s} avg {kv['avg_us']:8.1f} us x{kv['calls']:3d} | "
@@ -81,7 +85,8 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
                  f"valu/wait/stall {entry.get('wave_cycle_split', {}).get('valu_active', float('nan')):.2f}/"
                  f"{entry.get('wave_cycle_split', {}).get('wait_any', float('nan')):.2f}/"
                  f"{entry.get('wave_cycle_split', {}).get('wait_inst_any', float('nan')):.2f} | lanes {entry.get('active_lane_fraction', float('nan')):.2f} | "
-                 f"traffic {entry.get('hbm_bytes_per_point', float('nan')):.1f} B/pt")
+                 f"traffic {entry.get('hbm_bytes_per_point', float('nan')):.1f} B/pt | {entry.get('valu_insts_per_wave', float('nan')):.0f} valu/wave | "
+                 f"~{entry.get('approx_engine_clock_GHz', float('nan')):.2f} GHz")
 os.makedirs("profiles", exist_ok=True)
 json.dump(out, open(f"profiles/{tag}_rocprof_summary.json", "w"), indent=1)
 open(f"profiles/{tag}_side_kernels.txt", "w").write("\n".join(lines) + "\n")

@@ -13,5 +13,5 @@ PARGS="--steps 3 --warmup 1 --no-cpu-baseline $@"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $PARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $PARGS > $OUT/bench_write.json 2> $OUT/write.err || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $PARGS > $OUT/bench_sq.json 2> $OUT/sq.err || exit 1
-rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LEVEL_WAVES --output-format csv -d $OUT/pmc_mix -- python3 $ROOT/bench.py $PARGS > $OUT/bench_mix.json 2> $OUT/mix.err || exit 1
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mix -- python3 $ROOT/bench.py $PARGS > $OUT/bench_mix.json 2> $OUT/mix.err || exit 1
 cd $ROOT && python3 tools/parse_profiles.py $OUT $TAG
