@@ -500,39 +500,48 @@ def check_line_search_rejections(backend, def_type=ol.FULL_3D, yield_kind="J2", 
         assert np.mean(it_d == it_o) > 0.99, np.bincount(np.abs(it_d - it_o))
 
 
-def check_edge_cases(backend):
+def check_edge_cases(backend, def_type=ol.FULL_3D):
     """Zero strain (sigma = 0: the reference's normal is NaN there and masked by the branch select), iteration cap
-    reached without convergence (the reference returns the last iterate silently; status reports it), and a
-    very large strain increment."""
+    reached without convergence (the reference returns the last iterate silently; status reports it: with caps of 1, 2 and 3
+    the kernels' iterates are compared with the oracle's one by one), and a very large strain increment.  PLANE_STRESS runs
+    the first two on the J2 plane iteration (newton_j2_plane)."""
     from cmad_amd.models.device import NewtonSettings, build_desc
 
     class S:
         pass
     values = ol.j2_voce_values()
+    ps = def_type == ol.PLANE_STRESS
+    nu, nx = (4, 8) if ps else (9, 7)
     # --- zero / tiny strain
-    sc = S(); sc.mat = ol.Material(values); sc.desc, sc.info = build_desc(values)
+    sc = S(); sc.mat = ol.Material(values, def_type=def_type); sc.desc, sc.info = build_desc(values, def_type=def_type)
     B = 130
-    g = np.zeros((9, B)); g[0, 1::2] = 1e-300
-    xp = np.zeros((7, B))
+    g = np.zeros((nu, B)); g[0, 1::2] = 1e-300
+    xp = np.zeros((nx, B))
+    if ps:
+        xp[7] = 1.0
     xi, sig, status = backend.update(sc, g, xp)
-    assert np.isfinite(xi).all() and np.isfinite(sig).all() and not xi.any()
+    assert np.isfinite(xi).all() and np.isfinite(sig).all() and not (xi - xp).any()
     assert ((status.astype(np.uint32) & 0xFFFF) == 0).all() and ((status.astype(np.uint32) >> 16) & 1).all()
     sb = np.ones((6, B))
     gk, xb, ub = backend.vjp(sc, g, xp, xi, sb)
     assert np.isfinite(gk).all() and np.isfinite(xb).all() and np.isfinite(ub).all()
-    # --- iteration cap: 1 and 2 iterations only
+    # --- iteration cap: 1, 2 and 3 iterations only
     from cmad_amd.synthetic import gauss_point_batch
-    g = gauss_point_batch(512, seed=9, dev_scale=8.0)
-    xp = np.zeros((7, 512))
-    for cap in (1, 2):
-        sc = S(); sc.mat = ol.Material(values)
-        sc.desc, sc.info = build_desc(values, newton=NewtonSettings(max_iters=cap))
+    g = gauss_point_batch(512, seed=9, dev_scale=8.0, ndims=2 if ps else 3)
+    xp = np.zeros((nx, 512))
+    if ps:
+        xp[7] = 1.0
+    for cap in (1, 2, 3):
+        sc = S(); sc.mat = ol.Material(values, def_type=def_type)
+        sc.desc, sc.info = build_desc(values, def_type=def_type, newton=NewtonSettings(max_iters=cap))
         xi_o, sig_o, it_o, cv_o = sc.mat.update_batch(ol.newton_settings(max_iters=cap), g, xp)
         xi_d, sig_d, status = backend.update(sc, g, xp)
         status = status.astype(np.uint32)
         np.testing.assert_allclose(xi_d, xi_o, rtol=1e-10, atol=1e-13)          # same (unconverged) iterate
         assert ((status & 0xFFFF) == it_o).all() and (it_o.max() == cap)
-        assert (((status >> 16) & 1) == cv_o).all() and (cv_o == 0).any()
+        assert (((status >> 16) & 1) == cv_o).all() and ((cv_o == 0).any() or cap > 2)
+    if ps:
+        return
     # --- 20 x yield strain in one step, Hill with line search
     hv = ol.j2_voce_values(yield_kind="hill", hill=HILL)
     st_o, st_d = settings_pair(True)

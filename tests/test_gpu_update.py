@@ -173,8 +173,9 @@ def test_j2_radial_line_newton_matches_general_path(backend, def_type, rot):
         np.testing.assert_allclose(outs[1], outs[0], rtol=1e-9, atol=1e-9 * np.abs(outs[0]).max())
 
 
-def test_edge_cases(backend):
-    pc.check_edge_cases(backend)
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_edge_cases(backend, def_type):
+    pc.check_edge_cases(backend, def_type)
 
 
 @pytest.mark.parametrize("line_search", [False, True])

@@ -292,8 +292,9 @@ def test_j2_radial_line_newton_matches_general_path(def_type, rot, solver_varian
     assert hh.subspace_fallbacks() <= 20
 
 
-def test_edge_cases():
-    pc.check_edge_cases(BACKEND)
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_edge_cases(def_type):
+    pc.check_edge_cases(BACKEND, def_type)
 
 
 @pytest.mark.parametrize("plastic", [True, False])
