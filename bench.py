@@ -211,7 +211,7 @@ def main():
                     help="J2 workloads: plane_stress is a side measurement (the reference's material-point tests' type)")
     ap.add_argument("--workload", default="j2_update_vjp",
                     choices=["j2_update_vjp", "j2_update", "j2_update_tangent", "j2_objective_grad", "hosford_update",
-                             "hybrid_update", "ps_calibration_history"],
+                             "hybrid_update", "hosford_update_vjp", "hybrid_update_vjp", "ps_calibration_history"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
     args = ap.parse_args()
 
@@ -268,11 +268,11 @@ def main():
     if args.ls_evals > 0:                          # make_newton_solve: same tolerances + Armijo line search
         newton = NewtonSettings.traced(line_search_settings={"max evals": args.ls_evals})
     eps_y, hybrid = 1e-3, None
-    if wl == "hosford_update":                     # configs[2]: notch_hosford.yaml material + solver settings
+    if wl.startswith("hosford_update"):            # configs[2]: notch_hosford.yaml material + solver settings
         from cmad_amd.synthetic import hosford_values
         values, eps_y = hosford_values(), 2e-3
         newton = NewtonSettings.traced(max_iters=500, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 100})
-    elif wl == "hybrid_update":                    # configs[3]: hybrid Hill + ICNN [6,16,1]
+    elif wl.startswith("hybrid_update"):           # configs[3]: hybrid Hill + ICNN [6,16,1]
         from cmad_amd.models.device import HybridHillEffectiveStress
         from cmad_amd.synthetic import al7079_hybrid_setup
         icnn, values = al7079_hybrid_setup()
@@ -284,7 +284,7 @@ def main():
     if ps:
         assert wl.startswith("j2_"), "--def-type plane_stress applies to the J2 workloads"
     n_gradu, n_xi = (4, 8) if ps else (9, 7)
-    reads = n_gradu + n_xi + (6 if wl in ("j2_update_vjp", "j2_objective_grad") else 0)
+    reads = n_gradu + n_xi + (6 if (wl.endswith("_vjp") or wl == "j2_objective_grad") else 0)
     writes = 0 if wl == "j2_objective_grad" else n_xi + 6 + (6 * n_gradu if wl == "j2_update_tangent" else 0)
     bytes_per_update = 8 * (reads + writes)
     from cmad_amd.models.deformation_types import DefType
@@ -323,7 +323,7 @@ def main():
         if pending[i] is not None:                 # the buffer's previous all-reduce must have finished
             pending[i].wait()
             pending[i] = None
-        if wl == "j2_update_vjp":
+        if wl.endswith("_update_vjp"):
             out["grad"] = grads[i]
             ev.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
             return grads[i]
@@ -354,7 +354,7 @@ def main():
             graphs[i] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graphs[i], stream=side):
                 launch(i)
-    result_of = {"j2_update_vjp": grads, "j2_objective_grad": res13}.get(wl, [None, None])   # what each graph writes
+    result_of = res13 if wl == "j2_objective_grad" else (grads if wl.endswith("_update_vjp") else [None, None])   # what each graph writes
 
     def step(k):
         i = k & 1
@@ -443,7 +443,10 @@ def main():
                                                   "caller's per-integration-point call; side measurement)",
                              "j2_objective_grad": "fused J2 calibration objective + gradient, single step (configs[4] per GPU)",
                              "hosford_update": "Hosford a=100 stress update, notch_hosford.yaml material (configs[2])",
-                             "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])"}[wl]
+                             "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])",
+                             "hosford_update_vjp": "Hosford a=100 stress update + vjp w.r.t. parameters (configs[2] material; side measurement)",
+                             "hybrid_update_vjp": "hybrid Hill + ICNN[6,16,1] stress update + vjp w.r.t. parameters (configs[3] material; "
+                                                  "side measurement)"}[wl]
                             .replace("FULL_3D", "PLANE_STRESS (side measurement)" if ps else "FULL_3D")
                             .replace(" (BASELINE.json configs[1])", "" if (ps or args.yield_surface != "j2") else " (BASELINE.json configs[1])"),
                 "def_type": args.def_type, "yield_surface": args.yield_surface, "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),

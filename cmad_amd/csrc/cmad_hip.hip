@@ -1435,7 +1435,19 @@ int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n
 
 }  // namespace
 
+// Iteration-bound configurations (the network surfaces, Hosford under the line search: pool_pays<>) run cm_update on the work
+// pool.  The fused entry points below take the same route for them -- work-pool update, then the reverse sweep as a second
+// kernel over the stored states -- instead of the lockstep fused kernel, whose wavefronts wait for their slowest point
+// (CM_SOLVER_LOCKSTEP keeps the single fused kernel).  Same per-point arithmetic and the same reduction order either way.
+static inline bool pool_route(const cm_model_desc* m, int64_t B) {
+    if (!m || m->model_kind != CM_SMALL_ELASTIC_PLASTIC || (m->solver_flags & CM_SOLVER_LOCKSTEP) || B < 256) return false;
+    return is_nn_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && m->ls_max_evals > 0);
+}
 extern "C" {
+// objective + gradient at given converged states (the MODE 2 reverse kernel without a history vector); defined with cm_adjoint_step
+__attribute__((visibility("hidden")))
+int cmi_objective_from_state(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                             const double* data, const double* wsq6, double* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 
 #if CM_HAS_PART(1)
@@ -1547,6 +1559,10 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
                       void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p || !xi) return CM_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (pool_route(m, B) && gradu && xi_prev && sigma_bar) {
+        const int rc = cm_update(m, B, gradu, xi_prev, xi, sigma, nullptr, stream);
+        return rc != CM_OK ? rc : cm_update_vjp(m, B, gradu, xi_prev, xi, sigma_bar, grad_p, nullptr, nullptr, workspace, workspace_bytes, stream);
+    }
     return launch_reverse<3>(m, B, gradu, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr, nullptr,
                              grad_p, 1, 0, workspace, workspace_bytes, stream);
 }
@@ -1688,6 +1704,10 @@ int cm_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, con
 int cm_objective_grad(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       const double* data, const double* wsq6, double* out, double* xi,
                       void* workspace, int64_t workspace_bytes, void* stream) {
+    if (xi && pool_route(m, B) && gradu && xi_prev && data && out && workspace && workspace_bytes >= cm_workspace_bytes(B)) {
+        const int rc = cm_update(m, B, gradu, xi_prev, xi, nullptr, nullptr, stream);   // needs somewhere to keep the states: only with xi
+        return rc != CM_OK ? rc : cmi_objective_from_state(m, B, gradu, xi_prev, xi, data, wsq6, out, workspace, workspace_bytes, stream);
+    }
     return launch_reverse<1>(m, B, gradu, xi_prev, nullptr, data, wsq6, nullptr, xi, nullptr, nullptr, nullptr,
                              out, 0, 0, workspace, workspace_bytes, stream);
 }
@@ -1700,6 +1720,11 @@ int cm_adjoint_step(const cm_model_desc* m, int64_t B, const double* gradu, cons
     if (!hist_out) return CM_ERR_BAD_ARG;
     return launch_reverse<2>(m, B, gradu, xi_prev, xi, data, wsq6, hist_in, nullptr, nullptr, hist_out, nullptr,
                              out, 0, accumulate, workspace, workspace_bytes, stream);
+}
+int cmi_objective_from_state(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev, const double* xi,
+                             const double* data, const double* wsq6, double* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    return launch_reverse<2>(m, B, gradu, xi_prev, xi, data, wsq6, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             out, 0, 0, workspace, workspace_bytes, stream);
 }
 #endif
 

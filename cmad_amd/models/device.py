@@ -314,6 +314,17 @@ class DeviceEvaluator:
         return self._ws, need
 
     # -- entry points
+    def pool_route(self, B):
+        """True when `cm_update` runs this configuration on the work pool (network surfaces, Hosford under the line search;
+        B >= 256, total form, no CM_SOLVER_LOCKSTEP -- `pool_route` in cmad_hip.hip).  For those the multi-kernel routes
+        (work-pool update + reverse kernel per step) beat the single fused lockstep kernels, whose wavefronts wait for their
+        slowest point; callers use this to pick the route (`cm_update_and_vjp` and `cm_objective_grad` with a state buffer
+        do it themselves)."""
+        d = self.desc
+        if d.model_kind != 0 or (d.solver_flags & _lib.SOLVER_LOCKSTEP) or B < 256:
+            return False
+        return d.yield_kind in (3, 4) or (d.yield_kind == YIELD_KINDS["hosford"] and d.ls_max_evals > 0)
+
     def update(self, gradu, xi_prev, want_sigma=True, want_status=True, tangent=False, out=None):
         torch = _torch()
         B = gradu.shape[1]

@@ -6,7 +6,8 @@ for B independent Gauss points at once, sharded over ranks.
     grad(p) = dJ/dp in Parameters' flat active order, canonical (transform_grad applied) like the reference
 
 A K-step history is one `cm_objective_grad_history` launch (state in registers from step to step); with
-`fused_history=False` one `cm_update` launch per step forward and one `cm_adjoint_step` launch per step in reverse.
+`fused_history=False` -- the default for the configurations whose `cm_update` runs on the work pool (network surfaces, Hosford
+under the line search) -- one `cm_update` launch per step forward and one `cm_adjoint_step` launch per step in reverse.
 A single-step history uses the fused `cm_objective_grad`.  Multi-GPU: each rank owns a contiguous shard of
 the points; the only exchange is one all-reduce of (1 + 12) doubles per evaluation (RCCL on GPUs).
 """
@@ -44,7 +45,7 @@ class BatchedCalibrationObjective:
     xi0       : (n_xi, B_local) initial state (default: the model's init values)
     """
 
-    def __init__(self, model, gradu_hist, data_hist, weight, xi0=None, newton=None, group=None, fused_history=True):
+    def __init__(self, model, gradu_hist, data_hist, weight, xi0=None, newton=None, group=None, fused_history=None):
         import torch
         self._model = model
         self._parameters = model.parameters
@@ -60,8 +61,11 @@ class BatchedCalibrationObjective:
             xi0 = torch.from_numpy(init).to(dev)[:, None].repeat(1, self._B).contiguous()
         self._xi0 = xi0
         self._out = torch.zeros(13, dtype=torch.float64, device=dev)
-        # K > 1: one `cm_objective_grad_history` launch per evaluation (False: one launch per step and direction)
-        self._fused_history = bool(fused_history)
+        # K > 1: one `cm_objective_grad_history` launch per evaluation (False: one launch per step and direction).  None picks:
+        # the single launch, except for the iteration-bound configurations whose `cm_update` runs on the work pool
+        # (`DeviceEvaluator.pool_route`) -- for them per-step launches (work-pool update forward, adjoint step backward) are faster
+        # than the lockstep history kernel
+        self._fused_history = fused_history
         self._xi_hist = None
 
     def evaluate(self, flat_active_values) -> GradientResult:
@@ -80,9 +84,12 @@ class BatchedCalibrationObjective:
         out = self._out
         rate = getattr(model, "_model_kind", 0) == 1          # the rate form also takes the previous step's grad u
         prev = (lambda k: {"gradu_prev": g[k - 1]}) if rate else (lambda k: {})
+        pooled = (not rate) and ev.pool_route(self._B)
+        fused = (not pooled) if self._fused_history is None else bool(self._fused_history)
         if K == 1:
-            ev.objective_grad(g[1], self._xi0, d[1], self._wsq6, out=out, **prev(1))
-        elif self._fused_history:
+            # with a state buffer the entry point routes the iteration-bound configurations through the work pool
+            ev.objective_grad(g[1], self._xi0, d[1], self._wsq6, out=out, want_xi=pooled, **prev(1))
+        elif fused:
             _, self._xi_hist = ev.objective_grad_history(g, d, self._wsq6, self._xi0, xi_hist=self._xi_hist, out=out)
         else:
             xs = [self._xi0]

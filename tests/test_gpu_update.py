@@ -86,6 +86,48 @@ def test_hybrid_hill_icnn(backend, def_type):
     pc.check_hybrid_nn(backend, def_type, B=2048, rot=(def_type == ol.FULL_3D))
 
 
+@pytest.mark.parametrize("surface", ["hybrid", "hosford100"])
+def test_work_pool_route_equals_lockstep_kernels(surface):
+    """The iteration-bound configurations run cm_update on the work pool, and the fused entry points (cm_update_and_vjp,
+    cm_objective_grad with a state buffer) go work-pool update -> reverse kernel for them; CM_SOLVER_LOCKSTEP keeps the single
+    lockstep kernels.  Same per-point iteration either way: states, stresses, iteration counts, objective and gradient agree."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, HybridHillEffectiveStress, NewtonSettings, build_desc
+    from cmad_amd.synthetic import al7079_hybrid_setup, gauss_point_batch, hosford_values
+    B = 3001
+    if surface == "hybrid":
+        icnn, values = al7079_hybrid_setup()
+        mk = lambda lock: NewtonSettings(50, 1e-12, 1e-12, {"max evals": 10, "sufficient decrease": 1e-4, "min backtrack factor": 0.5,
+                                                           "max backtrack factor": 0.9}, lockstep=lock)
+        evs = [DeviceEvaluator(*build_desc(values, newton=mk(lock), hybrid=HybridHillEffectiveStress(icnn))) for lock in (False, True)]
+        eps_y = 525.0 / 70.2e3
+    else:
+        values = hosford_values()
+        mk = lambda lock: NewtonSettings(500, 1e-12, 1e-12, {"max evals": 100, "sufficient decrease": 1e-4, "min backtrack factor": 0.5,
+                                                            "max backtrack factor": 0.9}, lockstep=lock)
+        evs = [DeviceEvaluator(*build_desc(values, newton=mk(lock))) for lock in (False, True)]
+        eps_y = 2e-3
+    g = torch.from_numpy(gauss_point_batch(B, seed=31, eps_y=eps_y)).cuda()
+    xp = torch.zeros((7, B), dtype=torch.float64, device="cuda")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    sb = torch.randn((6, B), dtype=torch.float64, device="cuda", generator=gen)
+    data = 100.0 * torch.randn((6, B), dtype=torch.float64, device="cuda", generator=gen)
+    wsq = [1.0, 0.5, 0.0, 2.0, 0.0, 1.0]
+    up = [ev.update(g, xp) for ev in evs]
+    assert torch.equal(up[0][2], up[1][2])                                   # status words: iterations, converged, plastic
+    assert float(((up[0][2].to(torch.int64) >> 16) & 1).double().mean()) > 0.999
+    np.testing.assert_allclose(up[0][0].cpu().numpy(), up[1][0].cpu().numpy(), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(up[0][1].cpu().numpy(), up[1][1].cpu().numpy(), rtol=1e-12, atol=1e-10)
+    fused = [ev.update_and_vjp(g, xp, sb) for ev in evs]
+    for a, b in zip(fused[0], fused[1]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-11, atol=1e-11 * float(b.abs().max()))
+    np.testing.assert_allclose(fused[0][0].cpu().numpy(), up[0][0].cpu().numpy(), rtol=0, atol=0)      # the routed path IS cm_update
+    obj = [evs[0].objective_grad(g, xp, data, wsq, want_xi=True)[0], evs[0].objective_grad(g, xp, data, wsq)[0],
+           evs[1].objective_grad(g, xp, data, wsq, want_xi=True)[0]]
+    for o in obj[1:]:
+        np.testing.assert_allclose(o.cpu().numpy(), obj[0].cpu().numpy(), rtol=1e-11, atol=1e-11 * float(obj[0].abs().max()))
+
+
 @pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "J2", {}), (ol.FULL_3D, "hill", {"hill": pc.HILL}),
                                                     (ol.PLANE_STRESS, "J2", {}), (ol.FULL_3D, "hosford", {"a": 8.5})])
 def test_line_search_rejections(backend, def_type, yield_kind, kw):
