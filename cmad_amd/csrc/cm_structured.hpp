@@ -681,6 +681,37 @@ CM_D uint32_t newton_j2_plane(const cm_model_desc& m, const double eg[6], const 
     return st;
 }
 
+// ---- J2 / FULL_3D, parameter gradient of a converged step in closed form ----------------------------------------------
+// pbar of reverse_point_s for xin = NULL (no incoming state cotangent) at a CONVERGED J2 state, without the transposed solve:
+// the return map is  e = (eg - v_prev) - dgam N,  N the trial normal (independent of the parameters),  dgam the root of
+// f = phi_trial - 3 mu dgam - Y - H(alpha_prev + dgam); so with J = sum_k sbm_k s_k, s = lambda tr(e) d + 2 mu e:
+//     dJ/dlambda = tr(e) (sbm . d)
+//     dJ/dmu     = 2 sbm . e - 2 mu (sbm . N) d dgam / d mu ,  d dgam / d mu = (phi_trial / mu - 3 dgam) / (3 mu + H') = (phi / mu) / (3 mu + H')
+//     dJ/dY      = L ,  dJ/dS = L (1 - exp(-D alpha)) ,  dJ/dD = L S alpha exp(-D alpha) ,  dJ/dK = L alpha ,  L = 2 mu (sbm . N) / (3 mu + H')
+// This is the same derivative the IFT rule gives (A^-T applied to the stress cotangent, then the dC/dp contraction) evaluated
+// on the solution manifold f = 0: the fused kernels use it when every point of the wavefront converged and fall back to
+// reverse_point_s otherwise (an unconverged state is differentiated as the reference does it, through A(x) at that state).
+// ~45 instead of ~250 instructions.
+CM_D void reverse_j2_radial(const cm_model_desc& m, const double eg[6], const double* x, const double sbm[6],
+                            const EvalS<CM_YIELD_J2>& ev, double* pbar) {
+    double sbe = 0.0, sbn = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        sbe += sbm[k] * (eg[k] - x[k]);
+        sbn += sbm[k] * (ev.y.gt[k] * kIW[k]);
+    }
+    const double etr = (eg[0] - x[0]) + (eg[3] - x[3]) + (eg[5] - x[5]);
+    const double L = ev.plastic ? 2.0 * m.mu * sbn * rcp(3.0 * m.mu + ev.hd.dH) : 0.0;
+    pbar[CM_P_LAMBDA] = (sbm[0] + sbm[3] + sbm[5]) * etr;
+    pbar[CM_P_MU] = 2.0 * sbe - L * ev.y.phi * (2.0 * half_over_mu(m));
+    pbar[CM_P_Y] = L;
+    pbar[CM_P_VOCE_S] = m.has_voce ? L * (1.0 - ev.hd.expo) : 0.0;
+    pbar[CM_P_VOCE_D] = m.has_voce ? L * m.voce_S * x[6] * ev.hd.expo : 0.0;
+    pbar[CM_P_LIN_K] = m.has_linear ? L * x[6] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pbar[CM_P_YC0 + j] = 0.0;
+}
+
 // which (def_type, yield, line search) combinations have a Newton iteration restricted to its invariant subspace
 // (newton_j2_line, newton_j2_plane): the launchers pick the RL = true kernel variants for them unless CM_SOLVER_GENERAL_NEWTON
 template <int DEF, int YK, bool LS>

@@ -505,9 +505,10 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     constexpr int kLdsDoubles = ((SFAST && LS) ? kLsSlots * kBlock : 0) > kRed * kRedStride ? kLsSlots * kBlock : kRed * kRedStride;
     __shared__ double lds_buf[kLdsDoubles];
     double* const ls_stage = lds_buf;
+    uint32_t st = CM_STATUS_CONVERGED;
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
-            if constexpr (RL) newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
+            if constexpr (RL) st = newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
         else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
@@ -560,7 +561,14 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     // arrays are always passed (never a run-time null): a nullable local array would be forced into scratch
     // (MODE 1 / 3 have no per-point cotangent outputs at all: compile-time nulls let the compiler drop that work)
     constexpr bool BARS = (MODE == 0 || MODE == 2);
-    if constexpr (SFAST) reverse_point_s<YK, true, DEF>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs, z);
+    if constexpr (SFAST && RL && DEF == CM_FULL_3D) {
+        // converged J2 states: the parameter gradient is the derivative of the radial return itself (no transposed solve); a
+        // wavefront holding an unconverged point (iteration cap) differentiates through A(x) at the returned state as the
+        // reference does
+        if (!__any(!(st & CM_STATUS_CONVERGED))) reverse_j2_radial(m, eg, x, sbm, evs, &red[1]);
+        else reverse_point_s<YK, true, DEF>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs, z);
+    }
+    else if constexpr (SFAST) reverse_point_s<YK, true, DEF>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs, z);
     else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
                               BARS ? egbar : nullptr);
     if (BARS && xpbar_out && valid) {

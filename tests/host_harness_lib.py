@@ -65,6 +65,12 @@ def subspace_fallbacks(reset=True):
     return int(L.hh_subspace_fallbacks(int(bool(reset))))
 
 
+def set_radial_vjp(flag):
+    """J2 / FULL_3D: compute the parameter gradient of `vjp` by cm::reverse_j2_radial, the closed form of the fused J2 kernels,
+    instead of the transposed structured solve."""
+    lib().hh_set_radial_vjp(int(bool(flag)))
+
+
 def set_passes(flag):
     """Solve by cm::newton_pass (cm_pool.hpp: the resumable, one-evaluation-per-pass form of the same iteration that the
     work-pool kernels run) instead of cm::newton / cm::newton_s."""

@@ -20,9 +20,11 @@ using namespace cm;
 #if HH_HAS(0)
 int hh_g_dense = 0;       // 1: force the dense 7x7 path also for FULL_3D
 int hh_g_passes = 0;      // 1: solve by cm::newton_pass (the resumable form the work-pool kernels run)
+int hh_g_radial_vjp = 0;  // 1: J2 / FULL_3D parameter gradient by cm::reverse_j2_radial (what the fused J2 kernels use)
 #else
 extern int hh_g_dense;
 extern int hh_g_passes;
+extern int hh_g_radial_vjp;
 #endif
 
 template <int DEF, int YK, bool ROT>
@@ -93,6 +95,14 @@ static void run_vjp(const cm_model_desc& m, int64_t B, const double* gradu, cons
         cotangent_to_material<ROT>(m, sb, sbm);
         if (g_dense) reverse_any<DEF, YK, false>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
         else reverse_any<DEF, YK, true>(m, eg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+        if constexpr (DEF == CM_FULL_3D && YK == CM_YIELD_J2) {
+            if (hh_g_radial_vjp && !xin) {      // the fused J2 kernels' closed-form parameter gradient (cm::reverse_j2_radial)
+                EvalS<CM_YIELD_J2> evs;
+                double C[7];
+                residual_s<CM_YIELD_J2>(m, eg, x, xp, evs, C);
+                reverse_j2_radial(m, eg, x, sbm, evs, pb);
+            }
+        }
         for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
         if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
         if (gbar) for (int c = 0; c < NU; ++c) {
@@ -555,6 +565,7 @@ void hh_exp_s(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n
 #if HH_HAS(0)
 void hh_set_dense(int d) { g_dense = d; }
 void hh_set_passes(int d) { hh_g_passes = d; }
+void hh_set_radial_vjp(int d) { hh_g_radial_vjp = d; }
 // points that left the J2 subspace iterations for the general path since the last reset (cm::subspace_fallbacks)
 long long hh_subspace_fallbacks(int reset) { const long long n = cm::subspace_fallbacks(); if (reset) cm::subspace_fallbacks() = 0; return n; }
 #endif
