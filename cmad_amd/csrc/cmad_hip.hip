@@ -561,11 +561,14 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     // arrays are always passed (never a run-time null): a nullable local array would be forced into scratch
     // (MODE 1 / 3 have no per-point cotangent outputs at all: compile-time nulls let the compiler drop that work)
     constexpr bool BARS = (MODE == 0 || MODE == 2);
-    if constexpr (SFAST && RL && DEF == CM_FULL_3D) {
-        // converged J2 states: the parameter gradient is the derivative of the radial return itself (no transposed solve); a
-        // wavefront holding an unconverged point (iteration cap) differentiates through A(x) at the returned state as the
-        // reference does
-        if (!__any(!(st & CM_STATUS_CONVERGED))) reverse_j2_radial(m, eg, x, sbm, evs, &red[1]);
+    if constexpr (SFAST && RL) {
+        // converged J2 states: the parameter gradient is the derivative of the return map in its own coordinates (the radial
+        // line, the plane: no 7 / 8-dof transposed solve); a wavefront holding an unconverged point (iteration cap)
+        // differentiates through A(x) at the returned state as the reference does
+        if (!__any(!(st & CM_STATUS_CONVERGED))) {
+            if constexpr (DEF == CM_FULL_3D) reverse_j2_radial(m, eg, x, sbm, evs, &red[1]);
+            else reverse_j2_plane(m, eg, z, x, sbm, evs, &red[1]);
+        }
         else reverse_point_s<YK, true, DEF>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs, z);
     }
     else if constexpr (SFAST) reverse_point_s<YK, true, DEF>(m, eg, x, xp, sbm, nullptr, &red[1], nullptr, nullptr, &evs, z);

@@ -103,6 +103,14 @@ static void run_vjp(const cm_model_desc& m, int64_t B, const double* gradu, cons
                 reverse_j2_radial(m, eg, x, sbm, evs, pb);
             }
         }
+        if constexpr (DEF == CM_PLANE_STRESS && YK == CM_YIELD_J2) {
+            if (hh_g_radial_vjp && !xin) {      // ... and the plane's (cm::reverse_j2_plane)
+                EvalS<CM_YIELD_J2> evs;
+                double C[8];
+                residual_s<CM_YIELD_J2, CM_PLANE_STRESS>(m, eg, z, x, xp, evs, C);
+                reverse_j2_plane(m, eg, z, x, sbm, evs, pb);
+            }
+        }
         for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
         if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
         if (gbar) for (int c = 0; c < NU; ++c) {

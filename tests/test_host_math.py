@@ -293,17 +293,18 @@ def test_j2_radial_line_newton_matches_general_path(def_type, rot, solver_varian
 
 
 @pytest.mark.parametrize("rot", [False, True])
-def test_j2_closed_form_parameter_gradient(rot, solver_variant):
-    """cm::reverse_j2_radial (the parameter gradient of the fused J2 / FULL_3D kernels at converged states: derivative of the
-    radial return itself instead of the transposed solve) against the oracle's IFT gradient, two load steps from a hardened
-    state, Voce + linear hardening."""
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_j2_closed_form_parameter_gradient(def_type, rot, solver_variant):
+    """cm::reverse_j2_radial / cm::reverse_j2_plane (the parameter gradient of the fused J2 kernels at converged states: the
+    return map differentiated in its own coordinates instead of the 7 / 8-dof transposed solve) against the oracle's IFT
+    gradient, two load steps from a hardened state."""
     import host_harness_lib as hh
     if solver_variant != "structured":
         pytest.skip("specialisation of the structured path")
     hh.set_radial_vjp(True)
     try:
         for ls in (False, True):
-            pc.check_vjp(BACKEND, pc.Scenario(ol.FULL_3D, "J2", {}, rot, ls, B=1024))
+            pc.check_vjp(BACKEND, pc.Scenario(def_type, "J2", {}, rot, ls, B=1024))
     finally:
         hh.set_radial_vjp(False)
 
