@@ -373,19 +373,25 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
 // summation order, so the result is reproducible bit for bit.  `sh` may alias storage the Newton loop used
 // (hence the leading barrier); it needs NV * kRedStride doubles.
 constexpr int kRedStride = kBlock + 16;      // rows start 32 banks apart: the four 16-lane groups of a wave do not collide
-template <int NV>
+// NACT: only the first NACT values can be non-zero (J2: objective + six parameters) -- the others are written as zeros
+// without passing through LDS, and with NACT <= 64 / kGroup the block's other wavefronts skip the summation altogether.
+template <int NV, int NACT = NV>
 __device__ __forceinline__ void block_reduce_store(const double* v, double* __restrict__ partials, double* sh) {
     // kGroup lanes share a row: each adds kBlock / kGroup = 16 entries, then log2(kGroup) shuffle steps (256 lanes: 16 x 16
     // and four steps; 64 lanes: 4 x 16 and two)
     constexpr int kGroup = kBlock / 16;
-    static_assert((kBlock == 256 || kBlock == 128 || kBlock == 64) && NV <= 16, "thread (k, j) layout: 16 rows of kBlock / 16 lanes");
+    static_assert((kBlock == 256 || kBlock == 128 || kBlock == 64) && NV <= 16 && NACT <= NV, "thread (k, j) layout: 16 rows of kBlock / 16 lanes");
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; ++k) sh[k * kRedStride + threadIdx.x] = v[k];
+    for (int k = 0; k < NACT; ++k) sh[k * kRedStride + threadIdx.x] = v[k];
     __syncthreads();
     const int k = threadIdx.x / kGroup, j = threadIdx.x % kGroup;
+    if (NACT * kGroup <= 64 && threadIdx.x >= 64) {                 // wave-uniform: this wavefront's rows are all zero
+        if (k < NV && j == 0) partials[(int64_t)blockIdx.x * NV + k] = 0.0;
+        return;
+    }
     double a = 0.0;
-    if (k < NV) {
+    if (k < NACT) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) a += sh[k * kRedStride + i * kGroup + j];
     }
@@ -516,6 +522,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
             if (sigma_out) {
+                // from the stored state, as cm_update computes it: the two entry points return bit-identical stresses
                 Eval<DEF> ev;
                 strain_stress<DEF>(m, eg, z, x, ev);
                 double sg[6];
@@ -534,10 +541,13 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
         for (int k = 0; k < 6; ++k) sb[k] = sd[k];
     } else {
         // J = 1/2 sum_r wsq_r (sig_r - data_r)^2 ;  sbar_r = wsq_r (sig_r - data_r)   (qois/calibration.py:56-66)
-        Eval<DEF> ev;
-        strain_stress<DEF>(m, eg, z, x, ev);
         double sg[6];
-        to_global<ROT>(m, ev.s, sg);
+        if constexpr (SFAST && MODE == 1) to_global<ROT>(m, evs.s, sg);       // the solver's evaluation at the returned state
+        else {
+            Eval<DEF> ev;
+            strain_stress<DEF>(m, eg, z, x, ev);
+            to_global<ROT>(m, ev.s, sg);
+        }
         double J = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -596,7 +606,8 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
 #pragma unroll
         for (int k = 0; k < kRed; ++k) red[k] = 0.0;
     }
-    block_reduce_store<kRed>(red, partials, lds_buf);
+    // J2: objective, lambda, mu, Y, S, D, K -- the yield-coefficient slots are identically zero
+    block_reduce_store<kRed, (YK == CM_YIELD_J2) ? 1 + CM_P_YC0 : kRed>(red, partials, lds_buf);
 }
 
 // ---- reverse-mode kernels of the rate-form model (same MODEs as k_reverse; dense LU path) ----------------------
