@@ -542,7 +542,9 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     } else {
         // J = 1/2 sum_r wsq_r (sig_r - data_r)^2 ;  sbar_r = wsq_r (sig_r - data_r)   (qois/calibration.py:56-66)
         double sg[6];
-        if constexpr (SFAST && MODE == 1) to_global<ROT>(m, evs.s, sg);       // the solver's evaluation at the returned state
+        // plain Newton: the solver's evaluation at the returned state (with the line search the six extra live registers cost
+        // the kernel its third wavefront per SIMD)
+        if constexpr (SFAST && MODE == 1 && !LS) to_global<ROT>(m, evs.s, sg);
         else {
             Eval<DEF> ev;
             strain_stress<DEF>(m, eg, z, x, ev);
