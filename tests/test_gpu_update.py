@@ -301,6 +301,75 @@ def test_full_size_properties(line_search):
     assert torch.equal(grad, grad2)
 
 
+@pytest.mark.parametrize("line_search", [False, True])
+def test_full_size_properties_plane_stress(line_search):
+    """10^7 J2 points under PLANE_STRESS (the deformation type of the reference's material-point tests), solved in the
+    coordinates of the J2 plane (newton_j2_plane): every point converges, a random sample agrees with the oracle's 8-dof Newton
+    in state, stress and iteration count, a slice launched alone is bit-identical, sigma_33 vanishes and the yield condition
+    holds on every returned state, re-applying the same strain is a 0-iteration step on EVERY point, and the fused kernel's
+    gradient equals the general path's."""
+    import torch
+    from cmad_amd.models.deformation_types import DefType
+    from cmad_amd.models.device import DeviceEvaluator, NewtonSettings, build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+    B = 10_000_000
+    values = ol.j2_voce_values()
+    newton = NewtonSettings.traced() if line_search else NewtonSettings()
+    ev = DeviceEvaluator(*build_desc(values, def_type=DefType.PLANE_STRESS, newton=newton))
+    g_host = gauss_point_batch(B, seed=23, ndims=2)
+    gradu = torch.from_numpy(g_host).cuda()
+    xi_prev = torch.zeros((8, B), dtype=torch.float64, device="cuda"); xi_prev[7] = 1.0
+    gen = torch.Generator(device="cuda"); gen.manual_seed(8)
+    sbar = torch.randn((6, B), dtype=torch.float64, device="cuda", generator=gen)
+
+    xi, sig, grad = ev.update_and_vjp(gradu, xi_prev, sbar)
+    xi_u, sig_u, st = ev.update(gradu, xi_prev)
+    assert torch.equal(xi, xi_u) and torch.equal(sig, sig_u)
+    st = st.to(torch.int64)
+    assert bool(((st >> 16) & 1).all())
+    iters = st & 0xFFFF
+    assert int(iters.max()) <= 8 and 0.3 < float((iters > 1).double().mean()) < 0.8
+
+    idx = np.sort(np.random.default_rng(6).choice(B, 4096, replace=False))
+    tidx = torch.from_numpy(idx).cuda()
+    mat = ol.Material(values, def_type=ol.PLANE_STRESS)
+    st_o = (ol.newton_settings(ls_kind=ol.LS_TRACED, ls_max_evals=4) if line_search else ol.newton_settings())
+    xp_o = np.zeros((8, idx.size)); xp_o[7] = 1.0
+    xi_o, sig_o, it_o, cv_o = mat.update_batch(st_o, g_host[:, idx], xp_o)
+    np.testing.assert_allclose(xi[:, tidx].cpu().numpy(), xi_o, rtol=1e-10, atol=pc.XI_ATOL)
+    np.testing.assert_allclose(sig[:, tidx].cpu().numpy(), sig_o, rtol=1e-10, atol=1e-8)
+    assert float(np.mean(iters[tidx].cpu().numpy() == it_o)) > 0.995
+
+    lo, n = 4_444_444, 100_003
+    xi_s, sig_s, _ = ev.update(gradu[:, lo:lo + n].contiguous(), xi_prev[:, lo:lo + n].contiguous())
+    assert torch.equal(xi_s, xi[:, lo:lo + n]) and torch.equal(sig_s, sig[:, lo:lo + n])
+
+    E, nu, Y, S, D = 200e3, 0.3, 200.0, 200.0, 20.0
+    two_mu = E / (1.0 + nu)
+    assert float(sig[5].abs().max()) < 1e-8 * Y                         # plane stress: sigma_33 = 0 (Q = I)
+    w = torch.tensor([1.0, 2.0, 2.0, 1.0, 2.0, 1.0], dtype=torch.float64, device="cuda")[:, None]
+    p = (sig[0] + sig[3] + sig[5]) / 3.0
+    dev = sig.clone(); dev[0] -= p; dev[3] -= p; dev[5] -= p
+    vm = torch.sqrt(1.5 * (w * dev * dev).sum(0))
+    alpha = xi[6]
+    f = (vm - Y - S * (1.0 - torch.exp(-D * alpha))) / two_mu
+    plastic = alpha > 0
+    assert float(f[plastic].abs().max()) < 1e-13 and float(f[~plastic].max()) < 1e-14
+    assert float((xi[0] + xi[3] + xi[5]).abs().max()) < 1e-15
+
+    xi2, sig2, st2 = ev.update(gradu, xi)                                # idempotence, every point
+    assert bool(((st2.to(torch.int64) & 0xFFFF) == 0).all())
+    assert torch.equal(xi2, xi)
+
+    general = DeviceEvaluator(*build_desc(values, def_type=DefType.PLANE_STRESS,
+                                          newton=NewtonSettings(line_search=newton.line_search, j2_radial_line=False)))
+    sl = slice(0, 2_000_000)
+    xg, sg, gg = general.update_and_vjp(gradu[:, sl].contiguous(), xi_prev[:, sl].contiguous(), sbar[:, sl].contiguous())
+    xf, sf, gf = ev.update_and_vjp(gradu[:, sl].contiguous(), xi_prev[:, sl].contiguous(), sbar[:, sl].contiguous())
+    np.testing.assert_allclose(xf.cpu().numpy(), xg.cpu().numpy(), rtol=1e-10, atol=pc.XI_ATOL)
+    np.testing.assert_allclose(gf.cpu().numpy(), gg.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(gg.abs().max()))
+
+
 def test_full_size_objective_consistency():
     """configs[4] per-GPU size (10^7 points): the fused objective kernel against the update and vjp kernels run
     separately -- J = 1/2 sum w^2 (sigma - data)^2 from the stored stresses, gradient = vjp with
