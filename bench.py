@@ -207,7 +207,7 @@ def main():
     ap.add_argument("--yield-surface", default="j2", choices=["j2", "hill", "hosford8", "barlat8"],
                     help="j2_* workloads with another yield surface (side measurements): Al7079 Hill coefficients, "
                          "Hosford a = 8, Yld2004-18p with the Al7079 coefficients and a = 8")
-    ap.add_argument("--def-type", default="full_3d", choices=["full_3d", "plane_stress"],
+    ap.add_argument("--def-type", default="full_3d", choices=["full_3d", "plane_stress", "uniaxial_stress"],
                     help="J2 workloads: plane_stress is a side measurement (the reference's material-point tests' type)")
     ap.add_argument("--workload", default="j2_update_vjp",
                     choices=["j2_update_vjp", "j2_update", "j2_update_tangent", "j2_objective_grad", "hosford_update",
@@ -281,20 +281,22 @@ def main():
     # algorithmic bytes per point: rows of 8 bytes read (grad u, xi_prev, sigma_bar / data) and written (xi, sigma,
     # tangent); FULL_3D n_gradu = 9, n_xi = 7 -> 232 / 280 / 176 / 664; PLANE_STRESS n_gradu = 4, n_xi = 8 -> 208 / 256 / 144 / 400
     ps = args.def_type == "plane_stress"
-    if ps:
-        assert wl.startswith("j2_"), "--def-type plane_stress applies to the J2 workloads"
-    n_gradu, n_xi = (4, 8) if ps else (9, 7)
+    ux = args.def_type == "uniaxial_stress"
+    if ps or ux:
+        assert wl.startswith("j2_"), "--def-type applies to the J2 workloads"
+    n_gradu, n_xi = (4, 8) if ps else ((1, 9) if ux else (9, 7))
     reads = n_gradu + n_xi + (6 if (wl.endswith("_vjp") or wl == "j2_objective_grad") else 0)
     writes = 0 if wl == "j2_objective_grad" else n_xi + 6 + (6 * n_gradu if wl == "j2_update_tangent" else 0)
     bytes_per_update = 8 * (reads + writes)
     from cmad_amd.models.deformation_types import DefType
     newton.lockstep = bool(args.lockstep)
-    desc, info = build_desc(values, def_type=DefType.PLANE_STRESS if ps else DefType.FULL_3D, newton=newton, hybrid=hybrid)
+    desc, info = build_desc(values, def_type=DefType.PLANE_STRESS if ps else (DefType.UNIAXIAL_STRESS if ux else DefType.FULL_3D),
+                            newton=newton, hybrid=hybrid)
     ev = DeviceEvaluator(desc, info)
-    nxi = 8 if ps else 7
+    nxi = n_xi
 
     # resident inputs (disjoint shard per rank: seed + rank)
-    g_host = gauss_point_batch(B, seed=22 + rank, eps_y=eps_y, ndims=2 if ps else 3)
+    g_host = gauss_point_batch(B, seed=22 + rank, eps_y=eps_y, ndims=2 if ps else (1 if ux else 3))
     if args.coherent:
         nd = 2 if ps else 3
         e = 0.5 * (g_host.reshape(nd, nd, B) + g_host.reshape(nd, nd, B).transpose(1, 0, 2))
@@ -302,15 +304,15 @@ def main():
         g_host = np.ascontiguousarray(g_host[:, np.argsort(mag, kind="stable")])
     gradu = torch.from_numpy(g_host).to(dev)
     xi_prev = torch.zeros((nxi, B), dtype=torch.float64, device=dev)
-    if ps:
-        xi_prev[7] = 1.0                           # F33 starts at 1 (small_elastic_plastic.py:161-169)
+    if ps or ux:
+        xi_prev[7:] = 1.0                          # F33 (lateral stretches) start at 1 (small_elastic_plastic.py:161-180)
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
     sigma_bar = torch.randn((6, B), dtype=torch.float64, device=dev, generator=gen)
     out = {"xi": torch.empty((nxi, B), dtype=torch.float64, device=dev),
            "sigma": torch.empty((6, B), dtype=torch.float64, device=dev),
            "grad": torch.empty(12, dtype=torch.float64, device=dev)}
     if wl == "j2_update_tangent":
-        out["dsigma"] = torch.empty((6 * (4 if ps else 9), B), dtype=torch.float64, device=dev)
+        out["dsigma"] = torch.empty((6 * n_gradu, B), dtype=torch.float64, device=dev)
 
     # two result buffers: the all-reduce of step k (RCCL's own stream) overlaps the kernel of step k+1
     grads = [torch.empty(12, dtype=torch.float64, device=dev) for _ in range(2)]
@@ -447,8 +449,8 @@ def main():
                              "hosford_update_vjp": "Hosford a=100 stress update + vjp w.r.t. parameters (configs[2] material; side measurement)",
                              "hybrid_update_vjp": "hybrid Hill + ICNN[6,16,1] stress update + vjp w.r.t. parameters (configs[3] material; "
                                                   "side measurement)"}[wl]
-                            .replace("FULL_3D", "PLANE_STRESS (side measurement)" if ps else "FULL_3D")
-                            .replace(" (BASELINE.json configs[1])", "" if (ps or args.yield_surface != "j2") else " (BASELINE.json configs[1])"),
+                            .replace("FULL_3D", "PLANE_STRESS (side measurement)" if ps else ("UNIAXIAL_STRESS (side measurement)" if ux else "FULL_3D"))
+                            .replace(" (BASELINE.json configs[1])", "" if (ps or ux or args.yield_surface != "j2") else " (BASELINE.json configs[1])"),
                 "def_type": args.def_type, "yield_surface": args.yield_surface, "points_per_gpu": B, "plastic_fraction": round(plastic_frac, 4),
                 "point_order": "sorted by deviatoric strain (coherent wavefronts)" if args.coherent else "uncorrelated",
                 "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
@@ -464,7 +466,7 @@ def main():
                                "step, double-buffered so it overlaps the next step's kernel",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(B) if (wl == "j2_update_vjp" and not ps and args.yield_surface == "j2") else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(B) if (wl == "j2_update_vjp" and not (ps or ux) and args.yield_surface == "j2") else None,
                          "kernel": {"j2_update_vjp": "k_reverse<FULL_3D,J2,noROT,noLS,fused update+vjp,radial-line>"
                                     if not (args.general_newton or args.ls_evals > 0 or ps) else
                                     "k_reverse<J2,noROT,fused update+vjp>",
@@ -488,7 +490,7 @@ def main():
                                            "mean": float(np.mean(host_issue_ms))},
                          "per_rank_kernel_ms": per_rank_kernel_ms},
         }
-        if (n == 1 and wl == "j2_update_vjp" and not ps and args.ls_evals == 0 and not args.general_newton
+        if (n == 1 and wl == "j2_update_vjp" and not (ps or ux) and args.ls_evals == 0 and not args.general_newton
                 and args.yield_surface == "j2"):
             # the same workload (i) on the general 7-dof Newton path (no J2 specialisation) and (ii) with
             # make_newton_solve's default line search (4 evaluations; for J2 every full step passes the Armijo test,

@@ -765,6 +765,10 @@ template <int DEF, int YK, bool LS>
 constexpr bool has_j2_subspace() {
     return YK == CM_YIELD_J2 && (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS);
 }
+// what the launchers test to pick the RL = true kernel variants (UNIAXIAL_STRESS needs no variant: its kernels always take the
+// 9 x 9 Newton step through the 4 x 4 form, uniaxial_solve in cm_device.hpp, which is the same step)
+template <int DEF, int YK, bool LS>
+constexpr bool has_fast_newton() { return has_j2_subspace<DEF, YK, LS>(); }
 template <int DEF, bool LS>
 CM_D uint32_t newton_j2_sub(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
                             bool lane_valid, EvalS<CM_YIELD_J2>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
@@ -935,7 +939,7 @@ CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const doubl
         if constexpr (RL) return newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, ev, stage);
         else return newton_s<YK, LS, DEF>(m, eg, xp, x, valid, ev, stage, z);
     }
-    else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, valid);
+    else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS, STRUCT>(m, eg, z, xp, x, valid);   // STRUCT = false: the dense reference path
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
@@ -943,13 +947,13 @@ CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z
                       double* lam_out = nullptr) {
     if constexpr (STRUCT && has_structured<DEF, YK>())
         return reverse_point_s<YK, false, DEF>(m, eg, x, xp, sbm, xin, pbar, xpbar, egbar, nullptr, z, lam_out);
-    else return reverse_point<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, egbar, lam_out);
+    else return reverse_point<DEF, YK, STRUCT>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, egbar, lam_out);   // STRUCT = false: the dense reference path
 }
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool tangent_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
                       double (&T)[6][6]) {
     if constexpr (STRUCT && has_structured<DEF, YK>()) return tangent_point_s<YK, DEF>(m, eg, x, xp, T, z);
-    else return tangent_point<DEF, YK>(m, eg, z, x, xp, T);
+    else return tangent_point<DEF, YK, STRUCT>(m, eg, z, x, xp, T);
 }
 
 

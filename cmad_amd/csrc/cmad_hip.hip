@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
             if constexpr (RL) st = newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
-        else newton_any<DEF, YK, LS>(m, eg, z, xp, x, valid);
+        else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid);
         load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
@@ -1135,7 +1135,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
     const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (has_j2_subspace<D, Y, LS>()) {
+        if constexpr (has_fast_newton<D, Y, LS>()) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
                 return;
@@ -1181,7 +1181,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         // CM_DEBUG_DYN_LDS=<bytes>: occupancy experiments only (extra dynamic LDS per block limits blocks per CU)
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
         const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (has_j2_subspace<D, Y, LS>() && (MODE == 1 || MODE == 3)) {
+            if constexpr (has_fast_newton<D, Y, LS>() && (MODE == 1 || MODE == 3)) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_reverse<D, Y, R, LS, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                        hist_in, xi_out, sigma_out, xpbar, gbar, partials);
@@ -1251,7 +1251,7 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
         const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<D, Y, LS>()) {
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<D, Y, LS>()) {
                 if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                     hipLaunchKernelGGL((k_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
                     return;
@@ -1281,7 +1281,7 @@ int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double
     const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<D, Y, LS>()) {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<D, Y, LS>()) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
                 return;

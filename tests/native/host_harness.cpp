@@ -47,7 +47,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
                     : newton_by_passes<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, false>(m, eg, z, xp, x, stage);
             done = true;
         }
-        if constexpr (has_j2_subspace<DEF, YK, false>()) {          // same choice as launch_update (cmad_hip.hip)
+        if constexpr (has_fast_newton<DEF, YK, false>()) {          // same choice as launch_update (cmad_hip.hip)
             if (!done && !g_dense && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 st = ls ? newton_any<DEF, YK, true, true, true>(m, eg, z, xp, x, true, stage)
                         : newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
@@ -310,7 +310,7 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
         const LaneStage stage{parked, 1};
         const HostRowsIO io{B, b};
         bool done = false;
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<DEF, YK, false>()) {   // same choice as launch_history
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<DEF, YK, false>()) {   // same choice as launch_history
             if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 if (ls) history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
                 else history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
@@ -333,7 +333,7 @@ static void run_primal_history(const cm_model_desc& m, int64_t B, int K, const d
         const LaneStage stage{parked, 1};
         const HostRowsIO io{B, b};
         bool done = false;
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_j2_subspace<DEF, YK, false>()) {
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<DEF, YK, false>()) {
             if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
                 if (ls) primal_history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
                 else primal_history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
