@@ -35,45 +35,49 @@ def settings_pair(ls):
     return ol.newton_settings(), NewtonSettings()
 
 
-def param_paths(yield_kind):
-    p = [("elastic", "E"), ("elastic", "nu"),
-         ("plastic", "flow stress", "initial yield", "Y"),
-         ("plastic", "flow stress", "hardening", "voce", "S"),
-         ("plastic", "flow stress", "hardening", "voce", "D")]
+def param_paths(yield_kind, values=None):
+    """Leaves compared with the oracle: the analytical problem's (Voce) by default, the hardening laws actually present in
+    `values` when a tree is given."""
+    hard = {"voce": {"S": 0, "D": 0}} if values is None else values["plastic"]["flow stress"].get("hardening", {})
+    p = [("elastic", "E"), ("elastic", "nu"), ("plastic", "flow stress", "initial yield", "Y")]
+    p += [("plastic", "flow stress", "hardening", law, name) for law in ("voce", "linear") if law in hard for name in hard[law]]
     if yield_kind == "hill":
         p += [("plastic", "effective stress", "hill", n) for n in ol.HILL_NAMES]
     return p
 
 
-def leaf_grads(g_kp, info, mat, yield_kind, g_oracle):
+def leaf_grads(g_kp, info, mat, yield_kind, g_oracle, values=None):
     from cmad_amd.models.device import kp_to_leaf_grad
-    got = np.array([kp_to_leaf_grad(path, g_kp, info) for path in param_paths(yield_kind)])
-    ref = np.array([g_oracle[mat.param_index(path)] for path in param_paths(yield_kind)])
+    paths = param_paths(yield_kind, values)
+    got = np.array([kp_to_leaf_grad(path, g_kp, info) for path in paths])
+    ref = None if g_oracle is None else np.array([g_oracle[mat.param_index(path)] for path in paths])
     return got, ref
 
 
 class Scenario:
     """Material + a non-trivial previous state + a load step, with the oracle's answers."""
 
-    def __init__(self, def_type, yield_kind, kw, rot, ls, B, seed=22, uniaxial_idx=0):
+    def __init__(self, def_type, yield_kind, kw, rot, ls, B, seed=22, uniaxial_idx=0, values=None, eps_y=1e-3):
+        """values: a complete parameter tree instead of the J2AnalyticalProblem one (eps_y = its yield strain, the scale of the
+        synthetic strains)."""
         from cmad_amd.models.device import build_desc
         from cmad_amd.synthetic import gauss_point_batch
         rng = np.random.default_rng(seed)
         self.yield_kind = yield_kind
-        self.values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+        self.values = values if values is not None else ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
         self.nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
         self.st_o, self.st_d = settings_pair(ls)
         self.B = B
         if def_type == ol.UNIAXIAL_STRESS:                 # grad u = the axial strain, +-4 yield strains
             self.mat = ol.Material(self.values, def_type=def_type, uniaxial_idx=uniaxial_idx)
             self.desc, self.info = build_desc(self.values, def_type=def_type, newton=self.st_d, uniaxial_stress_idx=uniaxial_idx)
-            g0 = np.random.default_rng(seed + 2).uniform(-4e-3, 4e-3, size=(1, B))
-            g1 = np.random.default_rng(seed + 3).uniform(-4e-3, 4e-3, size=(1, B))
+            g0 = np.random.default_rng(seed + 2).uniform(-4 * eps_y, 4 * eps_y, size=(1, B))
+            g1 = np.random.default_rng(seed + 3).uniform(-4 * eps_y, 4 * eps_y, size=(1, B))
         else:
             self.mat = ol.Material(self.values, def_type=def_type)
             self.desc, self.info = build_desc(self.values, def_type=def_type, newton=self.st_d)
-            g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=self.nd)
-            g1 = gauss_point_batch(B, seed=seed + 1, skew=True, ndims=self.nd)
+            g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=self.nd, eps_y=eps_y)
+            g1 = gauss_point_batch(B, seed=seed + 1, skew=True, ndims=self.nd, eps_y=eps_y)
         self.gradu0 = g0
         self.xi0 = np.tile(self.mat.init_xi()[:, None], (1, B))
         self.xi1, self.sig1, self.it1, self.cv1 = self.mat.update_batch(self.st_o, g0, self.xi0)
@@ -117,7 +121,7 @@ def check_vjp(backend, sc, incoming=False, grad_atol=1e-12):
     g_d, xb_d, ub_d = backend.vjp(sc, sc.gradu, sc.xi1, sc.xi2, sbar)
     np.testing.assert_allclose(xb_d, xb_o, rtol=1e-9, atol=1e-9 * np.abs(xb_o).max())
     np.testing.assert_allclose(ub_d, ub_o, rtol=1e-9, atol=1e-9 * np.abs(ub_o).max())
-    got, ref = leaf_grads(g_d, sc.info, sc.mat, sc.yield_kind, g_o)
+    got, ref = leaf_grads(g_d, sc.info, sc.mat, sc.yield_kind, g_o, sc.values)
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=grad_atol * np.abs(ref).max())
     return sbar, ref
 
@@ -165,6 +169,69 @@ class GpuBackend:
         g, xb, ub = self.ev(sc).update_vjp(self.t(gradu), self.t(xi_prev), self.t(xi), self.t(sbar),
                                            want_xi_prev_bar=True, want_gradu_bar=True)
         return g.cpu().numpy(), xb.cpu().numpy(), ub.cpu().numpy()
+
+    def fused(self, sc, gradu, xi_prev, sbar, data, wsq6):
+        """cm_update_and_vjp and cm_objective_grad (the fused kernels): (xi, sigma, grad_kp), (J, grad_kp)"""
+        ev = self.ev(sc)
+        xi, sig, g = ev.update_and_vjp(self.t(gradu), self.t(xi_prev), self.t(sbar))
+        res, _ = ev.objective_grad(self.t(gradu), self.t(xi_prev), self.t(data), wsq6)
+        res = res.cpu().numpy()
+        return (xi.cpu().numpy(), sig.cpu().numpy(), g.cpu().numpy()), (res[0], res[1:])
+
+
+def random_material(rng, yield_kind, ls=True):
+    """A random but physical parameter tree: elastic constants, yield stress, Voce and / or linear hardening, a random
+    orientation, Hill coefficients around the isotropic 1/2 (3/2 for the shear ones) or a Hosford exponent."""
+    E, nu = rng.uniform(50e3, 250e3), rng.uniform(0.15, 0.42)
+    Y = rng.uniform(0.5e-3, 4e-3) * E
+    hard = {}
+    kind = rng.integers(0, 3)
+    if kind in (0, 2):
+        hard["voce"] = {"S": float(rng.uniform(0.2, 1.5) * Y), "D": float(rng.uniform(2.0, 200.0))}
+    if kind in (1, 2):
+        hard["linear"] = {"K": float(rng.uniform(0.005, 0.2) * E)}
+    if yield_kind == "J2":
+        eff = {"J2": 0.}
+    elif yield_kind == "hill":
+        c = np.r_[0.5 * rng.uniform(0.6, 1.5, 3), 1.5 * rng.uniform(0.6, 1.5, 3)]
+        eff = {"hill": dict(zip(ol.HILL_NAMES, [float(v) for v in c]))}
+    else:
+        # plain Newton (10 iterations, no line search) does not converge from these load steps for the sharper surfaces -- in the
+        # reference either -- so they are drawn only with the line search on
+        eff = {"hosford": {"a": float(rng.choice([4.0, 6.0, 8.0, 12.5] if ls else [4.0, 5.0, 6.0]))}}
+    values = {"rotation matrix": rand_rot(rng), "elastic": {"E": float(E), "nu": float(nu)},
+              "plastic": {"effective stress": eff, "flow stress": {"initial yield": {"Y": float(Y)}, "hardening": hard}}}
+    return values, Y / E
+
+
+def check_random_materials(backend, def_type, yield_kind, ls, seeds=range(6), B=192):
+    """Update (two load steps, states, stresses, iteration counts), consistent tangent and VJP against the oracle for randomly
+    drawn materials -- the J2 line / plane iterations, the closed-form gradients and the UNIAXIAL_STRESS step must not lean on the
+    one material of the analytical problem."""
+    for seed in seeds:
+        rng = np.random.default_rng(1000 + 17 * seed + def_type)
+        values, eps_y = random_material(rng, yield_kind, ls)
+        sc = Scenario(def_type, yield_kind, {}, True, ls, B, seed=50 + seed, uniaxial_idx=int(rng.integers(0, 3)), values=values, eps_y=eps_y)
+        check_update(backend, sc)
+        check_tangent(backend, sc)
+        sbar, ref = check_vjp(backend, sc, grad_atol=1e-10)
+        if hasattr(backend, "fused"):
+            # the fused kernels (closed-form J2 gradients, work-pool routes): same state, stress, gradient; the objective's
+            # gradient is the VJP with sigma_bar = wsq o (sigma - data)
+            wsq6 = [1.0, 0.5, 2.0, 1.0, 0.0, 1.5]
+            data = sc.sig2 + 0.05 * np.abs(sc.sig2).max() * np.random.default_rng(seed).normal(size=sc.sig2.shape)
+            (xi_f, sig_f, g_f), (J_f, gJ_f) = backend.fused(sc, sc.gradu, sc.xi1, sbar, data, wsq6)
+            np.testing.assert_allclose(xi_f, sc.xi2, rtol=1e-10, atol=XI_ATOL)
+            np.testing.assert_allclose(sig_f, sc.sig2, rtol=1e-10, atol=1e-8)
+            got, _ = leaf_grads(g_f, sc.info, sc.mat, sc.yield_kind, None, sc.values)
+            # (UNIAXIAL_STRESS: d/d nu vanishes analytically and is left with the round-off of O(1) cancelling terms)
+            np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+            w = np.asarray(wsq6)[:, None]
+            J_o = 0.5 * float((w * (sc.sig2 - data) ** 2).sum())
+            assert abs(J_f - J_o) <= 1e-9 * abs(J_o)
+            gJ_o, _, _ = sc.mat.update_vjp_batch(sc.gradu, sc.xi1, sc.xi2, w * (sc.sig2 - data))
+            gotJ, refJ = leaf_grads(gJ_f, sc.info, sc.mat, sc.yield_kind, gJ_o, sc.values)
+            np.testing.assert_allclose(gotJ, refJ, rtol=1e-8, atol=1e-9 * np.abs(refJ).max())
 
 
 def check_hosford_a100(backend, B=2048):

@@ -86,6 +86,15 @@ def test_hybrid_hill_icnn(backend, def_type):
     pc.check_hybrid_nn(backend, def_type, B=2048, rot=(def_type == ol.FULL_3D))
 
 
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_random_materials(backend, def_type, yield_kind, ls):
+    """Randomly drawn materials (elastic constants, yield stress, Voce and / or linear hardening, orientation, Hill coefficients /
+    Hosford exponent; uniaxial axis): update over two load steps, consistent tangent and VJP against the oracle."""
+    pc.check_random_materials(backend, def_type, yield_kind, ls, seeds=range(6), B=320)
+
+
 @pytest.mark.parametrize("surface", ["hybrid", "hosford100"])
 def test_work_pool_route_equals_lockstep_kernels(surface):
     """The iteration-bound configurations run cm_update on the work pool, and the fused entry points (cm_update_and_vjp,

@@ -279,6 +279,15 @@ def test_rate_model_explicit_blocks(def_type, yield_kind, kw, rot, solver_varian
     assert nplastic > 0
 
 
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_random_materials(def_type, yield_kind, ls, solver_variant):
+    if solver_variant == "passes" and not ls:
+        pytest.skip("one pass-based variant is enough")
+    pc.check_random_materials(BACKEND, def_type, yield_kind, ls, seeds=range(3), B=96)
+
+
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_j2_radial_line_newton_matches_general_path(def_type, rot, solver_variant):
