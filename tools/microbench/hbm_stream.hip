@@ -29,6 +29,23 @@ __global__ __launch_bounds__(BLOCK) void soa_rows(const double* __restrict__ in,
     if (NW == 0 && s == 1.2345e301) sink[0] = s;
 }
 
+// the same with separate hints for reads and writes
+template <int NR, int NW, bool NTR, bool NTW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void soa_rows_mixed(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ sink, int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    double v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = NTR ? ldnt(in + r * B + b) : in[r * B + b];
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s += v[r];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (NTW) __builtin_nontemporal_store(s + w, out + w * B + b); else out[w * B + b] = s + w;
+    }
+}
+
 // two points per lane (16-byte loads), same rows
 template <int NR, int NW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void soa_rows_x2(const double* __restrict__ in, double* __restrict__ out, double* __restrict__ sink, int64_t B) {
@@ -112,6 +129,10 @@ int main(int argc, char** argv) {
     }
     report("headline layout: 22 rows read + 13 written, block 128, nt", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 13, true, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
     report("headline layout: 22 rows read + 13 written, block 128", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 13, false, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
+    report("headline layout: 22 rows read + 13 written, block 64, nt", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 13, true, 64>), dim3(nb64), dim3(64), 0, 0, in, out, sink, B); }));
+    report("headline layout: 22 rows read + 13 written, block 256, nt", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<22, 13, true, 256>), dim3(nb256), dim3(256), 0, 0, in, out, sink, B); }));
+    report("headline layout: nt reads, cached writes, block 128", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_mixed<22, 13, true, false, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
+    report("headline layout: cached reads, nt writes, block 128", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_mixed<22, 13, false, true, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
     report("headline layout: 2 pt/lane (16 B accesses)", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_x2<22, 13, 128>), dim3((B / 2 + 127) / 128), dim3(128), 0, 0, in, out, sink, B); }));
     report("headline layout: persistent, 4096 blocks of 128", 280.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows_persistent<22, 13, 128>), dim3(4096), dim3(128), 0, 0, in, out, sink, B); }));
     report("update layout: 16 rows read + 13 written, block 128, nt", 232.0 * B, time_us([&] { hipLaunchKernelGGL((soa_rows<16, 13, true, 128>), dim3(nb128), dim3(128), 0, 0, in, out, sink, B); }));
