@@ -1649,18 +1649,34 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
 //   lam = A^-T ([sbar_m ; 0] + xin) ,  pbar = -(dC/dp)^T lam ,  xpbar = -(dC/dx_prev)^T lam ,
 //   degbar = -(dC/d deg)^T lam   (cotangent of the material strain INCREMENT; grad u gets +, grad u_prev gets -).
 // Block formulas: evaluate_blocks_rate below (checked there against the oracle's dual-number Jacobians).
-template <int DEF, int YK>
+// SOLVE_T: how A^-T is applied -- the dense 7x7 / 8x8 LU here, the structured solver of the total form through the
+// change of variables of cm::newton_s_rate (StructRateSolveT, cm_structured.hpp)
+struct DenseRateSolveT {
+    template <int DEF, int YK>
+    CM_D bool apply(const cm_model_desc& m, const double z[6], const double*, const double*, const Eval<DEF>& ev, const double Ht[6][6],
+                    double* lam) const {
+        constexpr int NX = Dims<DEF>::NX;
+        double At[NX][NX], b[NX];
+        jacobian_rate<DEF, true>(m, z, ev, Ht, At);
+        const bool ok = lu_factor<NX>(At);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) b[k] = lam[k];
+        lu_subst<NX>(At, b);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) lam[k] = b[k];
+        return ok;
+    }
+};
+template <int DEF, int YK, class SOLVE_T = DenseRateSolveT>
 CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const double z[6],
                              const double* x, const double* xp, const double sbm[6], const double* xin,
-                             double* pbar, double* xpbar, double* degbar, double* lam_out = nullptr) {
+                             double* pbar, double* xpbar, double* degbar, double* lam_out = nullptr, const SOLVE_T solve_t = SOLVE_T{}) {
     static_assert(DEF != CM_UNIAXIAL_STRESS, "batched rate-form reverse sweep: FULL_3D and PLANE_STRESS");
     constexpr int NX = Dims<DEF>::NX;
     constexpr bool PS = (DEF == CM_PLANE_STRESS);
     Eval<DEF> ev;
-    double C[NX], Ht[6][6], At[NX][NX], lam[NX];
+    double C[NX], Ht[6][6], lam[NX];
     residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
-    jacobian_rate<DEF, true>(m, z, ev, Ht, At);
-    const bool ok = lu_factor<NX>(At);
 #pragma unroll
     for (int k = 0; k < 6; ++k) lam[k] = sbm[k];
 #pragma unroll
@@ -1669,7 +1685,7 @@ CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const 
 #pragma unroll
         for (int k = 0; k < NX; ++k) lam[k] += xin[k];
     }
-    lu_subst<NX>(At, lam);
+    const bool ok = solve_t.template apply<DEF, YK>(m, z, x, xp, ev, Ht, lam);      // lam <- A^-T lam
     if (lam_out) {
 #pragma unroll
         for (int k = 0; k < NX; ++k) lam_out[k] = lam[k];

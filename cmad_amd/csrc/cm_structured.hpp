@@ -372,22 +372,29 @@ struct LaneStage {
     CM_D volatile double& at(int k) const { return const_cast<volatile double*>(p)[k * stride]; }
 };
 
-template <int YK, bool LS, int DEF = CM_FULL_3D>
+// ||C||^2 as the convergence test and the line search's merit see it: the plain sum of squares, or (NORM = RateNorm below) the
+// norm of a constant linear image of C -- Newton's iterates do not depend on such a map, its stopping test does.
+struct PlainNorm {
+    template <int NX> CM_D double sq(const double* C) const { return dot<NX>(C, C); }
+};
+// x0 (optional): start of the iteration when it is not x_prev (newton_s_rate)
+template <int YK, bool LS, int DEF = CM_FULL_3D, class NORM = PlainNorm>
 CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
-                       EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}, const double* z = nullptr) {
+                       EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}, const double* z = nullptr,
+                       const NORM norm = NORM{}, const double* x0 = nullptr) {
     constexpr int NX = Dims<DEF>::NX;
     double C[NX];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) x[k] = xp[k];
+    for (int k = 0; k < NX; ++k) x[k] = x0 ? x0[k] : xp[k];
     residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);
-    const double n0sq = dot<NX>(C, C);             // squared-norm form of nonlinear_solver.py:140-150, see cm::newton
+    const double n0sq = norm.template sq<NX>(C);   // squared-norm form of nonlinear_solver.py:140-150, see cm::newton
     const double rel2 = m.rel_tol * m.rel_tol * n0sq, abs2 = m.abs_tol * m.abs_tol;
     int it = 0;
     bool running = lane_valid;
     uint32_t flags = 0;
     if constexpr (!LS) {
         for (;;) {
-            const double nsq = dot<NX>(C, C);
+            const double nsq = norm.template sq<NX>(C);
             const bool conv = (nsq < rel2) || (nsq < abs2);
             if (running && conv) { running = false; flags |= CM_STATUS_CONVERGED; }
             if (running && it >= m.max_iters) running = false;
@@ -419,7 +426,7 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
             if (running && phase != 0) {
                 bool commit = (phase == 2);
                 if (phase == 1) {
-                    const double phi = 0.5 * dot<NX>(C, C);            // merit; phi(0) = cc / 2, phi'(0) = -cc
+                    const double phi = 0.5 * norm.template sq<NX>(C);            // merit; phi(0) = cc / 2, phi'(0) = -cc
                     const bool finite = isfinite(phi);
                     if (finite && phi < best_phi) { best_alpha = alpha; best_phi = phi; }
                     const bool accepted = finite && (phi <= 0.5 * cc + alpha * (m.ls_c1 * -cc));
@@ -451,7 +458,7 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
                 if (commit) { phase = 0; ++it; }
             }
             if (running && phase == 0) {
-                const double nsq = dot<NX>(C, C);
+                const double nsq = norm.template sq<NX>(C);
                 const bool conv = (nsq < rel2) || (nsq < abs2);
                 if (conv) { running = false; flags |= CM_STATUS_CONVERGED; }
                 else if (it >= m.max_iters) running = false;
@@ -941,6 +948,120 @@ CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const doubl
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS, STRUCT>(m, eg, z, xp, x, valid);   // STRUCT = false: the dense reference path
 }
+// ---- rate-form model on the structured solver -----------------------------------------------------------------------------------
+// cmad/models/small_rate_elastic_plastic.py:249-346: unknown x = [sigma(6), alpha (, F33)], residual
+//   C_sigma = (sigma - sigma_prev - Cel (deg + (F33 - F33_prev) z) + dgam Cel n) / 2mu ,  C_6 = f or dgam ,  C_7 = (w o z) . (Cel de - dgam Cel n) / 2mu.
+// With v defined by  sigma = Cel (E0 + (F33 - F33_prev) z - v),  E0 = Cel^-1 sigma_prev + deg,  this is
+//   C_sigma = -Cel (v - dgam n) / 2mu ,  C_7 = (w o z) . sigma / 2mu - (w o z) . sigma_prev / 2mu - (w o z) . C_sigma :
+// an affine change of variables and a CONSTANT nonsingular linear map of the total-form residual [v - dgam n, C_6, (w o z) . sigma / 2mu]
+// of a point with strain E0, previous plastic strain 0 and previous stretch 1.  Newton's iterates are invariant under both, so the
+// rate-form iteration started at sigma_prev is the total-form iteration in v started at v = deg -- same Jacobian, same structured
+// solve (3x3 + shear, dense-surface 6x6), every yield surface -- with the convergence test and the line search's merit taken on the
+// mapped residual (RateNorm).  Same iterates and iteration counts as cm::newton<DEF, YK, RATE> (host tests run both against the
+// oracle); ~2.5x (FULL_3D) to 4x (PLANE_STRESS) fewer instructions than the dense 7x7 / 8x8 path.
+template <int DEF>
+struct RateNorm {
+    double l2;             // lambda / 2mu
+    const double* z;       // PLANE_STRESS: V(q3 q3^T)
+    double c7_shift;       // (w o z) . sigma_prev / 2mu
+    template <int NX> CM_D double sq(const double* C) const {
+        const double t = l2 * (C[0] + C[3] + C[5]);
+        double n = C[6] * C[6], zc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double cs = C[k] + (kDiag[k] ? t : 0.0);              // -(C_sigma)_k = (Cel C_v)_k / 2mu
+            n += cs * cs;
+            if constexpr (DEF == CM_PLANE_STRESS) zc += kW[k] * z[k] * cs;
+        }
+        if constexpr (DEF == CM_PLANE_STRESS) { const double c7 = C[7] - c7_shift + zc; n += c7 * c7; }
+        return n;
+    }
+};
+template <int YK, bool LS, int DEF>
+CM_D uint32_t newton_s_rate(const cm_model_desc& m, const double deg[6], const double* z, const double* xp, double* x,
+                            bool lane_valid, LaneStage stage = LaneStage{nullptr, 0}) {
+    constexpr int NX = Dims<DEF>::NX;
+    constexpr bool PS = (DEF == CM_PLANE_STRESS);
+    const double i2mu = half_over_mu(m), trs = xp[0] + xp[3] + xp[5];
+    const double cc = m.lambda * rcp(3.0 * m.lambda + 2.0 * m.mu);      // Cel^-1 s = (s - cc tr(s) d) / 2mu
+    double E0[6], v0[NX], vp[NX], v[NX];
+    double shift = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        E0[k] = (xp[k] - (kDiag[k] ? cc * trs : 0.0)) * i2mu + deg[k];
+        vp[k] = 0.0; v0[k] = deg[k];
+        if constexpr (PS) shift += kW[k] * z[k] * xp[k];
+    }
+    vp[6] = v0[6] = xp[6];
+    if constexpr (PS) { vp[7] = 1.0; v0[7] = 1.0; }
+    const RateNorm<DEF> norm{m.lambda * i2mu, z, shift * i2mu};
+    EvalS<YK> ev;
+    const uint32_t st = newton_s<YK, LS, DEF, RateNorm<DEF>>(m, E0, vp, v, lane_valid, ev, stage, z, norm, v0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = ev.s[k];
+    x[6] = v[6];
+    if constexpr (PS) x[7] = xp[7] + (v[7] - 1.0);
+    return st;
+}
+// A_rate^-T through the structured solver: A_rate = T A_tot P^-1 with the constant maps of the comment above
+// (P = d(sigma, alpha, F33) / d(v, alpha, F33) = [[-Cel, 0, Cel z], [0, 1, 0], [0, 0, 1]],  T = [[-Cel / 2mu, 0, 0], [0, 1, 0],
+// [(w o z)^T Cel / 2mu, 0, 1]]), so  lam = T^-T A_tot^-T P^T b :  b_v = -Cel b_sigma, b_7 += (Cel z) . b_sigma ;  mu = A_tot^-T b ;
+// lam_sigma = -2mu Cel^-1 mu_v + (w o z) mu_7.
+template <int YKS>
+struct StructRateSolveT {
+    template <int DEF, int YK>
+    CM_D bool apply(const cm_model_desc& m, const double z[6], const double* x, const double* xp, const Eval<DEF>&, const double (*)[6],
+                    double* lam) const {
+        static_assert(YK == YKS, "one yield surface per instantiation");
+        constexpr int NX = Dims<DEF>::NX;
+        constexpr bool PS = (DEF == CM_PLANE_STRESS);
+        const double i2mu = half_over_mu(m), cc = m.lambda * rcp(3.0 * m.lambda + 2.0 * m.mu), twomu = 2.0 * m.mu;
+        // the structured evaluation at this state: a total-form point with elastic strain Cel^-1 sigma
+        const double trs = x[0] + x[3] + x[5];
+        double ee[6], xi[NX], xip[NX], Cd[NX], b[NX], mu[NX];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ee[k] = (x[k] - (kDiag[k] ? cc * trs : 0.0)) * i2mu; xi[k] = 0.0; xip[k] = 0.0; }
+        xi[6] = x[6]; xip[6] = xp[6];
+        if constexpr (PS) { xi[7] = 1.0; xip[7] = 1.0; }
+        EvalS<YK> evs;
+        residual_s<YK, DEF>(m, ee, z, xi, xip, evs, Cd);
+        PlasticOpFor<YK> op;
+        op_build<YK>(m, evs, op);
+        double cb[6];
+        apply_cel(m, lam, cb);                                   // Cel b_sigma
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = -cb[k];
+        b[6] = lam[6];
+        if constexpr (PS) b[7] = lam[7] + dot<6>(z, cb);         // (Cel z) . b_sigma = z . Cel b_sigma
+        const bool ok = solve_s<DEF, true>(m, op, evs, z, b, mu);
+        const double trm = mu[0] + mu[3] + mu[5];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            lam[k] = -(mu[k] - (kDiag[k] ? cc * trm : 0.0));     // -2mu Cel^-1 mu_v
+            if constexpr (PS) lam[k] += kW[k] * z[k] * mu[7];
+        }
+        lam[6] = mu[6];
+        if constexpr (PS) lam[7] = mu[7];
+        (void)twomu;
+        return ok && op.ok;
+    }
+};
+template <int DEF, int YK, bool STRUCT = true>
+CM_D bool reverse_rate_any(const cm_model_desc& m, const double deg[6], const double z[6], const double* x, const double* xp,
+                           const double sbm[6], const double* xin, double* pbar, double* xpbar, double* degbar, double* lam_out = nullptr) {
+    if constexpr (STRUCT && has_structured<DEF, YK>())
+        return reverse_point_rate<DEF, YK, StructRateSolveT<YK>>(m, deg, z, x, xp, sbm, xin, pbar, xpbar, degbar, lam_out);
+    else return reverse_point_rate<DEF, YK>(m, deg, z, x, xp, sbm, xin, pbar, xpbar, degbar, lam_out);
+}
+
+// the rate-form model's Newton: the structured solver where the total form has one, cm::newton otherwise (STRUCT = false: always)
+template <int DEF, int YK, bool LS, bool STRUCT = true>
+CM_D uint32_t newton_rate_any(const cm_model_desc& m, const double deg[6], const double* z, const double* xp, double* x, bool valid,
+                              LaneStage stage = LaneStage{nullptr, 0}) {
+    if constexpr (STRUCT && has_structured<DEF, YK>()) return newton_s_rate<YK, LS, DEF>(m, deg, z, xp, x, valid, stage);
+    else return newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
+}
+
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool reverse_any(const cm_model_desc& m, const double eg[6], const double z[6], const double* x, const double* xp,
                       const double sbm[6], const double* xin, double* pbar, double* xpbar, double* egbar,
@@ -988,7 +1109,7 @@ CM_D void primal_history_point(const cm_model_desc& m, int K, const double* grad
                 strain_from_gradu<DEF, ROT>(m, dG, deg);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) xp[i] = x[i];
-                st = newton<DEF, YK, MK, LS>(m, deg, z, xp, x, valid);
+                st = newton_rate_any<DEF, YK, LS>(m, deg, z, xp, x, valid, stage);
             } else {
                 strain_from_gradu<DEF, ROT>(m, G, eg);
 #pragma unroll
@@ -1061,7 +1182,7 @@ CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist,
 #pragma unroll
         for (int i = 0; i < NX; ++i) xp[i] = x[i];
         if constexpr (RU) ru_newton<YK, LS>(m, eg[0], xp, x, valid);
-        else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) newton<DEF, YK, MK, LS>(m, eg, z, xp, x, valid);
+        else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) newton_rate_any<DEF, YK, LS>(m, eg, z, xp, x, valid, stage);
         else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, stage);
         if (valid) io.template store<NX>(xi_hist, (int64_t)k * NX, x);
     }
@@ -1099,7 +1220,7 @@ CM_D void history_point(const cm_model_desc& m, int K, const double* gradu_hist,
         }
         cotangent_to_material<ROT>(m, sb, sbm);
         if constexpr (RU) ru_reverse<YK>(m, eg[0], x, xp, sb, xin, pbar, xpbar, nullptr, lam);
-        else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) reverse_point_rate<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
+        else if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) reverse_rate_any<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
         else reverse_any<DEF, YK>(m, eg, z, x, xp, sbm, xin, pbar, xpbar, nullptr, lam);
         if (hc.lam_hist && valid) io.template store<NX>(hc.lam_hist, (int64_t)k * NX, lam);
         red[0] += J;

@@ -310,11 +310,14 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
 #pragma unroll
     for (int k = 0; k < NU; ++k) G[k] -= Gp[k];                  // eps - eps_prev is linear in grad u
     uint32_t st;
+    // the line search of the structured solver parks its iterate and direction in the lane's LDS column
+    constexpr bool STAGED = LS && !RU && has_structured<DEF, YK>();
+    __shared__ double ls_stage[STAGED ? kLsSlots * kBlock : 1];
     if constexpr (RU) st = ru_newton<YK, LS>(m, G[0], xp, x, valid);
     else {
         strain_from_gradu<DEF, ROT>(m, G, deg);
         strain_z<DEF, ROT>(m, z);
-        st = newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
+        st = newton_rate_any<DEF, YK, LS>(m, deg, z, xp, x, valid, LaneStage{ls_stage + (STAGED ? threadIdx.x : 0), kBlock});
     }
     double sg[6];
     to_global<ROT>(m, x, sg);                                    // small_rate_elastic_plastic.py:351-359
@@ -633,7 +636,10 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
     if (sigma_out) sigma_out += blk0;
     if (xpbar_out) xpbar_out += blk0;
     if (gbar_out) gbar_out += blk0;
-    __shared__ double lds_buf[kRed * kRedStride];
+    // one LDS buffer: the line search's parked iterates during the Newton loop, the gradient reduction afterwards
+    constexpr bool STAGED = LS && !RU && (MODE == 1 || MODE == 3) && has_structured<DEF, YK>();
+    constexpr int kLdsDoubles = (STAGED ? kLsSlots * kBlock : 0) > kRed * kRedStride ? kLsSlots * kBlock : kRed * kRedStride;
+    __shared__ double lds_buf[kLdsDoubles];
     double G[NU], Gp[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], sd[6];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NU>(gradu_prev, B, b, Gp);
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
     }
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (RU) ru_newton<YK, LS>(m, G[0], xp, x, valid);
-        else newton<DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, LS>(m, deg, z, xp, x, valid);
+        else newton_rate_any<DEF, YK, LS>(m, deg, z, xp, x, valid, LaneStage{lds_buf + (STAGED ? threadIdx.x : 0), kBlock});
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
     } else {
         load_soa<NX>(xi_in, B, b, x);
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
         ru_reverse<YK>(m, G[0], x, xp, sb, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr, BARS ? &ubar : nullptr);
         degbar[0] = ubar;                                        // the one grad-u entry: its cotangent, stored below
     } else {
-        reverse_point_rate<RU ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
+        reverse_rate_any<RU ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, sbm, (MODE == 2) ? xin : nullptr, &red[1], BARS ? xpbar : nullptr,
                                                      BARS ? degbar : nullptr);
     }
     if (BARS && xpbar_out && valid) {
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, 
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
     const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
-    constexpr bool STAGED = LS && MK == CM_SMALL_ELASTIC_PLASTIC && has_structured<DEF, YK>();
+    constexpr bool STAGED = LS && has_structured<DEF, YK>();       // both model kinds: the rate form rides on the same solver
     constexpr int kLdsDoubles = (STAGED ? kLsSlots * kBlock : 0) > kRed * kRedStride ? kLsSlots * kBlock : kRed * kRedStride;
     __shared__ double lds_buf[kLdsDoubles];
     double red[kRed];
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(kBlock) void k_primal_history(cm_model_desc m, int6
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
     const bool valid = blk0 + threadIdx.x < B;
     const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
-    constexpr bool STAGED = LS && MK == CM_SMALL_ELASTIC_PLASTIC && has_structured<DEF, YK>();
+    constexpr bool STAGED = LS && has_structured<DEF, YK>();
     __shared__ double ls_stage[STAGED ? kLsSlots * kBlock : 1];
     primal_history_point<DEF, YK, ROT, LS, MK, RL>(m, K, gradu_hist + blk0, xi0 + blk0, xi_hist ? xi_hist + blk0 : nullptr,
                                                sigma_hist ? sigma_hist + blk0 : nullptr, status_hist ? status_hist + blk0 : nullptr,

@@ -144,7 +144,8 @@ static void run_vjp_rate(const cm_model_desc& m, int64_t B, const double* gradu,
             strain_from_gradu<DEF, ROT>(m, G, deg);
             strain_z<DEF, ROT>(m, z);
             cotangent_to_material<ROT>(m, sb, sbm);
-            reverse_point_rate<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+            if (g_dense) reverse_rate_any<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, false>(m, deg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
+            else reverse_rate_any<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, true>(m, deg, z, x, xp, sbm, xin ? xi_in : nullptr, pb, xb, eb);
             for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] += pb[k];
             if (xpbar) for (int k = 0; k < NX; ++k) xpbar[k * B + b] = xb[k];
             if (gbar) for (int c = 0; c < NU; ++c) {
@@ -199,8 +200,13 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
         uint32_t st;
         if (hh_g_passes) st = (m.ls_max_evals > 0) ? newton_by_passes<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, stage)
                                                    : newton_by_passes<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, stage);
-        else st = (m.ls_max_evals > 0) ? newton<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, true)
-                                       : newton<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, true);
+        else {      // same choice as k_update_rate: the structured solver where there is one; the "dense" variant keeps cm::newton
+            constexpr int D2 = (DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF;
+            if (g_dense) st = (m.ls_max_evals > 0) ? newton_rate_any<D2, YK, true, false>(m, deg, z, xp, x, true, stage)
+                                                   : newton_rate_any<D2, YK, false, false>(m, deg, z, xp, x, true, stage);
+            else st = (m.ls_max_evals > 0) ? newton_rate_any<D2, YK, true, true>(m, deg, z, xp, x, true, stage)
+                                           : newton_rate_any<D2, YK, false, true>(m, deg, z, xp, x, true, stage);
+        }
         to_global<ROT>(m, x, sg);
         for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
         for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];

@@ -181,8 +181,6 @@ def test_scaled_hybrid_hill_icnn(def_type, rot):
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_rate_model_update(def_type, yield_kind, kw, rot, ls, solver_variant):
     import host_harness_lib as hh
-    if hh.lib() and solver_variant == "dense":
-        pytest.skip("rate form always uses the dense path")
     pc.check_rate_model(lambda desc, info, g, gp, xp: hh.update_rate(desc, g, gp, xp, {0: 7, 2: 8, 3: 12}[desc.def_type]),
                         def_type, yield_kind, kw, rot, ls, B=256)
 
