@@ -1788,16 +1788,30 @@ CM_D bool reverse_point_rate(const cm_model_desc& m, const double deg[6], const 
 // T[r][l] = d s_r / d (d eg)_l : the unknown x[0:6] IS the material stress, so T is the first six rows of
 // dx / d deg = -A^-1 dC/d deg with dC_k/d deg_l = -Cel_kl / 2mu (both branches) and, under PLANE_STRESS,
 // dC_7/d deg_l = (Cel (w o z))_l / 2mu  (small_rate_elastic_plastic.py:249-346; IFT rule nonlinear_solver.py:158-171).
-template <int DEF, int YK>
+// SOLVE: factor A once, apply A^-1 to several right-hand sides -- the dense LU here, the structured solver of the total form
+// through the change of variables of cm::newton_s_rate (StructRateSolve, cm_structured.hpp)
+template <int NXMAX>
+struct DenseRateSolve {
+    double A[NXMAX][NXMAX];
+    template <int DEF, int YK>
+    CM_D bool setup(const cm_model_desc& m, const double deg[6], const double z[6], const double* x, const double* xp) {
+        static_assert(Dims<DEF>::NX == NXMAX, "one size per instantiation");
+        Eval<DEF> ev;
+        double C[NXMAX], Ht[6][6];
+        residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
+        jacobian_rate<DEF, false>(m, z, ev, Ht, A);
+        return lu_factor<NXMAX>(A);
+    }
+    template <int DEF, int YK>
+    CM_D void solve(const cm_model_desc&, const double*, double (&b)[NXMAX]) const { lu_subst<NXMAX>(A, b); }
+};
+template <int DEF, int YK, class SOLVE = DenseRateSolve<Dims<DEF>::NX>>
 CM_D bool tangent_point_rate(const cm_model_desc& m, const double deg[6], const double z[6],
                              const double* x, const double* xp, double (&T)[6][6]) {
     static_assert(DEF != CM_UNIAXIAL_STRESS, "batched rate-form tangent: FULL_3D and PLANE_STRESS");
     constexpr int NX = Dims<DEF>::NX;
-    Eval<DEF> ev;
-    double C[NX], Ht[6][6], A[NX][NX];
-    residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
-    jacobian_rate<DEF, false>(m, z, ev, Ht, A);
-    const bool ok = lu_factor<NX>(A);
+    SOLVE solver;
+    const bool ok = solver.template setup<DEF, YK>(m, deg, z, x, xp);
     const double i2mu = half_over_mu(m);
     double czw[6];
     if constexpr (DEF == CM_PLANE_STRESS) {
@@ -1816,7 +1830,7 @@ CM_D bool tangent_point_rate(const cm_model_desc& m, const double deg[6], const 
         for (int k = 0; k < 6; ++k) b[k] = col[k] * i2mu;        // -dC_k / d deg_l
         b[6] = 0.0;
         if constexpr (DEF == CM_PLANE_STRESS) b[7] = -czw[l] * i2mu;
-        lu_subst<NX>(A, b);
+        solver.template solve<DEF, YK>(m, z, b);                 // b <- A^-1 b
 #pragma unroll
         for (int r = 0; r < 6; ++r) T[r][l] = b[r];
     }

@@ -1046,6 +1046,59 @@ struct StructRateSolveT {
         return ok && op.ok;
     }
 };
+// A_rate^-1 = P A_tot^-1 T^-1 for several right-hand sides (the tangent):  b_v = -2mu Cel^-1 b_sigma, b_7 += (w o z) . b_sigma ;
+// y = A_tot^-1 b ;  x_sigma = -Cel y_v + Cel z y_7.
+template <int YKS, int DEFS>
+struct StructRateSolve {
+    EvalS<YKS> evs;
+    PlasticOpFor<YKS> op;
+    template <int DEF, int YK>
+    CM_D bool setup(const cm_model_desc& m, const double*, const double z[6], const double* x, const double* xp) {
+        static_assert(YK == YKS && DEF == DEFS, "one configuration per instantiation");
+        constexpr int NX = Dims<DEF>::NX;
+        const double i2mu = half_over_mu(m), cc = m.lambda * rcp(3.0 * m.lambda + 2.0 * m.mu), trs = x[0] + x[3] + x[5];
+        double ee[6], xi[NX], xip[NX], Cd[NX];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ee[k] = (x[k] - (kDiag[k] ? cc * trs : 0.0)) * i2mu; xi[k] = 0.0; xip[k] = 0.0; }
+        xi[6] = x[6]; xip[6] = xp[6];
+        if constexpr (DEF == CM_PLANE_STRESS) { xi[7] = 1.0; xip[7] = 1.0; }
+        residual_s<YK, DEF>(m, ee, z, xi, xip, evs, Cd);
+        op_build<YK>(m, evs, op);
+        return op.ok;
+    }
+    template <int DEF, int YK>
+    CM_D void solve(const cm_model_desc& m, const double* z, double (&b)[Dims<DEF>::NX]) const {
+        constexpr int NX = Dims<DEF>::NX;
+        constexpr bool PS = (DEF == CM_PLANE_STRESS);
+        const double cc = m.lambda * rcp(3.0 * m.lambda + 2.0 * m.mu);
+        const double trb = b[0] + b[3] + b[5];
+        double t[NX], y[NX];
+        double zb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            t[k] = -(b[k] - (kDiag[k] ? cc * trb : 0.0));                // -2mu Cel^-1 b_sigma
+            if constexpr (PS) zb += kW[k] * z[k] * b[k];
+        }
+        t[6] = b[6];
+        if constexpr (PS) t[7] = b[7] + zb;
+        solve_s<DEF, false>(m, op, evs, z, t, y);
+        double u[6], cu[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) u[k] = -y[k] + (PS ? z[k] * y[NX - 1] : 0.0);
+        apply_cel(m, u, cu);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = cu[k];
+        b[6] = y[6];
+        if constexpr (PS) b[7] = y[7];
+    }
+};
+template <int DEF, int YK, bool STRUCT = true>
+CM_D bool tangent_rate_any(const cm_model_desc& m, const double deg[6], const double z[6], const double* x, const double* xp,
+                           double (&T)[6][6]) {
+    if constexpr (STRUCT && has_structured<DEF, YK>()) return tangent_point_rate<DEF, YK, StructRateSolve<YK, DEF>>(m, deg, z, x, xp, T);
+    else return tangent_point_rate<DEF, YK>(m, deg, z, x, xp, T);
+}
+
 template <int DEF, int YK, bool STRUCT = true>
 CM_D bool reverse_rate_any(const cm_model_desc& m, const double deg[6], const double z[6], const double* x, const double* xp,
                            const double sbm[6], const double* xin, double* pbar, double* xpbar, double* degbar, double* lam_out = nullptr) {

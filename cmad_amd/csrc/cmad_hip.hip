@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
             return;
         }
         double T[6][6];
-        const bool ok = tangent_point_rate<RU ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, T);
+        const bool ok = tangent_rate_any<RU ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, T);
         if (!ok && valid && status) status[b] = st | CM_STATUS_SINGULAR;
 #pragma unroll
         for (int c = 0; c < NU; ++c) {

@@ -231,7 +231,8 @@ static void run_tangent_rate(const cm_model_desc& m, int64_t B, const double* gr
         }
         strain_from_gradu<DEF, ROT>(m, G, deg);
         strain_z<DEF, ROT>(m, z);
-        tangent_point_rate<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK>(m, deg, z, x, xp, T);
+        if (g_dense) tangent_rate_any<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, false>(m, deg, z, x, xp, T);
+        else tangent_rate_any<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, true>(m, deg, z, x, xp, T);
         for (int c = 0; c < NU; ++c) {
             double Gd[NU], dm[6], t[6], tg[6];
             for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
