@@ -615,7 +615,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     block_reduce_store<kRed, (YK == CM_YIELD_J2) ? 1 + CM_P_YC0 : kRed>(red, partials, lds_buf);
 }
 
-// ---- reverse-mode kernels of the rate-form model (same MODEs as k_reverse; dense LU path) ----------------------
+// ---- reverse-mode kernels of the rate-form model (same MODEs as k_reverse; structured solver via reverse_rate_any) -----
 // grad u enters through deg = strain(grad u - grad u_prev): the cotangent written to gbar_out is the one of grad u,
 // the one of grad u_prev is its negative.
 template <int DEF, int YK, bool ROT, bool LS, int MODE>
