@@ -234,6 +234,18 @@ def check_random_materials(backend, def_type, yield_kind, ls, seeds=range(6), B=
             np.testing.assert_allclose(gotJ, refJ, rtol=1e-8, atol=1e-9 * np.abs(refJ).max())
 
 
+def check_random_materials_rate(update_rate, tangent_rate, vjp_rate, def_type, yield_kind, ls, seeds=range(4), B=160):
+    """The rate-form model (on the structured solver through the change of variables of newton_s_rate) for randomly drawn
+    materials: three load steps, tangent and reverse sweep against the oracle."""
+    for seed in seeds:
+        rng = np.random.default_rng(2000 + 13 * seed + def_type)
+        values, eps_y = random_material(rng, yield_kind, ls)
+        check_rate_model(update_rate, def_type, yield_kind, {}, True, ls, B=B, seed=60 + seed, values=values, eps_y=eps_y)
+        if not ls:
+            check_rate_tangent(tangent_rate, def_type, yield_kind, {}, True, B=B, seed=60 + seed, values=values, eps_y=eps_y)
+            check_rate_vjp(vjp_rate, def_type, yield_kind, {}, True, B=B, seed=60 + seed, values=values, eps_y=eps_y)
+
+
 def check_hosford_a100(backend, B=2048):
     """BASELINE.json configs[2]: near-Tresca Hosford (a = 100) with the notch deck's material and solver
     settings (examples/notch_hosford.yaml:29-42: E 1000, nu 0.25, Y 2, Voce S 10 D 2; 500 local iterations,
@@ -321,18 +333,19 @@ def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False, scaled=False
                                    atol=1e-10 * np.abs(g_o).max())
 
 
-def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed=22):
+def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed=22, values=None, eps_y=1e-3):
     """small_rate_elastic_plastic on the device path vs the oracle: three load steps (the residual needs the
     previous grad u), state = [sigma(6), alpha (, F33)].  `update_rate(desc, info, gradu, gradu_prev, xi_prev)`."""
     from cmad_amd.models.device import build_desc
     from cmad_amd.synthetic import gauss_point_batch
     rng = np.random.default_rng(seed)
-    values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+    if values is None:
+        values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
     nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
     st_o, st_d = settings_pair(ls)
     mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=1)
     desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d, uniaxial_stress_idx=1)
-    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
+    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd, eps_y=eps_y)
     g_prev = np.zeros_like(g0)
     xp = np.tile(mat.init_xi()[:, None], (1, B))
     plastic_seen = 0.0
@@ -343,27 +356,29 @@ def check_rate_model(update_rate, def_type, yield_kind, kw, rot, ls, B=512, seed
         status = status.astype(np.uint32)
         assert cv_o.all() and ((status >> 16) & 1).all()
         # stresses ~1e2 with 1/2mu-scaled residual tolerance 1e-14 -> ~1e-9 absolute
-        np.testing.assert_allclose(xi_d[:6], xi_o[:6], rtol=1e-10, atol=1e-7)
+        sscale = max(1.0, np.abs(sig_o).max() / 400.0)           # stresses of the analytical problem are ~4e2
+        np.testing.assert_allclose(xi_d[:6], xi_o[:6], rtol=1e-10, atol=1e-7 * sscale)
         np.testing.assert_allclose(xi_d[6:], xi_o[6:], rtol=1e-10, atol=1e-12)
-        np.testing.assert_allclose(sig_d, sig_o, rtol=1e-10, atol=1e-7)
+        np.testing.assert_allclose(sig_d, sig_o, rtol=1e-10, atol=1e-7 * sscale)
         assert np.abs((status & 0xFFFF).astype(int) - it_o).max() <= 1
         plastic_seen = max(plastic_seen, (it_o > 0).mean())
         xp, g_prev = xi_o, g
     assert plastic_seen > 0.2
 
 
-def check_rate_tangent(tangent_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
+def check_rate_tangent(tangent_rate, def_type, yield_kind, kw, rot, B=512, seed=22, values=None, eps_y=1e-3):
     """IFT tangent d sigma / d grad u of the rate form after two load steps vs the oracle (jacfwd through the
     custom_jvp rule, with the previous grad u).  `tangent_rate(desc, info, gradu, gradu_prev, xi_prev, xi) -> (6 nu, B)`."""
     from cmad_amd.models.device import build_desc
     from cmad_amd.synthetic import gauss_point_batch
     rng = np.random.default_rng(seed)
-    values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+    if values is None:
+        values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
     nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
     st_o, st_d = settings_pair(False)
     mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=1)
     desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d, uniaxial_stress_idx=1)
-    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
+    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd, eps_y=eps_y)
     xp = np.tile(mat.init_xi()[:, None], (1, B))
     x1, _, _, cv1 = mat.update_batch(st_o, 0.9 * g0, xp, gradu_prev=np.zeros_like(g0))
     x2, _, it2, cv2 = mat.update_batch(st_o, 1.5 * g0, x1, gradu_prev=0.9 * g0)
@@ -373,19 +388,20 @@ def check_rate_tangent(tangent_rate, def_type, yield_kind, kw, rot, B=512, seed=
     np.testing.assert_allclose(ds_d, ds_o, rtol=1e-9, atol=1e-10 * np.abs(ds_o).max())
 
 
-def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
+def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22, values=None, eps_y=1e-3):
     """Reverse sweep of the rate form at converged states vs the oracle (transpose of the custom_jvp rule with the
     previous grad u): parameter gradient, xi_prev cotangent, grad u cotangent.
     `vjp_rate(desc, info, gradu, gradu_prev, xi_prev, xi, sbar) -> (grad_kp, xi_prev_bar, gradu_bar)`."""
     from cmad_amd.models.device import build_desc
     from cmad_amd.synthetic import gauss_point_batch
     rng = np.random.default_rng(seed)
-    values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
+    if values is None:
+        values = ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
     nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
     st_o, st_d = settings_pair(False)
     mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP, uniaxial_idx=1)
     desc, info = build_desc(values, def_type=def_type, model_kind=1, newton=st_d, uniaxial_stress_idx=1)
-    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd)
+    g0 = gauss_point_batch(B, seed=seed, skew=True, ndims=nd, eps_y=eps_y)
     xp = np.tile(mat.init_xi()[:, None], (1, B))
     x1, _, _, cv1 = mat.update_batch(st_o, 0.9 * g0, xp, gradu_prev=np.zeros_like(g0))
     x2, _, it2, cv2 = mat.update_batch(st_o, 1.5 * g0, x1, gradu_prev=0.9 * g0)
@@ -395,7 +411,7 @@ def check_rate_vjp(vjp_rate, def_type, yield_kind, kw, rot, B=512, seed=22):
     g_d, xb_d, ub_d = vjp_rate(desc, info, 1.5 * g0, 0.9 * g0, x1, x2, sbar)
     np.testing.assert_allclose(xb_d, xb_o, rtol=1e-9, atol=1e-9 * np.abs(xb_o).max())
     np.testing.assert_allclose(ub_d, ub_o, rtol=1e-9, atol=1e-9 * np.abs(ub_o).max())
-    got, ref = leaf_grads(g_d, info, mat, yield_kind, g_o)
+    got, ref = leaf_grads(g_d, info, mat, yield_kind, g_o, values)
     # (12-dof UNIAXIAL_STRESS form: both sides difference O(1) terms of the pivoted 12 x 12 solves -> 1e-10 of the largest entry)
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=(1e-9 if def_type == ol.UNIAXIAL_STRESS else 1e-12) * np.abs(ref).max())
 

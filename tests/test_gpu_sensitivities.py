@@ -114,6 +114,30 @@ def test_rate_form_tangent(def_type, yield_kind, kw, rot):
     pc.check_rate_tangent(run, def_type, yield_kind, kw, rot, B=1024)
 
 
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_random_materials_rate_form(def_type, yield_kind, ls):
+    """The rate-form model's kernels (structured solver through the change of variables of newton_s_rate) for randomly drawn
+    materials: update over three load steps, tangent, reverse sweep against the oracle."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def update(desc, info, g, gp, xp):
+        xi, sig, st = DeviceEvaluator(desc, info).update_rate(t(g), t(gp), t(xp))
+        return xi.cpu().numpy(), sig.cpu().numpy(), st.cpu().numpy().astype(np.uint32)
+
+    def tangent(desc, info, g, gp, xp, x_expected):
+        return DeviceEvaluator(desc, info).update_rate(t(g), t(gp), t(xp), tangent=True)[3].cpu().numpy()
+
+    def vjp(desc, info, g, gp, xp, x, sbar):
+        gk, xb, ub = DeviceEvaluator(desc, info).update_vjp(t(g), t(xp), t(x), t(sbar), want_xi_prev_bar=True, want_gradu_bar=True,
+                                                            gradu_prev=t(gp))
+        return gk.cpu().numpy(), xb.cpu().numpy(), ub.cpu().numpy()
+    pc.check_random_materials_rate(update, tangent, vjp, def_type, yield_kind, ls, seeds=range(4), B=320)
+
+
 def _rate_case(def_type, yield_kind, kw, rot, B, seed=22):
     import torch
     from cmad_amd.models.device import DeviceEvaluator, build_desc

@@ -279,6 +279,20 @@ def test_rate_model_explicit_blocks(def_type, yield_kind, kw, rot, solver_varian
 
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_random_materials_rate_form(def_type, yield_kind, ls, solver_variant):
+    import host_harness_lib as hh
+    if solver_variant == "passes":
+        pytest.skip("the pass-based solver is the work pool's (total form)")
+    nx = {ol.FULL_3D: 7, ol.PLANE_STRESS: 8}[def_type]
+    pc.check_random_materials_rate(lambda desc, info, g, gp, xp: hh.update_rate(desc, g, gp, xp, nx),
+                                   lambda desc, info, g, gp, xp, x: hh.tangent_rate(desc, g, gp, xp, x),
+                                   lambda desc, info, g, gp, xp, x, sb: hh.vjp_rate(desc, g, gp, xp, x, sb),
+                                   def_type, yield_kind, ls, seeds=range(3), B=96)
+
+
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_random_materials(def_type, yield_kind, ls, solver_variant):
     if solver_variant == "passes" and not ls:
