@@ -211,7 +211,8 @@ def main():
                     help="J2 workloads: plane_stress is a side measurement (the reference's material-point tests' type)")
     ap.add_argument("--workload", default="j2_update_vjp",
                     choices=["j2_update_vjp", "j2_update", "j2_update_tangent", "j2_objective_grad", "hosford_update",
-                             "hybrid_update", "hosford_update_vjp", "hybrid_update_vjp", "ps_calibration_history"],
+                             "hybrid_update", "hosford_update_vjp", "hybrid_update_vjp", "hosford_update_tangent", "hybrid_update_tangent",
+                             "ps_calibration_history"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
     args = ap.parse_args()
 
@@ -286,7 +287,7 @@ def main():
         assert wl.startswith("j2_"), "--def-type applies to the J2 workloads"
     n_gradu, n_xi = (4, 8) if ps else ((1, 9) if ux else (9, 7))
     reads = n_gradu + n_xi + (6 if (wl.endswith("_vjp") or wl == "j2_objective_grad") else 0)
-    writes = 0 if wl == "j2_objective_grad" else n_xi + 6 + (6 * n_gradu if wl == "j2_update_tangent" else 0)
+    writes = 0 if wl == "j2_objective_grad" else n_xi + 6 + (6 * n_gradu if wl.endswith("_update_tangent") else 0)
     bytes_per_update = 8 * (reads + writes)
     from cmad_amd.models.deformation_types import DefType
     newton.lockstep = bool(args.lockstep)
@@ -311,7 +312,7 @@ def main():
     out = {"xi": torch.empty((nxi, B), dtype=torch.float64, device=dev),
            "sigma": torch.empty((6, B), dtype=torch.float64, device=dev),
            "grad": torch.empty(12, dtype=torch.float64, device=dev)}
-    if wl == "j2_update_tangent":
+    if wl.endswith("_update_tangent"):
         out["dsigma"] = torch.empty((6 * n_gradu, B), dtype=torch.float64, device=dev)
 
     # two result buffers: the all-reduce of step k (RCCL's own stream) overlaps the kernel of step k+1
@@ -332,7 +333,7 @@ def main():
         if wl == "j2_objective_grad":              # sigma_bar doubles as the "measured stress" array
             ev.objective_grad(gradu, xi_prev, sigma_bar, wsq6, out=res13[i])
             return res13[i]
-        ev.update(gradu, xi_prev, want_status=False, out=out, tangent=(wl == "j2_update_tangent"))
+        ev.update(gradu, xi_prev, want_status=False, out=out, tangent=wl.endswith("_update_tangent"))
         return None
 
     def reduce_async(k, r):
@@ -447,6 +448,10 @@ def main():
                              "hosford_update": "Hosford a=100 stress update, notch_hosford.yaml material (configs[2])",
                              "hybrid_update": "hybrid Hill + ICNN[6,16,1] stress update (configs[3])",
                              "hosford_update_vjp": "Hosford a=100 stress update + vjp w.r.t. parameters (configs[2] material; side measurement)",
+                             "hosford_update_tangent": "Hosford a=100 stress update + consistent tangent: the per-integration-point call of "
+                                                       "the notch_hosford.yaml FE deck (configs[2] material and solver settings; side measurement)",
+                             "hybrid_update_tangent": "hybrid Hill + ICNN[6,16,1] stress update + consistent tangent (configs[3] material; "
+                                                      "side measurement)",
                              "hybrid_update_vjp": "hybrid Hill + ICNN[6,16,1] stress update + vjp w.r.t. parameters (configs[3] material; "
                                                   "side measurement)"}[wl]
                             .replace("FULL_3D", "PLANE_STRESS (side measurement)" if ps else ("UNIAXIAL_STRESS (side measurement)" if ux else "FULL_3D"))

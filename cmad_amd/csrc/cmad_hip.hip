@@ -1129,6 +1129,54 @@ inline int pool_resident_waves(const void* kernel) {
     return cus * per_cu;
 }
 
+// Iteration-bound configurations (the network surfaces, Hosford under the line search: pool_pays<>) run cm_update on the work
+// pool.  The fused entry points below take the same route for them -- work-pool update, then the reverse sweep as a second
+// kernel over the stored states -- instead of the lockstep fused kernel, whose wavefronts wait for their slowest point
+// (CM_SOLVER_LOCKSTEP keeps the single fused kernel).  Same per-point arithmetic and the same reduction order either way.
+static inline bool pool_route(const cm_model_desc* m, int64_t B) {
+    if (!m || m->model_kind != CM_SMALL_ELASTIC_PLASTIC || (m->solver_flags & CM_SOLVER_LOCKSTEP) || B < 256) return false;
+    return is_nn_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && m->ls_max_evals > 0);
+}
+// ---- consistent tangent at given converged states (second kernel of cm_update_tangent's work-pool route) -------------------
+template <int DEF, int YK, bool ROT>
+__global__ __launch_bounds__(kBlock) void k_tangent_state(cm_model_desc m, int64_t B, const double* __restrict__ gradu,
+        const double* __restrict__ xi_prev, const double* __restrict__ xi, double* __restrict__ dsig, uint32_t* __restrict__ status) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
+    gradu += blk0; xi_prev += blk0; xi += blk0; dsig += blk0;
+    if (status) status += blk0;
+    double G[NU], xp[NX], x[NX], eg[6], z[Dims<DEF>::NZ];
+    load_soa<NU>(gradu, B, b, G);
+    load_soa<NX>(xi_prev, B, b, xp);
+    load_soa<NX, false>(xi, B, b, x);                            // just written by the update kernel: a cached read
+    strain_from_gradu<DEF, ROT>(m, G, eg);
+    strain_z<DEF, ROT>(m, z);
+    double T[6][6];
+    const bool ok = tangent_any<DEF, YK>(m, eg, z, x, xp, T);
+    if (!ok && valid && status) status[b] |= CM_STATUS_SINGULAR;
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+        double Gd[NU], dm[6], t[6], tg[6];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Gd[k] = (k == c) ? 1.0 : 0.0;
+        strain_from_gradu<DEF, ROT>(m, Gd, dm);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) s += T[r][l] * dm[l];
+            t[r] = s;
+        }
+        to_global<ROT>(m, t, tg);
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) (dsig + (int64_t)(r * NU + c) * B)[b] = tg[r];
+        }
+    }
+}
+
 template <bool TANGENT>
 int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                   double* xi, double* sigma, double* dsig, uint32_t* status, void* stream) {
@@ -1140,6 +1188,19 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     hipStream_t s = (hipStream_t)stream;
     const cm_model_desc md = *m;
     (void)hipGetLastError();            // drop any stale error left by other users of the runtime (e.g. torch)
+    if constexpr (TANGENT) {
+        // iteration-bound configurations: work-pool update, then the tangent at the stored states as a second kernel
+        if (pool_route(m, B)) {
+            const int rc = cm_update(m, B, gradu, xi_prev, xi, sigma, status, stream);
+            if (rc != CM_OK) return rc;
+            const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
+                if constexpr (pool_pays<Y, true>())
+                    hipLaunchKernelGGL((k_tangent_state<D, Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, dsig, status);
+            });
+            if (!found) return CM_ERR_UNSUPPORTED;
+            return check_launch();
+        }
+    }
     const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (has_fast_newton<D, Y, LS>()) {
             if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
@@ -1465,14 +1526,6 @@ int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n
 
 }  // namespace
 
-// Iteration-bound configurations (the network surfaces, Hosford under the line search: pool_pays<>) run cm_update on the work
-// pool.  The fused entry points below take the same route for them -- work-pool update, then the reverse sweep as a second
-// kernel over the stored states -- instead of the lockstep fused kernel, whose wavefronts wait for their slowest point
-// (CM_SOLVER_LOCKSTEP keeps the single fused kernel).  Same per-point arithmetic and the same reduction order either way.
-static inline bool pool_route(const cm_model_desc* m, int64_t B) {
-    if (!m || m->model_kind != CM_SMALL_ELASTIC_PLASTIC || (m->solver_flags & CM_SOLVER_LOCKSTEP) || B < 256) return false;
-    return is_nn_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && m->ls_max_evals > 0);
-}
 extern "C" {
 // objective + gradient at given converged states (the MODE 2 reverse kernel without a history vector); defined with cm_adjoint_step
 __attribute__((visibility("hidden")))

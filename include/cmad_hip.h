@@ -66,9 +66,9 @@ enum cm_param_index {
  * finished its Gauss point takes the next one instead of waiting for the slowest point of its wavefront (same
  * iteration per point, same results).  CM_SOLVER_LOCKSTEP keeps one point per lane for the whole kernel. */
 #define CM_SOLVER_LOCKSTEP 4
-/* For those same configurations cm_update_and_vjp, and cm_objective_grad when it is given a state buffer (xi != NULL), run as
- * work-pool update + reverse kernel over the stored states (two launches on the stream, same results and reduction order)
- * instead of one lockstep fused kernel; CM_SOLVER_LOCKSTEP keeps the single kernel. */
+/* For those same configurations cm_update_tangent, cm_update_and_vjp, and cm_objective_grad when it is given a state buffer
+ * (xi != NULL), run as work-pool update + a second kernel over the stored states (tangent / reverse sweep; two launches on the
+ * stream, same results and reduction order) instead of one lockstep fused kernel; CM_SOLVER_LOCKSTEP keeps the single kernel. */
 
 /* status word written per point by cm_update* (all optional outputs may be NULL) */
 #define CM_STATUS_ITERS_MASK 0xFFFFu

@@ -131,6 +131,11 @@ def test_work_pool_route_equals_lockstep_kernels(surface):
     for a, b in zip(fused[0], fused[1]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-11, atol=1e-11 * float(b.abs().max()))
     np.testing.assert_allclose(fused[0][0].cpu().numpy(), up[0][0].cpu().numpy(), rtol=0, atol=0)      # the routed path IS cm_update
+    tang = [ev.update(g, xp, tangent=True) for ev in evs]                  # cm_update_tangent: work pool + tangent kernel vs lockstep
+    assert torch.equal(tang[0][2], tang[1][2])
+    np.testing.assert_allclose(tang[0][0].cpu().numpy(), up[0][0].cpu().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(tang[0][3].cpu().numpy(), tang[1][3].cpu().numpy(), rtol=1e-10,
+                               atol=1e-10 * float(tang[1][3].abs().max()))
     obj = [evs[0].objective_grad(g, xp, data, wsq, want_xi=True)[0], evs[0].objective_grad(g, xp, data, wsq)[0],
            evs[1].objective_grad(g, xp, data, wsq, want_xi=True)[0]]
     for o in obj[1:]:
