@@ -1853,7 +1853,7 @@ CM_D void evaluate_blocks(const cm_model_desc& m, const double* G, const double*
     strain_z<DEF, ROT>(m, z);
     residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
     to_global<ROT>(m, ev.s, sg);
-    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
+    const double i2mu = half_over_mu(m);
     const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? CM_NUM_PARAMS : NU);
     if (which == CM_W_NONE) return;
     // material-frame stress derivative columns ds[6] per column, then rotated
@@ -2008,7 +2008,7 @@ CM_D void evaluate_blocks_rate(const cm_model_desc& m, const double* G, const do
     residual_rate<DEF, YK, true>(m, deg, z, x, xp, ev, C, Ht);
     to_global<ROT>(m, x, sg);
     if (which == CM_W_NONE) return;
-    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
+    const double i2mu = half_over_mu(m);
     const int ncols = (which == CM_W_XI || which == CM_W_XI_PREV) ? NX : (which == CM_W_PARAMS ? NP_ : NU);
     if (S) for (int i = 0; i < 6 * ncols; ++i) S[i] = 0.0;
     if (J) for (int i = 0; i < NX * ncols; ++i) J[i] = 0.0;

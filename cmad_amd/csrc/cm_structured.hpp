@@ -1015,7 +1015,7 @@ struct StructRateSolveT {
         static_assert(YK == YKS, "one yield surface per instantiation");
         constexpr int NX = Dims<DEF>::NX;
         constexpr bool PS = (DEF == CM_PLANE_STRESS);
-        const double i2mu = half_over_mu(m), cc = m.lambda * rcp(3.0 * m.lambda + 2.0 * m.mu), twomu = 2.0 * m.mu;
+        const double i2mu = half_over_mu(m), cc = m.lambda * rcp(3.0 * m.lambda + 2.0 * m.mu);
         // the structured evaluation at this state: a total-form point with elastic strain Cel^-1 sigma
         const double trs = x[0] + x[3] + x[5];
         double ee[6], xi[NX], xip[NX], Cd[NX], b[NX], mu[NX];
@@ -1042,7 +1042,6 @@ struct StructRateSolveT {
         }
         lam[6] = mu[6];
         if constexpr (PS) lam[7] = mu[7];
-        (void)twomu;
         return ok && op.ok;
     }
 };
