@@ -504,7 +504,13 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     double G[NU], xp[NX], x[NX], eg[6], z[Dims<DEF>::NZ], sd[6];
     load_soa<NU>(gradu, B, b, G);
     load_soa<NX>(xi_prev, B, b, xp);
-    if constexpr (MODE == 0 || MODE == 2) load_soa<6>(sbar_or_data, B, b, sd);
+#ifndef CM_EARLY_SBAR
+#define CM_EARLY_SBAR 1
+#endif
+    // the fused J2 update + vjp kernel has registers to spare since round 2 (108 of 128): all 22 row loads in flight before the
+    // solve instead of 16 + 6 (-3 % and steadier, profiles/r02_early_sigma_bar_ab.txt); the objective kernel (125) would spill
+    constexpr bool EARLY = (CM_EARLY_SBAR != 0) && RL && DEF == CM_FULL_3D && !LS && MODE == 3;
+    if constexpr (MODE == 0 || MODE == 2 || EARLY) load_soa<6>(sbar_or_data, B, b, sd);
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
     // fused modes on the structured path keep the converged-state evaluation for the reverse sweep
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
         }
         else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid);
-        load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
+        if constexpr (!EARLY) load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
         if constexpr (MODE == 3) {
             if (sigma_out) {
@@ -545,9 +551,9 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     } else {
         // J = 1/2 sum_r wsq_r (sig_r - data_r)^2 ;  sbar_r = wsq_r (sig_r - data_r)   (qois/calibration.py:56-66)
         double sg[6];
-        // plain Newton: the solver's evaluation at the returned state (with the line search the six extra live registers cost
-        // the kernel its third wavefront per SIMD)
-        if constexpr (SFAST && MODE == 1 && !LS) to_global<ROT>(m, evs.s, sg);
+        // plain Newton, Q = I: the solver's evaluation at the returned state (with the line search the six extra live registers
+        // cost the kernel its third wavefront per SIMD, with a rotation they spill)
+        if constexpr (SFAST && MODE == 1 && !LS && !ROT) to_global<ROT>(m, evs.s, sg);
         else {
             Eval<DEF> ev;
             strain_stress<DEF>(m, eg, z, x, ev);
