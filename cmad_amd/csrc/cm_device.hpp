@@ -1169,6 +1169,11 @@ struct UniaxialOp {
     double pg, a66, d6;
     bool ok;
 };
+// the quadratic surfaces (J2, Hill: Ht = (A - gt gt^T) / phi) apply the Hessian from that form: no 6 x 6 array (72 registers) is
+// built, and the callers evaluate the residual without its Hessian (uniaxial_needs_hessian<YK>() == false)
+template <int YK>
+constexpr bool uniaxial_needs_hessian() { return !(YK == CM_YIELD_J2 || YK == CM_YIELD_HILL); }
+template <int YK>
 CM_D void uniaxial_setup(const cm_model_desc& m, const double z[18], const Eval<CM_UNIAXIAL_STRESS>& ev, const double Ht[6][6],
                          UniaxialOp& op, bool want_transposed) {
     const double i2mu = half_over_mu(m);
@@ -1180,12 +1185,26 @@ CM_D void uniaxial_setup(const cm_model_desc& m, const double z[18], const Eval<
     for (int i = 0; i < 3; ++i) {
         double gc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            double h = 0.0;
+        for (int k = 0; k < 6; ++k) gc += ev.gt[k] * cz[i][k];
+        if constexpr (uniaxial_needs_hessian<YK>()) {
 #pragma unroll
-            for (int q = 0; q < 6; ++q) h += Ht[k][q] * cz[i][q];
-            op.hs[i][k] = ev.plastic ? h : 0.0;
-            gc += ev.gt[k] * cz[i][k];
+            for (int k = 0; k < 6; ++k) {
+                double h = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) h += Ht[k][q] * cz[i][q];
+                op.hs[i][k] = ev.plastic ? h : 0.0;
+            }
+        } else {
+            const QuadForm qf = quad_form<YK>(m);
+            const double ip = (ev.plastic && ev.phi > 0.0) ? rcp(ev.phi) : 0.0;
+            const double* c = cz[i];
+            double Ac[6];
+            Ac[0] = qf.a00 * c[0] + qf.a03 * c[3] + qf.a05 * c[5];
+            Ac[3] = qf.a03 * c[0] + qf.a33 * c[3] + qf.a35 * c[5];
+            Ac[5] = qf.a05 * c[0] + qf.a35 * c[3] + qf.a55 * c[5];
+            Ac[1] = qf.a11 * c[1]; Ac[2] = qf.a22 * c[2]; Ac[4] = qf.a44 * c[4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) op.hs[i][k] = ip * (Ac[k] - ev.gt[k] * gc);
         }
         op.gc[i] = ev.plastic ? gc * i2mu : 0.0;
     }
@@ -1283,10 +1302,11 @@ CM_D void uniaxial_apply_T(const UniaxialOp& op, const double z[18], const doubl
     lam[7] = q[1];
     lam[8] = q[2];
 }
+template <int YK>
 CM_D bool uniaxial_solve(const cm_model_desc& m, const double z[18], const Eval<CM_UNIAXIAL_STRESS>& ev, const double Ht[6][6],
                          const double* C, double* delta) {
     UniaxialOp op;
-    uniaxial_setup(m, z, ev, Ht, op, false);
+    uniaxial_setup<YK>(m, z, ev, Ht, op, false);
     uniaxial_apply(op, z, C, delta);
     return op.ok;
 }
@@ -1345,9 +1365,10 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
         if (!__any(running)) break;
         if (running) {
             double delta[NX];
-            residual_mk<MK, DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
-            if constexpr (FAST && DEF == CM_UNIAXIAL_STRESS && MK == CM_SMALL_ELASTIC_PLASTIC) {
-                if (!uniaxial_solve(m, z, ev, Ht, C, delta)) flags |= CM_STATUS_SINGULAR;
+            constexpr bool UXS = FAST && DEF == CM_UNIAXIAL_STRESS && MK == CM_SMALL_ELASTIC_PLASTIC;
+            residual_mk<MK, DEF, YK, !UXS || uniaxial_needs_hessian<YK>()>(m, eg, z, x, xp, ev, C, Ht);
+            if constexpr (UXS) {
+                if (!uniaxial_solve<YK>(m, z, ev, Ht, C, delta)) flags |= CM_STATUS_SINGULAR;
             } else {
                 double A[NX][NX];
                 jacobian_mk<MK, DEF>(m, z, ev, Ht, A);
@@ -1444,10 +1465,10 @@ CM_D bool reverse_point(const cm_model_desc& m, const double eg[6], const double
     constexpr bool UX = FAST && DEF == CM_UNIAXIAL_STRESS;
     Eval<DEF> ev;
     double C[NX], Ht[6][6], At[UX ? 1 : NX][UX ? 1 : NX], lam[NX];
-    residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
+    residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);          // Ht is also applied to u below
     UniaxialOp uop;
     bool ok;
-    if constexpr (UX) { uniaxial_setup(m, z, ev, Ht, uop, true); ok = uop.ok; }
+    if constexpr (UX) { uniaxial_setup<YK>(m, z, ev, Ht, uop, true); ok = uop.ok; }
     else { jacobian_x<DEF, true>(m, z, ev, Ht, At); ok = lu_factor<NX>(At); }
     double csb[6];
     apply_cel(m, sbm, csb);                                  // Cel sbar_m (Cel symmetric)
@@ -1582,10 +1603,10 @@ CM_D bool tangent_point(const cm_model_desc& m, const double eg[6], const double
     constexpr bool UX = FAST && DEF == CM_UNIAXIAL_STRESS;
     Eval<DEF> ev;
     double C[NX], Ht[6][6], A[UX ? 1 : NX][UX ? 1 : NX];
-    residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);
+    residual<DEF, YK, true>(m, eg, z, x, xp, ev, C, Ht);          // the tangent's right-hand sides use Ht
     UniaxialOp uop;
     bool ok;
-    if constexpr (UX) { uniaxial_setup(m, z, ev, Ht, uop, false); ok = uop.ok; }
+    if constexpr (UX) { uniaxial_setup<YK>(m, z, ev, Ht, uop, false); ok = uop.ok; }
     else { jacobian_x<DEF, false>(m, z, ev, Ht, A); ok = lu_factor<NX>(A); }
     const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), lam = m.lambda;
     const double gd = ev.gt[0] + ev.gt[3] + ev.gt[5];

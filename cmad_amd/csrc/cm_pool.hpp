@@ -102,7 +102,7 @@ CM_D void newton_pass(const cm_model_desc& m, const double eg[6], const double* 
                     if (!solve_s<DEF, false>(m, op, evs, z, C, delta)) s.flags |= CM_STATUS_SINGULAR;
                 } else {
                     if constexpr (DEF == CM_UNIAXIAL_STRESS && MK == CM_SMALL_ELASTIC_PLASTIC) {
-                        if (!uniaxial_solve(m, z, ev, Ht, C, delta)) s.flags |= CM_STATUS_SINGULAR;    // the 9 x 9 step through 4 x 4
+                        if (!uniaxial_solve<YK>(m, z, ev, Ht, C, delta)) s.flags |= CM_STATUS_SINGULAR;    // the 9 x 9 step through 4 x 4
                     } else {
                         double A[NX][NX];
                         jacobian_mk<MK, DEF>(m, z, ev, Ht, A);

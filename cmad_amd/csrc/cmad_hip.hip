@@ -96,6 +96,9 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #ifndef CM_OCC_REV_HILL
 #define CM_OCC_REV_HILL 1
 #endif
+#ifndef CM_OCC_UNIAXIAL
+#define CM_OCC_UNIAXIAL 1          // UNIAXIAL_STRESS update / reverse kernels on the quadratic surfaces (4x4 Newton step, no dense Hessian)
+#endif
 #ifndef CM_OCC_PS_J2_PLANE
 #define CM_OCC_PS_J2_PLANE 1       // J2 / PLANE_STRESS kernels on the plane iteration (newton_j2_plane), plain Newton
 #endif
@@ -113,6 +116,7 @@ constexpr int kLsSlots = 2 * 8;         // line search: parked iterate and direc
 template <int DEF, int YK, bool LS, bool TANGENT, bool RL = false>
 constexpr int min_waves_update() {
     if (DEF == CM_PLANE_STRESS && YK == CM_YIELD_J2 && RL && !TANGENT) return LS ? CM_OCC_PS_J2_PLANE_LS : CM_OCC_PS_J2_PLANE;
+    if (DEF == CM_UNIAXIAL_STRESS && (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) && !TANGENT) return CM_OCC_UNIAXIAL;
     if (DEF != CM_FULL_3D) return 1;
     if (YK == CM_YIELD_J2) return LS ? CM_OCC_UPD_J2_LS : CM_OCC_UPD_J2;
     if (YK == CM_YIELD_HOSFORD) return LS ? CM_OCC_UPD_HOSFORD_LS : CM_OCC_UPD_HOSFORD;
@@ -477,6 +481,7 @@ struct Wsq { double w[6]; };
 template <int DEF, int YK, bool LS, int MODE, bool RL = false>
 constexpr int min_waves() {
     if (DEF == CM_PLANE_STRESS && YK == CM_YIELD_J2 && RL) return LS ? CM_OCC_PS_J2_PLANE_LS : CM_OCC_PS_J2_PLANE;
+    if (DEF == CM_UNIAXIAL_STRESS && (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) && (MODE == 1 || MODE == 3)) return CM_OCC_UNIAXIAL;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && LS) return CM_OCC_REV_J2_LS;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_HILL && !LS) return CM_OCC_REV_HILL;
     return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? CM_OCC_REV_J2 : 1;
