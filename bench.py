@@ -134,8 +134,10 @@ def history_workload(args, dev, rank, world, distributed):
     values = j2_voce_values()
     flags = tree_map(lambda leaf: False, values)
     flags["plastic"]["flow stress"] = tree_map(lambda leaf: True, flags["plastic"]["flow stress"])     # Y, S, D active
-    model = SmallElasticPlastic(Parameters(values, flags, tree_map(lambda leaf: None, values)), DefType.PLANE_STRESS)
-    g1 = torch.from_numpy(gauss_point_batch(B, seed=22 + rank, ndims=2)).to(dev)
+    ps = args.workload == "ps_calibration_history" or args.def_type == "plane_stress"
+    model = SmallElasticPlastic(Parameters(values, flags, tree_map(lambda leaf: None, values)),
+                                DefType.PLANE_STRESS if ps else DefType.FULL_3D)
+    g1 = torch.from_numpy(gauss_point_batch(B, seed=22 + rank, ndims=2 if ps else 3)).to(dev)
     ramp = torch.linspace(0.0, 1.5, K + 1, dtype=torch.float64, device=dev)
     gradu_hist = (ramp[:, None, None] * g1[None]).contiguous()                    # proportional ramp to 6 eps_y
     gen = torch.Generator(device=dev); gen.manual_seed(99 + rank)
@@ -165,13 +167,13 @@ def history_workload(args, dev, rank, world, distributed):
         # grad u 32 + previous xi 64 + data 48.  --per-step-history (one launch per step and direction): forward read
         # grad u 32 + xi_prev 64, write xi 64; adjoint read grad u 32 + xi_prev 64 + xi 64 + data 48 + history 64,
         # write history 64
-        bytes_per = (96 + 144) if fused else (160 + 336)
+        bytes_per = ((96 + 144) if fused else (160 + 336)) if ps else ((128 + 176) if fused else (184 + 344))
         value = world * B * K * args.steps / elapsed
         print(json.dumps({
             "metric": METRIC, "value": value, "unit": "point-steps/s (objective + gradient)", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"J2 PLANE_STRESS calibration objective + gradient over a {K}-step history per point "
+            "config": {"workload": f"J2 {'PLANE_STRESS' if ps else 'FULL_3D'} calibration objective + gradient over a {K}-step history per point "
                                    "(side measurement for configs[4])", "points_per_gpu": B, "history_steps": K},
             "roofline": {"bound": "hbm", "achieved": bytes_per * B * K * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_per * B * K * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
@@ -212,7 +214,7 @@ def main():
     ap.add_argument("--workload", default="j2_update_vjp",
                     choices=["j2_update_vjp", "j2_update", "j2_update_tangent", "j2_objective_grad", "hosford_update",
                              "hybrid_update", "hosford_update_vjp", "hybrid_update_vjp", "hosford_update_tangent", "hybrid_update_tangent",
-                             "ps_calibration_history"],
+                             "ps_calibration_history", "calibration_history"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
     args = ap.parse_args()
 
@@ -252,7 +254,7 @@ def main():
 
     B = args.points
     wl = args.workload
-    if wl == "ps_calibration_history":
+    if wl in ("ps_calibration_history", "calibration_history"):   # the second takes --def-type (full_3d / plane_stress)
         return history_workload(args, dev, rank, world, distributed)
     values = j2_voce_values()
     if args.yield_surface != "j2":
