@@ -754,8 +754,15 @@ struct PointRowsIO {
     __device__ __forceinline__ void put(double* base, int64_t row, double v) const { base[row * B + b] = v; }
 };
 
+#ifndef CM_OCC_HIST_J2
+#define CM_OCC_HIST_J2 1           // whole-history objective kernel, J2 / FULL_3D on the radial line
+#endif
+template <int DEF, int YK, bool LS, int MK, bool RL>
+constexpr int min_waves_history() {
+    return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && MK == CM_SMALL_ELASTIC_PLASTIC && RL) ? CM_OCC_HIST_J2 : 1;
+}
 template <int DEF, int YK, bool ROT, bool LS, int MK, bool RL = false>
-__global__ __launch_bounds__(kBlock) void k_history(cm_model_desc m, int64_t B, int K,
+__global__ __launch_bounds__(kBlock, (min_waves_history<DEF, YK, LS, MK, RL>())) void k_history(cm_model_desc m, int64_t B, int K,
         const double* __restrict__ gradu_hist, const double* __restrict__ data_hist, Wsq wsq,
         const double* __restrict__ xi0, double* xi_hist, double* __restrict__ partials, HistoryCotangents hc) {
     const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
