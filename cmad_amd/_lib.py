@@ -65,6 +65,8 @@ def lib():
     # first makes the dynamic loader resolve our NEEDED entry to that already-loaded runtime instead of a
     # second copy from /opt/rocm (two runtimes in one process -> hipErrorNoDevice on the first launch).
     import torch  # noqa: F401  (device-array carrier; loads its HIP runtime)
+    # CMAD_HIP_LIB=/path/to/variant.so: A/B measurements of library builds without overwriting the in-tree build output
+    LIB = os.environ.get("CMAD_HIP_LIB") or globals()["LIB"]
     if not os.path.exists(LIB):
         raise HipLibraryMissing(
             f"{LIB} not found: run `python -m cmad_amd.build` (needs hipcc). "

@@ -26,6 +26,16 @@ using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::e
 
 namespace cm {
 
+// Read-only, wave-uniform device data (the network weights): through the CONSTANT address space the loads are s_load_* into
+// scalar registers.  Through a generic pointer the compiler cannot prove that the kernel's own stores do not alias the data
+// and emits a vector load per lane of the same address plus a vmcnt wait inside the loop over the hidden units.
+#if defined(CM_HOST_BUILD)
+typedef const double* cm_uniform_ptr;
+#else
+typedef const __attribute__((address_space(4))) double* cm_uniform_ptr;
+#endif
+CM_D cm_uniform_ptr uniform_ptr(const double* p) { return (cm_uniform_ptr)p; }
+
 // 1/a without the IEEE division sequence: v_rcp_f64 (~2^-26 relative) + two Newton steps -> ~1 ulp.
 // Used where a is a well-scaled, non-zero quantity (phi, pivots, determinants); 5 instructions instead of ~12.
 CM_D double rcp(double a) {
@@ -63,8 +73,10 @@ CM_D double rsqrt_pos(double a) {
 // constants), e^r by its Taylor polynomial of degree 13 (truncation 4e-18 relative), scaled by 2^k with one ldexp (which
 // also delivers overflow to inf and gradual underflow to 0).  Below 1 ulp over the range the hardening laws use; the
 // argument is clamped to +-1100 so that k fits an int.  tests/test_host_math.py::test_exp_s checks it against libm.
+// EXP_CLAMP = false: the caller guarantees |x| <= 700 (no clamp instructions)
+template <bool EXP_CLAMP = true>
 CM_D double exp_s(double x) {
-    x = fmax(fmin(x, 1100.0), -1100.0);
+    if constexpr (EXP_CLAMP) x = fmax(fmin(x, 1100.0), -1100.0);
     const double k = __builtin_rint(x * CM_SCALAR(0x1.71547652b82fep+0));
     double r = __builtin_fma(k, CM_SCALAR(-0x1.62e42fefa39efp-1), x);
     r = __builtin_fma(k, CM_SCALAR(-0x1.abc9e3b39803fp-56), r);
@@ -253,6 +265,39 @@ CM_D double log_near_one(double S) {
     return lo ? r - 0.6931471805599453 : r;
 }
 
+// log(x) for any positive normal x, ~1 ulp, in ~30 VALU instructions: x = m 2^e with m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh((m - 1) / (m + 1)) by the same odd series as log1p_01 (|s| <= 0.1716, truncation 6e-19 relative),
+// log x = e ln2_hi + (e ln2_lo + log m) with the usual split of ln 2 (e ln2_hi is exact for |e| < 2^11).
+// tests/test_host_math.py::test_softplus_pieces checks it against libm.
+CM_D double log_pos(double x) {
+#if defined(CM_HOST_BUILD)
+    int e;
+    double mant = std::frexp(x, &e);                            // [1/2, 1)
+#else
+    double mant = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+#endif
+    const bool lo = mant < 0.7071067811865476;
+    mant = lo ? mant + mant : mant;
+    e = lo ? e - 1 : e;
+    const double s = (mant - 1.0) * rcp(mant + 1.0);
+    const double s2 = s * s;
+    double p = CM_SCALAR(1.0 / 21.0);
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 19.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 17.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 15.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 13.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 11.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 9.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 7.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 5.0));
+    p = __builtin_fma(s2, p, CM_SCALAR(1.0 / 3.0));
+    const double two_s = s + s;
+    const double r = __builtin_fma(two_s * s2, p, two_s);
+    const double ed = (double)e;
+    return __builtin_fma(ed, CM_SCALAR(0x1.62e42fee00000p-1), __builtin_fma(ed, CM_SCALAR(0x1.a39ef35793c76p-33), r));
+}
+
 struct SoftUnit { double sp, sg; };
 CM_D SoftUnit soft_unit(double a) {
     const double e = exp_s(-fabs(a));                           // in (0, 1]
@@ -262,30 +307,71 @@ CM_D SoftUnit soft_unit(double a) {
     u.sg = (a >= 0.0) ? inv : e * inv;                          // sigmoid(a)
     return u;
 }
+// Both signs of one hidden unit from ONE exponential.  With t = xs . W0[:, o], b = b0[o], p = e^t, q = e^b (uniform: read from
+// the table the host appends to the packed weights, include/cmad_hip.h), A = 1 + q p, Bq = p + q, Pi = A Bq, R = 1 / Pi:
+//     softplus(b + t) + softplus(b - t) = log((1 + q p)(1 + q / p)) = log(Pi) - t
+//     sigmoid(b + t) - sigmoid(b - t)   = q (p^2 - 1) R
+//     sum of sigmoid (1 - sigmoid)      = q p (Bq^2 + A^2) R^2
+// -- one exp, one log, one reciprocal per unit instead of two of each (the two-sided form of soft_unit: ~112 instead of ~189
+// VALU instructions per unit with the Hessian).  Range: t is clamped to +-kIcnnTClamp for the exponential; beyond the clamp the
+// sigmoids are saturated to below 1e-17 and the value grows by |t| - kIcnnTClamp exactly, which is added back.  Units with
+// |b| >= kIcnnBMax (where the clamp would not saturate, or Pi could overflow: 2 (T + |b|) < 709) take the two-sided form; b is
+// uniform, so that branch is too.  Absolute accuracy of every term is ~1e-16 of the unit's own magnitude (p^2 - 1 cancels
+// near t = 0, where the term itself vanishes).
+constexpr double kIcnnTClamp = 190.0, kIcnnBMax = 150.0;
+constexpr int kIcnnRec = 10;             // doubles per hidden-unit record of the device pack (include/cmad_hip.h, nn_weights)
+// offsets into the device pack for widths [6, H, 1]
+CM_D int icnn_off_b1(int H) { return 7 * H + 6; }
+CM_D int icnn_off_scalers(int H) { return 8 * H + 7; }          // in_scale[6], in_min[6], out_scale, out_min, f(0)
+CM_D int icnn_off_records(int H) { return 8 * H + 7 + 15; }     // per unit: W0[0..5][o], b0[o], Wz[o], e^b0[o], e^b0[o] Wz[o]
 template <bool HESS>
 CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6], double& F, double G[6], double Hx[21]) {
-    const double* W0 = w; const double* b0 = w + 6 * H; const double* Wx1 = b0 + H; const double* b1 = Wx1 + 6;
-    const double* Wz = b1 + 1;
-    F = 2.0 * b1[0];
+    const cm_uniform_ptr u = uniform_ptr(w);
+    const cm_uniform_ptr rec = u + icnn_off_records(H);
+    F = 2.0 * u[icnn_off_b1(H)];
 #pragma unroll
     for (int i = 0; i < 6; ++i) G[i] = 0.0;
     if constexpr (HESS) {
 #pragma unroll
         for (int i = 0; i < 21; ++i) Hx[i] = 0.0;
     }
+    // one contiguous record per unit (two wide scalar loads); the next unit's record is requested before this unit's
+    // arithmetic, so its latency is covered
+    double rn[kIcnnRec];
+#pragma unroll
+    for (int i = 0; i < kIcnnRec; ++i) rn[i] = rec[i];
     for (int o = 0; o < H; ++o) {
+        double r[kIcnnRec];
+#pragma unroll
+        for (int i = 0; i < kIcnnRec; ++i) r[i] = rn[i];
+        const cm_uniform_ptr rnext = rec + kIcnnRec * ((o + 1 < H) ? o + 1 : o);
+#pragma unroll
+        for (int i = 0; i < kIcnnRec; ++i) rn[i] = rnext[i];
         double t = 0.0;
         double wc[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { wc[i] = W0[i * H + o]; t += xs[i] * wc[i]; }
-        const SoftUnit up = soft_unit(b0[o] + t), un = soft_unit(b0[o] - t);
-        const double wz = Wz[o];
-        F += (up.sp + un.sp) * wz;
-        const double c1 = (up.sg - un.sg) * wz;
+        for (int i = 0; i < 6; ++i) { wc[i] = r[i]; t += xs[i] * wc[i]; }
+        const double b = r[6], wz = r[7];
+        double c1, c2 = 0.0;
+        if (fabs(b) < kIcnnBMax) {                                  // uniform
+            const double q = r[8], qwz = r[9];
+            const double tc = fmax(fmin(t, kIcnnTClamp), -kIcnnTClamp);
+            const double p = exp_s<false>(tc);
+            const double A = __builtin_fma(q, p, 1.0), Bq = p + q, Pi = A * Bq;
+            const double R = rcp(Pi);
+            const double v = (log_pos(Pi) - tc) + fmax(fabs(t) - kIcnnTClamp, 0.0);
+            F = __builtin_fma(v, wz, F);
+            c1 = qwz * __builtin_fma(p, p, -1.0) * R;
+            if constexpr (HESS) c2 = (qwz * p) * (R * R) * __builtin_fma(A, A, Bq * Bq);
+        } else {
+            const SoftUnit up = soft_unit(b + t), un = soft_unit(b - t);
+            F += (up.sp + un.sp) * wz;
+            c1 = (up.sg - un.sg) * wz;
+            if constexpr (HESS) c2 = (up.sg * (1.0 - up.sg) + un.sg * (1.0 - un.sg)) * wz;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) G[i] += c1 * wc[i];
         if constexpr (HESS) {
-            const double c2 = (up.sg * (1.0 - up.sg) + un.sg * (1.0 - un.sg)) * wz;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const double ci = c2 * wc[i];
@@ -303,7 +389,7 @@ template <bool HESS>
 CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val, double g6[6], double Hp[21]) {
     const double* __restrict__ w = m.nn_weights;
     const int H = m.nn_widths[1];
-    const double* sc = w + 6 * H + H + 6 + 1 + H;             // in_scale[6], in_min[6], out_scale, out_min, f0
+    const cm_uniform_ptr sc = uniform_ptr(w) + icnn_off_scalers(H);   // in_scale[6], in_min[6], out_scale, out_min, f0
     const double h = (s[0] + s[3] + s[5]) * (1.0 / 3.0);
     const double x[6] = {s[0] - h, s[3] - h, s[5] - h, s[1], s[2], s[4]};
     // scaled input; the reference evaluates g(xs) and g(-xs) (input_convex_neural_network.py:59-69)

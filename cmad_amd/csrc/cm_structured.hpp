@@ -365,12 +365,23 @@ CM_D bool solve_s(const cm_model_desc& m, const PlasticOpFor<YK>& op, const Eval
 // LS: the line search is a compile-time variant.  While trial points are evaluated the base iterate and the
 // Newton direction are parked in the lane's LDS column (`stage`, 2*NX doubles); they are read back only when a
 // trial is rejected.
+// On the device the column lives in LDS and is addressed as such (address space 3: ds_read / ds_write with immediate offsets;
+// through a generic pointer the same accesses are flat_load / flat_store, which travel the vector-memory path).
+#if defined(CM_HOST_BUILD)
+typedef double cm_stage_double;
+#else
+typedef __attribute__((address_space(3))) double cm_stage_double;
+#endif
 struct LaneStage {
-    double* p;        // this lane's first slot
-    int stride;       // distance between consecutive slots of one lane (block size on the device, 1 on the host)
+    cm_stage_double* p;   // this lane's first slot
+    int stride;           // distance between consecutive slots of one lane (block size on the device, 1 on the host)
     // volatile: without it the compiler forwards the stored values to the loads and keeps them in registers
-    CM_D volatile double& at(int k) const { return const_cast<volatile double*>(p)[k * stride]; }
+    CM_D volatile cm_stage_double& at(int k) const { return const_cast<volatile cm_stage_double*>(p)[k * stride]; }
 };
+// the lane's column of a __shared__ staging array (device) / of a plain array (host)
+CM_D LaneStage lane_stage(double* base, int lane_offset, int stride) {
+    return LaneStage{(cm_stage_double*)base + lane_offset, stride};
+}
 
 // ||C||^2 as the convergence test and the line search's merit see it: the plain sum of squares, or (NORM = RateNorm below) the
 // norm of a constant linear image of C -- Newton's iterates do not depend on such a map, its stopping test does.

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>
     strain_from_gradu<DEF, ROT>(m, G, eg);
     strain_z<DEF, ROT>(m, z);
     __shared__ double ls_stage[(LS && has_structured<DEF, YK>()) ? kLsSlots * kBlock : 1];   // parked iterate + direction
-    uint32_t st = newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
+    uint32_t st = newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock));
     Eval<DEF> ev;
     strain_stress<DEF>(m, eg, z, x, ev);
     if (status) {
@@ -193,8 +193,16 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>
 // points (W = wavefronts in the grid; static assignment -- no atomics, no workspace, results independent of scheduling).
 // Each lane runs the resumable Newton of cm_pool.hpp on its current point; when kPoolRefill lanes of the wavefront have
 // finished theirs (or nothing is left to hand out), those lanes store their results and take the next consecutive points
-// of the wavefront's chunk, so a refill reads and writes contiguous runs of every SoA row.  Used for the iteration-bound
-// configurations (everything but J2 / FULL_3D): a lockstep wavefront runs max(iterations) over its 64 points there.
+// of the wavefront's stream.  Used for the iteration-bound configurations (pool_pays<> / pool_route() below: the network
+// surfaces, and Hosford under the line search): a lockstep wavefront runs max(iterations) over its 64 points there.
+//
+// Input staging (round 3).  With ~4 passes per point a quarter of the lanes finish in EVERY pass, so a refill that loads its
+// 16 input rows from global memory puts an HBM round trip (~2 us) on the critical path of every pass (round-2 counters:
+// 43 % of the wave-cycles waiting, 28 % issuing VALU).  The wavefront's point stream is therefore staged through LDS in halves
+// of 32 consecutive points: an LDS-DMA copy (global_load_lds: coalesced 16-byte pieces straight into LDS, no registers) of the
+// half after next is issued as soon as a half has been handed out, and lands while the lanes iterate; a refill is 16 ds_reads.
+// Ring: 2 halves x (n_gradu + n_xi) rows x 32 points (8 KB under FULL_3D).  `wide` = 16-byte pieces (B even and both arrays
+// 16-byte aligned), else 4-byte pieces (any alignment a double array has).
 #ifndef CM_POOL_WAVES_HOSFORD
 #define CM_POOL_WAVES_HOSFORD 1
 #endif
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>
 #define CM_POOL_REFILL 16
 #endif
 constexpr int kPoolRefill = CM_POOL_REFILL;
+constexpr int kPoolHalf = 32;            // points per staged half (one LDS-DMA instruction moves 4 rows of it in 16-byte pieces)
 
 template <int DEF, int YK>
 constexpr int min_waves_pool() { return is_dense_yield(YK) ? CM_POOL_WAVES_NN : CM_POOL_WAVES_HOSFORD; }
@@ -214,16 +223,54 @@ constexpr int min_waves_pool() { return is_dense_yield(YK) ? CM_POOL_WAVES_NN : 
 template <int YK, bool LS>
 constexpr bool pool_pays() { return is_nn_yield(YK) || (YK == CM_YIELD_HOSFORD && LS); }
 
+typedef __attribute__((address_space(3))) double cm_lds_double;
+typedef __attribute__((address_space(3))) void* cm_lds_vptr;
+typedef const __attribute__((address_space(1))) void* cm_gvptr;
+
 template <int DEF, int YK, bool ROT, bool LS>
-__global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int kPoolChunk,
+__global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int chunk_shift, int wide,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
-    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NIN = NU + NX;
+    __shared__ double ring[2 * NIN * kPoolHalf];                 // [half & 1][row][32 points]
     __shared__ double ls_stage[LS ? 2 * NX * 64 : 1];
-    const LaneStage stage{ls_stage + (LS ? threadIdx.x : 0), 64};
+    const LaneStage stage = lane_stage(ls_stage, LS ? threadIdx.x : 0, 64);
+    volatile cm_lds_double* const ringl = (volatile cm_lds_double*)ring;
+    const unsigned lane = threadIdx.x;
     const int64_t nwaves = gridDim.x;
-    int64_t chunk = blockIdx.x;                                  // wave-uniform cursor over this wavefront's chunks
-    int64_t cur = chunk * kPoolChunk, cend = cur + kPoolChunk < B ? cur + kPoolChunk : B;
+    // The wavefront's stream in halves of 32 points: half h lies in chunk (blockIdx.x + (h >> hshift) * nwaves) at offset
+    // (h & hmask) * 32; its first point is half_base(h).  Chunks hold 2^chunk_shift points (a multiple of 32).
+    const int hshift = chunk_shift - 5, hmask = (1 << hshift) - 1;
+#define CM_HALF_BASE(h) ((((int64_t)blockIdx.x + (int64_t)((h) >> hshift) * nwaves) << chunk_shift) + (int64_t)(((h) & hmask) * kPoolHalf))
+    int next_issue = 0, ready = 0, cons_half = 0, cons_off = 0;  // wave-uniform cursors: issued / arrived / handed out
+    bool stream_end = false;
+    // issue the LDS-DMA copies of every half whose ring slot is free (at most two halves ahead of the consumer)
+#define CM_TRY_ISSUE() \
+    while (!stream_end && next_issue < cons_half + 2) { \
+        const int64_t g0_ = CM_HALF_BASE(next_issue); \
+        if (g0_ >= B) { stream_end = true; break; } \
+        const unsigned dst_ = (unsigned)__builtin_amdgcn_readfirstlane((next_issue & 1) * NIN * kPoolHalf); \
+        if (wide) { \
+            int64_t pt_ = g0_ + 2 * (lane & 15); \
+            if (pt_ > B - 2) pt_ = B - 2;                       /* pairs past the end re-read the last pair; never handed out */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < (NIN + 3) / 4; ++i_) { \
+                const int r_ = 4 * i_ + (int)(lane >> 4); \
+                if (r_ < NIN) { \
+                    const double* src_ = (r_ < NU) ? gradu + (int64_t)r_ * B + pt_ : xi_prev + (int64_t)(r_ - NU) * B + pt_; \
+                    __builtin_amdgcn_global_load_lds((cm_gvptr)src_, (cm_lds_vptr)((cm_lds_double*)ring + dst_ + 4 * i_ * kPoolHalf), 16, 0, 0); \
+                } \
+            } \
+        } else { \
+            int64_t pt_ = g0_ + (lane >> 1); \
+            if (pt_ > B - 1) pt_ = B - 1; \
+            _Pragma("unroll") for (int r_ = 0; r_ < NIN; ++r_) { \
+                const double* src_ = (r_ < NU) ? gradu + (int64_t)r_ * B + pt_ : xi_prev + (int64_t)(r_ - NU) * B + pt_; \
+                __builtin_amdgcn_global_load_lds((cm_gvptr)((const char*)src_ + 4 * (lane & 1)), \
+                                                 (cm_lds_vptr)((cm_lds_double*)ring + dst_ + r_ * kPoolHalf), 4, 0, 0); \
+            } \
+        } \
+        ++next_issue; \
+    }
     double x[NX], xp[NX], eg[6], z[Dims<DEF>::NZ];
     strain_z<DEF, ROT>(m, z);
 #pragma unroll
@@ -234,10 +281,11 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
     bool running = false;
     PassState st;
     pass_reset(st);
+    CM_TRY_ISSUE()
     for (;;) {
         const uint64_t idle_mask = __ballot(!running);
         const int nidle = __popcll(idle_mask);
-        const bool more = cur < B;                               // uniform: points left in this wavefront's chunks
+        const bool more = cons_half < next_issue;                // uniform: issued points not yet handed out
         if (nidle == 64 || (more && nidle >= kPoolRefill)) {
             if (!running && pt >= 0) {                           // retire: state, stress and status of the finished point
                 Eval<DEF> ev;
@@ -263,34 +311,43 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
             if (more) {                                          // refill: consecutive points to the idle lanes, in lane order
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                int need = nidle, first = 0;
-                while (need > 0 && cur < B) {                    // uniform; at most two chunks per refill
-                    const int avail = (int)(cend - cur);
-                    const int take = need < avail ? need : avail;
-                    if (!running && pt < 0 && rank >= first && rank < first + take) pt = cur + (rank - first);
-                    cur += take; first += take; need -= take;
-                    if (cur == cend) {
-                        chunk += nwaves;
-                        cur = chunk * kPoolChunk;
-                        cend = cur + kPoolChunk < B ? cur + kPoolChunk : B;
-                        if (cur > B) cur = B;
+                int need = nidle, first = 0, slot = -1;
+                while (need > 0 && cons_half < next_issue) {     // uniform; at most three halves per refill
+                    if (cons_half >= ready) {                    // first use of this half: its copy (and all before it) has landed
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        ready = next_issue;
                     }
+                    const int64_t g0 = CM_HALF_BASE(cons_half);
+                    const int vc = (B - g0 < kPoolHalf) ? (int)(B - g0) : kPoolHalf;     // >= 1: only halves that start below B are issued
+                    const int avail = vc - cons_off;
+                    const int take = need < avail ? need : avail;
+                    if (!running && slot < 0 && rank >= first && rank < first + take) {
+                        const int sl = cons_off + (rank - first);
+                        pt = g0 + sl;
+                        slot = (cons_half & 1) * NIN * kPoolHalf + sl;
+                    }
+                    cons_off += take; first += take; need -= take;
+                    if (cons_off == vc) { ++cons_half; cons_off = 0; }
                 }
-                if (!running && pt >= 0) {
+                if (!running && slot >= 0) {
                     double G[NU];
 #pragma unroll
-                    for (int k = 0; k < NU; ++k) G[k] = (gradu + (int64_t)k * B)[pt];
+                    for (int k = 0; k < NU; ++k) G[k] = ringl[slot + k * kPoolHalf];
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) { xp[k] = (xi_prev + (int64_t)k * B)[pt]; x[k] = xp[k]; }
+                    for (int k = 0; k < NX; ++k) { xp[k] = ringl[slot + (NU + k) * kPoolHalf]; x[k] = xp[k]; }
                     strain_from_gradu<DEF, ROT>(m, G, eg);
                     pass_reset(st);
                     running = true;
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring reads are complete before a slot is refilled
+                CM_TRY_ISSUE()
             }
         }
-        if (!__any(running)) break;
+        if (!__any(running)) break;                              // nothing running => nothing left (a refill always hands out >= 1 point)
         newton_pass<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, st, running, stage);
     }
+#undef CM_TRY_ISSUE
+#undef CM_HALF_BASE
 }
 
 // ---- cm_update_rate: rate-form model (small_rate_elastic_plastic) ------------------------------------------
@@ -321,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t
     else {
         strain_from_gradu<DEF, ROT>(m, G, deg);
         strain_z<DEF, ROT>(m, z);
-        st = newton_rate_any<DEF, YK, LS>(m, deg, z, xp, x, valid, LaneStage{ls_stage + (STAGED ? threadIdx.x : 0), kBlock});
+        st = newton_rate_any<DEF, YK, LS>(m, deg, z, xp, x, valid, lane_stage(ls_stage, STAGED ? threadIdx.x : 0, kBlock));
     }
     double sg[6];
     to_global<ROT>(m, x, sg);                                    // small_rate_elastic_plastic.py:351-359
@@ -528,8 +585,8 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     uint32_t st = CM_STATUS_CONVERGED;
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
-            if constexpr (RL) st = newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock});
-            else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, LaneStage{ls_stage + (LS ? threadIdx.x : 0), kBlock}, z);
+            if constexpr (RL) st = newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock));
+            else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock), z);
         }
         else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid);
         if constexpr (!EARLY) load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
@@ -663,7 +720,7 @@ __global__ __launch_bounds__(kBlock) void k_reverse_rate(cm_model_desc m, int64_
     }
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (RU) ru_newton<YK, LS>(m, G[0], xp, x, valid);
-        else newton_rate_any<DEF, YK, LS>(m, deg, z, xp, x, valid, LaneStage{lds_buf + (STAGED ? threadIdx.x : 0), kBlock});
+        else newton_rate_any<DEF, YK, LS>(m, deg, z, xp, x, valid, lane_stage(lds_buf, STAGED ? threadIdx.x : 0, kBlock));
         if (xi_out && valid) store_soa<NX>(xi_out, B, b, x);
     } else {
         load_soa<NX>(xi_in, B, b, x);
@@ -778,7 +835,7 @@ __global__ __launch_bounds__(kBlock, (min_waves_history<DEF, YK, LS, MK, RL>()))
     if (hc.xibar_hist) hc.xibar_hist += blk0;
     if (hc.lam_hist) hc.lam_hist += blk0;
     history_point<DEF, YK, ROT, LS, MK, RL>(m, K, gradu_hist + blk0, data_hist ? data_hist + blk0 : nullptr, wsq.w, xi0 + blk0,
-                                        xi_hist + blk0, valid, LaneStage{lds_buf + (STAGED ? threadIdx.x : 0), kBlock},
+                                        xi_hist + blk0, valid, lane_stage(lds_buf, STAGED ? threadIdx.x : 0, kBlock),
                                         SoaRowsIO{B, b}, red, hc);
     if (!valid) {
 #pragma unroll
@@ -800,7 +857,7 @@ __global__ __launch_bounds__(kBlock) void k_primal_history(cm_model_desc m, int6
     __shared__ double ls_stage[STAGED ? kLsSlots * kBlock : 1];
     primal_history_point<DEF, YK, ROT, LS, MK, RL>(m, K, gradu_hist + blk0, xi0 + blk0, xi_hist ? xi_hist + blk0 : nullptr,
                                                sigma_hist ? sigma_hist + blk0 : nullptr, status_hist ? status_hist + blk0 : nullptr,
-                                               valid, LaneStage{ls_stage + (STAGED ? threadIdx.x : 0), kBlock}, SoaRowsIO{B, b});
+                                               valid, lane_stage(ls_stage, STAGED ? threadIdx.x : 0, kBlock), SoaRowsIO{B, b});
 }
 
 // ---- cm_evaluate: residual / Jacobian block / stress / stress-derivative block at given states ----------
@@ -1079,6 +1136,16 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     return true;
 }
 
+// Combinations the rate-form entry points have no specialisation for (checked at run time BEFORE any launch, so that an entry
+// point never returns CM_OK without having written its outputs): the arithmetic-T / forward-mode kernels of the rate form with a
+// dense yield surface, and the 12-dof UNIAXIAL_STRESS rate form with a dense yield surface.
+inline bool rate_dense(const cm_model_desc* m, int model_kind) {
+    return model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind);
+}
+inline bool rate_uniaxial_dense(const cm_model_desc* m) {
+    return m->def_type == CM_UNIAXIAL_STRESS && is_dense_yield(m->yield_kind);
+}
+
 // calls F.template operator()<DEF, YK, ROT>() for the runtime (def_type, yield_kind, rotation) triple
 // returns false when no specialisation exists (the caller reports CM_ERR_UNSUPPORTED -- never a silent no-op)
 // UNIAXIAL_STRESS is built for the total-form entries and cm_hessians_rate (`UNI` = the caller has those specialisations)
@@ -1231,10 +1298,12 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
             if (!(m->solver_flags & CM_SOLVER_LOCKSTEP) && B >= 256) {
                 static const int resident = pool_resident_waves((const void*)k_update_pool<D, Y, R, LS>);
                 // chunks of 256 points when every resident wavefront gets at least eight of them, else of 64
-                const int chunk = (B >= (int64_t)resident * 256 * 8) ? 256 : 64;
-                const int64_t nchunks = (B + chunk - 1) / chunk;
+                const int chunk_shift = (B >= (int64_t)resident * 256 * 8) ? 8 : 6;
+                const int64_t nchunks = (B + ((int64_t)1 << chunk_shift) - 1) >> chunk_shift;
                 const unsigned nw = (unsigned)(nchunks < resident ? nchunks : resident);
-                hipLaunchKernelGGL((k_update_pool<D, Y, R, LS>), dim3(nw), dim3(64), 0, s, md, B, chunk, gradu, xi_prev, xi, sigma, status);
+                // 16-byte LDS-DMA pieces need every row start 16-byte aligned: both arrays, and an even row length
+                const int wide = ((B & 1) == 0 && (((uintptr_t)gradu | (uintptr_t)xi_prev) & 15) == 0) ? 1 : 0;
+                hipLaunchKernelGGL((k_update_pool<D, Y, R, LS>), dim3(nw), dim3(64), 0, s, md, B, chunk_shift, wide, gradu, xi_prev, xi, sigma, status);
                 return;
             }
         }
@@ -1438,7 +1507,7 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
                     const double* xi_prev, const double* xi,
                     double* d2C, double* d2S, double* dC, double* dS, double* C0, double* S0, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || !has_generic_eval(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK)) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
@@ -1499,7 +1568,7 @@ template <int MK>
 int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu,
                         const double* gradu_prev, const double* xi_prev, const double* xi, double* dC, double* dS, void* stream) {
     if (!m || B < 0 || n_ep < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || !has_generic_eval(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK)) return CM_ERR_UNSUPPORTED;
     if (B == 0 || n_ep == 0) return CM_OK;
     if (!ep_index || !gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     const cm_model_desc md = *m;
@@ -1519,7 +1588,7 @@ int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n
                                  const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* sbar_hist,
                                  double* grad_ep, void* workspace, int64_t wbytes, void* stream) {
     if (!m || B < 0 || K < 1 || n_ep < 0 || !grad_ep) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || !has_generic_eval(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK)) return CM_ERR_UNSUPPORTED;
     if (n_ep == 0) return CM_OK;
     if (!workspace || wbytes < (B > 0 ? B : 1) * (int64_t)n_ep * (int64_t)sizeof(double)) return CM_ERR_WORKSPACE;
     if (!ep_index || (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !sbar_hist))) return CM_ERR_BAD_ARG;
@@ -1598,7 +1667,7 @@ int cm_update(const cm_model_desc* m, int64_t B, const double* gradu, const doub
 int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
                    const double* xi_prev, double* xi, double* sigma, uint32_t* status, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || rate_uniaxial_dense(m)) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !gradu_prev || !xi_prev || !xi) return CM_ERR_BAD_ARG;
     const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
@@ -1619,7 +1688,7 @@ int cm_update_rate_tangent(const cm_model_desc* m, int64_t B, const double* grad
                            const double* xi_prev, double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status,
                            void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || rate_uniaxial_dense(m)) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !gradu_prev || !xi_prev || !xi || !dsigma_dgradu) return CM_ERR_BAD_ARG;
     const dim3 grid((unsigned)nblocks_of(B)), block(kBlock);
@@ -1770,7 +1839,7 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
                      const double* xi_prev, const double* xi, double* C, double* jac, double* sigma, double* dsigma,
                      void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || rate_uniaxial_dense(m)) return CM_ERR_UNSUPPORTED;
     if (which != CM_W_XI && which != CM_W_XI_PREV && which != CM_W_PARAMS && which != CM_W_U && which != CM_W_U_PREV &&
         which != CM_W_NONE) return CM_ERR_BAD_ARG;
     if (B == 0) return CM_OK;

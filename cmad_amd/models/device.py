@@ -58,6 +58,18 @@ def _first_key(d):
     return next(iter(d))
 
 
+def unit_records(nn_params):
+    """Per unit of the first hidden layer of an ICNN [6, H, ..., 1]: W0[0..5][o], b0[o], Wz[o], exp(b0[o]), exp(b0[o]) Wz[o]
+    (Wz = first z-layer's weights when the next layer is the scalar output, else zeros: deeper networks do not use it)."""
+    W0 = np.asarray(nn_params["x params"][0]["weights"], dtype=np.float64)
+    b0 = np.asarray(nn_params["x params"][0]["biases"], dtype=np.float64).ravel()
+    Wz = np.asarray(nn_params["z params"][0]["weights"], dtype=np.float64)
+    wz = Wz.ravel() if Wz.shape[1] == 1 else np.zeros_like(b0)
+    with np.errstate(over="ignore"):
+        q = np.exp(b0)                              # entries with |b0| >= 150 are never read (two-sided form in the kernel)
+        return np.column_stack([W0.T, b0, wz, q, q * wz]).ravel()
+
+
 class HybridHillEffectiveStress:
     """Selector for the hybrid yield surface phi = phi_hill(sigma) + ICNN(dev sigma)
     (`hybrid_hill_effective_stress`, cmad/models/effective_stress.py:149-163).  Pass an instance as
@@ -74,12 +86,15 @@ class HybridHillEffectiveStress:
         self.icnn = icnn
 
     def packed(self, values):
-        """Device layout: the oracle/ICNN packing + f(0) of the scaled network appended."""
+        """Device layout (include/cmad_hip.h, `nn_weights`): the ICNN packing, then f(0) of the scaled network, then one
+        record of 10 doubles per unit of the first hidden layer -- W0[0..5][o], b0[o], Wz[o], exp(b0[o]), exp(b0[o]) Wz[o] --
+        which is what the kernels' loop over the hidden units reads (contiguous: a few wide scalar loads per unit; the
+        exponential of the bias lets both signs of a unit come from ONE exponential of the lane's own argument)."""
         from ..neural_networks.input_convex_neural_network import forward
         nn_params = values["plastic"]["effective stress"].get("neural network", self.icnn.params)
         widths, w = self.icnn.pack_for_device(nn_params)
         f0 = float(np.asarray(forward(np.zeros(widths[0]), nn_params)).ravel()[0])
-        return widths, np.concatenate([w, [f0]])
+        return widths, np.concatenate([w, [f0], unit_records(nn_params)])
 
 
 class ScaledHybridHillEffectiveStress(HybridHillEffectiveStress):

@@ -26,12 +26,18 @@ def shard_bounds(B: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+COLLECTIVE_CALLS = 0        # how many result vectors went through dist.all_reduce in this process (tests assert on it)
+
+
 def allreduce_sum_(t, group=None):
-    """In-place SUM all-reduce of the (1 + CM_NUM_PARAMS) result vector when torch.distributed is initialised
-    (backend nccl == RCCL on GPUs; gloo in the CPU tests); no-op otherwise."""
+    """In-place SUM all-reduce of the (1 + CM_NUM_PARAMS) result vector whenever torch.distributed is initialised -- also for
+    a one-rank group, so that a single-GPU rehearsal sends the vector through the same ncclAllReduce the N-GPU job uses
+    (backend nccl == RCCL on GPUs; gloo in the CPU tests).  Without a process group there is nothing to exchange."""
+    global COLLECTIVE_CALLS
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        COLLECTIVE_CALLS += 1
     return t
 
 

@@ -62,13 +62,16 @@ enum cm_param_index {
  * CM_SOLVER_J2_RADIAL_LINE is accepted for compatibility (the restriction is the default). */
 #define CM_SOLVER_J2_RADIAL_LINE 1
 #define CM_SOLVER_GENERAL_NEWTON 2
-/* cm_update runs the iteration-bound configurations (everything but J2 / FULL_3D) on a work pool: a lane that has
- * finished its Gauss point takes the next one instead of waiting for the slowest point of its wavefront (same
- * iteration per point, same results).  CM_SOLVER_LOCKSTEP keeps one point per lane for the whole kernel. */
-#define CM_SOLVER_LOCKSTEP 4
-/* For those same configurations cm_update_tangent, cm_update_and_vjp, and cm_objective_grad when it is given a state buffer
+/* cm_update runs the iteration-bound configurations on a work pool: a lane that has finished its Gauss point takes the next one
+ * instead of waiting for the slowest point of its wavefront (same iteration per point, same results).  The predicate
+ * (pool_route() in cmad_hip.hip, DeviceEvaluator.pool_route in cmad_amd/models/device.py): total-form model, B >= 256, and
+ * yield_kind is CM_YIELD_HYBRID_HILL_NN / CM_YIELD_SCALED_HYBRID_HILL_NN, or CM_YIELD_HOSFORD with ls_max_evals > 0.  Every other
+ * configuration (J2, Hill, Barlat, Hosford without the line search) measured slower on the pool and stays one point per lane.
+ * CM_SOLVER_LOCKSTEP keeps one point per lane for the whole kernel for the pool configurations too (it changes nothing elsewhere).
+ * For the pool configurations cm_update_tangent, cm_update_and_vjp, and cm_objective_grad when it is given a state buffer
  * (xi != NULL), run as work-pool update + a second kernel over the stored states (tangent / reverse sweep; two launches on the
  * stream, same results and reduction order) instead of one lockstep fused kernel; CM_SOLVER_LOCKSTEP keeps the single kernel. */
+#define CM_SOLVER_LOCKSTEP 4
 
 /* status word written per point by cm_update* (all optional outputs may be NULL) */
 #define CM_STATUS_ITERS_MASK 0xFFFFu
@@ -102,7 +105,15 @@ typedef struct cm_model_desc {
     double  abs_tol, rel_tol;   /* default 1e-14 / 1e-14 */
     double  ls_c1, ls_lo, ls_hi;/* sufficient decrease 1e-4, backtrack factors 0.5 / 0.9 */
     /* symmetric input-convex network of the hybrid Hill + NN yield surface
-     * (neural_networks/input_convex_neural_network.py:36-69); device pointer or NULL */
+     * (neural_networks/input_convex_neural_network.py:36-69); device pointer or NULL.  Layout (doubles), widths [6, H, 1]:
+     *   W0[6][H] (x-layer 0, row-major in x out), b0[H], Wx1[6] (x-layer 1), b1, Wz[H] (z-layer 0),
+     *   in_scale[6], in_min[6], out_scale, out_min      (input / output AffineScaler, :13-33)
+     *   f0 = forward(0)                                 (value of the scaled network at the origin)
+     *   rec[H][10] = W0[0..5][o], b0[o], Wz[o], exp(b0[o]), exp(b0[o]) Wz[o]
+     *                                                   (what the kernels' loop over the hidden units reads: one contiguous
+     *                                                    record per unit -> wide scalar loads; exp(b0) lets both signs of a
+     *                                                    unit come from one exponential.  Built by
+     *                                                    cmad_amd.models.device.unit_records) */
     const double* nn_weights;
     int32_t nn_nlayers;
     int32_t nn_widths[7];

@@ -570,6 +570,11 @@ int hh_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* 
 #endif
 #if HH_HAS(0)
 void hh_log1p_01(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n; ++i) y[i] = log1p_01(x[i]); }
+void hh_log_pos(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n; ++i) y[i] = log_pos(x[i]); }
+// cm::icnn_symmetric on n scaled inputs: F[n], G[n][6], Hx[n][21] (packed upper triangle); w = the device weight pack
+void hh_icnn_symmetric(const double* w, int H, int64_t n, const double* xs, double* F, double* G, double* Hx) {
+    for (int64_t i = 0; i < n; ++i) icnn_symmetric<true>(w, H, xs + 6 * i, F[i], G + 6 * i, Hx + 21 * i);
+}
 void hh_soft_unit(int64_t n, const double* x, double* sp, double* sg) {
     for (int64_t i = 0; i < n; ++i) { const SoftUnit u = soft_unit(x[i]); sp[i] = u.sp; sg[i] = u.sg; }
 }

@@ -51,13 +51,46 @@ def newton_settings(max_iters=10, abs_tol=1e-14, rel_tol=1e-14, ls_kind=LS_NONE,
     return Newton(max_iters, abs_tol, rel_tol, ls_kind, ls_max_evals, c1, lo, hi)
 
 
+_PORT_SO = os.path.join(_ORACLE_DIR, "libcmad_port.so")
+
+
 def build(force=False):
-    """Compile the oracle if needed (g++, a few seconds)."""
+    """Compile the oracle (and the CPU port of the kernel arithmetic that bench.py times beside it) if needed
+    (g++, a few seconds)."""
     src = [os.path.join(_ORACLE_DIR, f) for f in ("cmad_oracle.cpp", "dual.hpp")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
-    if force or stale:
+    csrc = os.path.join(_ROOT, "cmad_amd", "csrc")
+    psrc = [os.path.join(_ORACLE_DIR, "cmad_port.cpp"), os.path.join(_ROOT, "include", "cmad_hip.h")] + \
+           [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hpp")]
+    pstale = (not os.path.exists(_PORT_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_PORT_SO) for s in psrc)
+    if force:
+        subprocess.run(["make", "-C", _ORACLE_DIR, "clean"], check=True, capture_output=True)
+    if force or stale or pstale:
         subprocess.run(["make", "-C", _ORACLE_DIR], check=True, capture_output=True)
     return _SO
+
+
+_port = None
+
+
+def port_update_and_vjp(desc, gradu, xi_prev, sbar6, general=False, nthreads=1):
+    """oracle/cmad_port.cpp: the kernels' own per-point arithmetic (host build of cmad_amd/csrc) in an OpenMP loop -- update +
+    vjp of `cm_update_and_vjp` for FULL_3D, Q = I, plain Newton.  `desc` is a cmad_amd._lib.ModelDesc.
+    Returns (xi (7, B), sigma (6, B), grad KP (12,))."""
+    global _port
+    if _port is None:
+        build()
+        _port = C.CDLL(_PORT_SO)
+    from cmad_amd import _lib as cl
+    assert _port.port_sizeof_desc() == C.sizeof(cl.ModelDesc)
+    gradu, xi_prev, sbar6 = f64(gradu), f64(xi_prev), f64(sbar6)
+    B = gradu.shape[1]
+    xi = np.empty((7, B)); sig = np.empty((6, B)); g = np.zeros(12)
+    rc = _port.port_update_and_vjp(C.byref(desc), C.c_int64(B), _p(gradu), _p(xi_prev), _p(sbar6), _p(xi), _p(sig), _p(g),
+                                   C.c_int(int(general)), C.c_int(int(nthreads)))
+    if rc != 0:
+        raise NotImplementedError("cmad_port: FULL_3D, Q = I, no line search, J2 / Hill / Hosford only")
+    return xi, sig, g
 
 
 _lib = None

@@ -754,23 +754,32 @@ model = SmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
 w = np.zeros((3, 3)); w[0, 0] = w[1, 1] = 1.0
 obj = BatchedCalibrationObjective(model, gh, dh, w)
 x = model.parameters.flat_active_values(True)
+import cmad_amd.objectives.batched as batched
+calls = []
+orig = dist.all_reduce
+def spy(t, *a, **k):                           # what the product hands to the collective, and on which backend
+    calls.append((tuple(t.shape), str(t.dtype), t.is_cuda, dist.get_backend(k.get("group"))))
+    return orig(t, *a, **k)
+dist.all_reduce = spy
 r = obj.evaluate(x)
+dist.all_reduce = orig
 if use_group:
-    t = torch.ones(13, dtype=torch.float64, device="cuda")
-    dist.all_reduce(t)                         # the collective itself: 13 doubles through RCCL
-    assert float(t.sum()) == 13.0
     backend = dist.get_backend()
     dist.destroy_process_group()
 else:
     backend = "none"
-print("RESULT " + json.dumps({"J": r.J, "grad": list(map(float, r.grad)), "backend": backend}))
+print("RESULT " + json.dumps({"J": r.J, "grad": list(map(float, r.grad)), "backend": backend,
+                              "collective_calls": batched.COLLECTIVE_CALLS, "seen": calls}))
 '''
 
 
 def test_sharded_objective_through_rccl_process_group(tmp_path):
     """The multi-GPU path's collective on hardware: a fresh child process brings up a 1-rank `nccl` (= RCCL) process group
-    before touching the GPU, evaluates `BatchedCalibrationObjective` on its shard -- the (1 + 12)-vector goes through
-    `dist.all_reduce` -- and must report the same objective and gradient as a child that runs without a group.
+    before touching the GPU and evaluates `BatchedCalibrationObjective` on its shard.  `allreduce_sum_` sends the product's own
+    (1 + 12)-vector through `dist.all_reduce` whenever a group is initialised (one rank included), so the vector really
+    traverses ncclAllReduce: the child records every tensor handed to the collective (a CUDA float64 vector of 13 on the nccl
+    backend, exactly once per evaluation) and the counter the collective path increments; objective and gradient must equal
+    those of a child that runs without a group (whose counter stays 0).
     (The 8-GPU scaling run is the driver's; world size 2 over gloo runs in tests/test_host_logic.py.)"""
     import json
     import subprocess
@@ -786,6 +795,8 @@ def test_sharded_objective_through_rccl_process_group(tmp_path):
         line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         out[flag] = json.loads(line[len("RESULT "):])
     assert out["1"]["backend"] == "nccl"
+    assert out["1"]["collective_calls"] == 1 and out["0"]["collective_calls"] == 0
+    assert out["1"]["seen"] == [[[13], "torch.float64", True, "nccl"]] and out["0"]["seen"] == []
     assert np.isfinite(out["1"]["J"]) and out["1"]["J"] > 0.0
     np.testing.assert_allclose(out["1"]["J"], out["0"]["J"], rtol=1e-14)
     np.testing.assert_allclose(out["1"]["grad"], out["0"]["grad"], rtol=1e-13, atol=0.0)

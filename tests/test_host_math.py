@@ -435,6 +435,55 @@ def test_softplus_pieces():
         sg_ref = np.where(a >= 0, 1. / (1. + np.exp(-np.abs(a))), np.exp(-np.abs(a)) / (1. + np.exp(-np.abs(a))))
     np.testing.assert_allclose(sp, sp_ref, rtol=1e-15, atol=1e-320)
     np.testing.assert_allclose(sg, sg_ref, rtol=1e-15, atol=1e-320)
+    # cm::log_pos: log of any positive normal double
+    x = np.concatenate([np.exp(rng.uniform(-700., 700., 300000)), rng.uniform(0.5, 2.0, 100000),
+                        np.array([1.0, 0.7071067811865476, 0.7071067811865475, 1.4142135623730951, 2.0, 1e-300, 1e300])])
+    y = np.zeros_like(x)
+    L.hh_log_pos(C.c_int64(x.size), vp(x), vp(y))
+    ref = np.log(x)
+    assert y[x == 1.0].any() == False
+    nz = ref != 0
+    ulp = np.abs(y[nz] - ref[nz]) / np.spacing(np.abs(ref[nz]))
+    assert ulp.max() <= 2.0, ulp.max()
+
+
+def test_icnn_one_exponential_per_unit():
+    """cm::icnn_symmetric (both signs of a hidden unit from one exponential, one logarithm, one reciprocal; table exp(b0)
+    appended to the weight pack) against the plain formulas f(x) + f(-x), its gradient and Hessian in numpy -- moderate inputs,
+    saturated units beyond the clamp, and a unit with |b0| above the fast form's range (two-sided fallback)."""
+    import ctypes as C
+    import numpy as np
+    import host_harness_lib as hh
+    L = hh.lib()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(5)
+    H = 9
+    W0 = rng.normal(size=(6, H)); b0 = rng.normal(size=H) * 2.0; b0[3] = 160.0; b0[5] = -155.0; b0[7] = 40.0
+    Wx1 = rng.normal(size=6); b1 = 0.3; Wz = np.abs(rng.normal(size=H))
+    with np.errstate(over="ignore"):
+        rec = np.column_stack([W0.T, b0, Wz, np.exp(b0), np.exp(b0) * Wz]).ravel()      # cmad_amd.models.device.unit_records
+        pack = np.concatenate([W0.ravel(), b0, Wx1, [b1], Wz, np.ones(6), np.zeros(6), [1.0, 0.0, 0.0], rec])
+    n = 4000
+    xs = rng.normal(size=(n, 6)) * rng.choice([0.0, 1e-9, 0.3, 3.0, 60.0, 400.0], size=(n, 1))
+    F, G, Hx = np.zeros(n), np.zeros((n, 6)), np.zeros((n, 21))
+    L.hh_icnn_symmetric(vp(pack), C.c_int(H), C.c_int64(n), vp(np.ascontiguousarray(xs)), vp(F), vp(G), vp(Hx))
+    T = np.zeros((n, H))                                                          # the kernel's summation order (the large
+    for i in range(6):                                                            # inputs cancel to O(1) arguments)
+        T = T + xs[:, i:i + 1] * W0[i][None, :]
+    sp = lambda a: np.logaddexp(a, 0.0)
+    with np.errstate(over="ignore"):
+        sg = lambda a: np.where(a >= 0, 1. / (1. + np.exp(-np.abs(a))), np.exp(-np.abs(a)) / (1. + np.exp(-np.abs(a))))
+        Fr = 2 * b1 + ((sp(b0 + T) + sp(b0 - T)) * Wz).sum(1)
+        c1 = (sg(b0 + T) - sg(b0 - T)) * Wz
+        c2 = (sg(b0 + T) * (1 - sg(b0 + T)) + sg(b0 - T) * (1 - sg(b0 - T))) * Wz
+    Gr = c1 @ W0.T
+    Hr = np.einsum("no,io,jo->nij", c2, W0, W0)
+    scale = (np.abs(sp(b0 + T)) + np.abs(sp(b0 - T))) @ Wz + 1.0                   # every term to ~1e-16 of the sum of magnitudes
+    assert (np.abs(F - Fr) <= 4e-15 * scale).all(), (np.abs(F - Fr) / scale).max()
+    gs = (np.abs(W0)[None] * Wz[None, None]).sum(2).max()
+    assert np.abs(G - Gr).max() <= 2e-15 * gs
+    iu = np.triu_indices(6)
+    assert np.abs(Hx - Hr[:, iu[0], iu[1]]).max() <= 2e-15 * max(1.0, np.abs(Hr).max())
 
 
 @pytest.mark.parametrize("rate", [False, True])

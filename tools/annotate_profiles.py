@@ -45,8 +45,13 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
              "code_object": res.get(name), "workload": bench.get("config", {}).get("workload") if isinstance(bench, dict) else None}
     pts = bench.get("config", {}).get("points_per_gpu") if isinstance(bench, dict) else None
     bpu = bench.get("roofline", {}).get("algorithmic_bytes_per_update") if isinstance(bench, dict) else None
+    # a workload whose step is several kernels (work-pool update + tangent / reverse at the stored states): the roofline
+    # fraction of the STEP divides the algorithmic bytes by the sum of their average durations, not by the dominant one's
+    route = {short(k): v["avg_us"] for k, v in kernels.items() if v["calls"] == kv["calls"]}
+    entry["step_kernels_us"] = route
+    step_us = sum(route.values())
     if pts and bpu:
-        entry["algorithmic_GBs_at_kernel_time"] = bpu * pts / (kv["avg_us"] * 1e-6) / 1e9
+        entry["algorithmic_GBs_at_kernel_time"] = bpu * pts / (step_us * 1e-6) / 1e9
         entry["hbm_roof_frac_kernel_only"] = entry["algorithmic_GBs_at_kernel_time"] / 8000.0
         entry["bench_under_trace"] = {k: bench.get(k) for k in ("value", "ms_per_step")}
     c = {}
