@@ -11,6 +11,7 @@ SOLVER_J2_RADIAL_LINE = 1
 SOLVER_GENERAL_NEWTON = 2
 SOLVER_LOCKSTEP = 4
 STATUS_ITERS_MASK, STATUS_CONVERGED, STATUS_PLASTIC, STATUS_SINGULAR = 0xFFFF, 1 << 16, 1 << 17, 1 << 18
+LS_ARMIJO, LS_LEGACY = 0, 1
 CM_OK, CM_ERR_BAD_ARG, CM_ERR_UNSUPPORTED, CM_ERR_LAUNCH, CM_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
 EXPORTS = ["cm_hessians", "cm_hessians_rate", "cm_update_rate_tangent", "cm_update_rate_vjp", "cm_update_rate_and_vjp",
@@ -33,7 +34,7 @@ class ModelDesc(C.Structure):
         ("ls_c1", C.c_double), ("ls_lo", C.c_double), ("ls_hi", C.c_double),
         ("nn_weights", C.c_void_p), ("nn_nlayers", C.c_int32), ("nn_widths", C.c_int32 * 7),
         ("beta_equivalent_stress", C.c_double), ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double),
-        ("beta_max_iters", C.c_int32), ("reserved0", C.c_int32),
+        ("beta_max_iters", C.c_int32), ("ls_kind", C.c_int32),
     ]
 
 

@@ -1419,6 +1419,24 @@ CM_D double quad_min(double phi0, double dphi0, double a, double phi) {
     return (denom == 0.0) ? 0.5 * a : (-dphi0 * a * a / safe);
 }
 
+// One trial of the LEGACY backtracking of newton_solve (cmad/models/nonlinear_solver.py:55-81), shared by every solver form.
+// `phi` = psi_j = ||C||^2 / 2 at the trial just evaluated (step length `alpha`, the n-th evaluation so far counting from 0),
+// `cc` = ||C||^2 at the base iterate (psi_0 = cc / 2, psi_0' = -cc).  Returns 0 when the trial is kept -- accepted,
+// psi_j < (1 - 2 beta alpha) psi_0 (a NaN merit compares false in the reference's `>=` and is kept as well), or the evaluations
+// have run out ("reached max ls evals": the state stays at the last EVALUATED alpha) -- else the increment (alpha_new - alpha)
+// by which the trial moves along the Newton direction (x <- x - increment * delta, as the reference's add_to_xi does), with
+// alpha_new = max(eta alpha, -alpha^2 psi_0' / (2 (psi_j - psi_0 - alpha psi_0'))).  beta = m.ls_c1, eta = m.ls_lo.
+CM_D double ls_trial_legacy(const cm_model_desc& m, double phi, double cc, double& alpha, int& n) {
+    const double psi0 = 0.5 * cc;
+    ++n;
+    if (!(phi >= (1.0 - 2.0 * m.ls_c1 * alpha) * psi0)) return 0.0;
+    const double a_new = fmax(m.ls_lo * alpha, (alpha * alpha * cc) / (2.0 * (phi - psi0 + alpha * cc)));
+    if (n >= m.ls_max_evals) return 0.0;
+    const double inc = a_new - alpha;
+    alpha = a_new;
+    return inc;
+}
+
 // ---- local Newton ------------------------------------------------------------------------------
 // make_newton_solve (cmad/models/nonlinear_solver.py:102-155) with the quadratic Armijo line search
 // of cmad/util/line_search.py:95-189 (ls_max_evals > 0) or the plain Newton of newton_solve
@@ -1477,6 +1495,7 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
 #pragma unroll
                 for (int k = 0; k < NX; ++k) { Cbest[k] = C[k]; Ct[k] = C[k]; }
                 bool ls = true;
+                const bool legacy = (m.ls_kind == CM_LS_LEGACY);      // uniform
                 while (__any(ls)) {
                     if (ls) {
 #pragma unroll
@@ -1484,6 +1503,11 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
                         Eval<DEF> et;
                         residual_mk<MK, DEF, YK, false>(m, eg, z, xt, xp, et, Ct, Ht);
                         const double phi = 0.5 * dot<NX>(Ct, Ct);
+                        if (legacy) {                                  // newton_solve's backtracking: the last evaluated trial is kept
+                            const double a_eval = alpha;
+                            if (ls_trial_legacy(m, phi, cc, alpha, n) == 0.0) { alpha = a_eval; accepted = true; ls = false; }
+                            continue;
+                        }
                         const bool finite = isfinite(phi);
                         if (finite && phi < best_phi) {
                             best_alpha = alpha; best_phi = phi;

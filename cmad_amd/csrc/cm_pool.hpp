@@ -56,7 +56,14 @@ CM_D void newton_pass(const cm_model_desc& m, const double eg[6], const double* 
         } else if (s.phase == CM_PH_ITERATE) {
             at_iterate = true;
         } else if constexpr (LS) {
-            if (s.phase == CM_PH_TRIAL) {
+            if (s.phase == CM_PH_TRIAL && m.ls_kind == CM_LS_LEGACY) {  // uniform: newton_solve's backtracking (ls_trial_legacy)
+                const double step = ls_trial_legacy(m, 0.5 * dot<NX>(C, C), s.cc, s.alpha, s.n);
+                if (step == 0.0) { ++s.it; at_iterate = true; }
+                else {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) x[k] -= step * stage.at(NX + k);
+                }
+            } else if (s.phase == CM_PH_TRIAL) {
                 const double phi = 0.5 * dot<NX>(C, C);                // merit; phi(0) = cc / 2, phi'(0) = -cc
                 const bool finite = isfinite(phi);
                 if (finite && phi < s.best_phi) { s.best_alpha = s.alpha; s.best_phi = phi; }

@@ -116,6 +116,11 @@ CM_D uint32_t ru_newton(const cm_model_desc& m, double dU, const double* xp, dou
                     for (int k = 0; k < NX; ++k) xt[k] = x[k] - alpha * delta[k];
                     ru_eval<YK>(m, dU, xt, xp, Ct, sg);
                     const double phi = 0.5 * dot<NX>(Ct, Ct);
+                    if (m.ls_kind == CM_LS_LEGACY) {                    // newton_solve's backtracking: the last evaluated trial is kept
+                        const double a_eval = alpha;
+                        if (ls_trial_legacy(m, phi, cc, alpha, n) == 0.0) { alpha = a_eval; accepted = true; }
+                        continue;
+                    }
                     const bool finite = isfinite(phi);
                     if (finite && phi < best_phi) { best_alpha = alpha; best_phi = phi; for (int k = 0; k < NX; ++k) Cbest[k] = Ct[k]; }
                     accepted = finite && (phi <= phi0 + alpha * armijo);

@@ -436,7 +436,15 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
         for (;;) {
             if (running && phase != 0) {
                 bool commit = (phase == 2);
-                if (phase == 1) {
+                if (phase == 1 && m.ls_kind == CM_LS_LEGACY) {          // uniform: newton_solve's backtracking (ls_trial_legacy)
+                    const double phi = 0.5 * norm.template sq<NX>(C);
+                    const double step = ls_trial_legacy(m, phi, cc, alpha, n);
+                    if (step == 0.0) commit = true;
+                    else {
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) x[k] -= step * stage.at(NX + k);
+                    }
+                } else if (phase == 1) {
                     const double phi = 0.5 * norm.template sq<NX>(C);            // merit; phi(0) = cc / 2, phi'(0) = -cc
                     const bool finite = isfinite(phi);
                     if (finite && phi < best_phi) { best_alpha = alpha; best_phi = phi; }

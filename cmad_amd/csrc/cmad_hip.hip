@@ -209,10 +209,14 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>
 #ifndef CM_POOL_WAVES_NN
 #define CM_POOL_WAVES_NN 2
 #endif
+// idle lanes that trigger a retire / refill step; measured (profiles/r03_pool_refill_ab.txt): 16 for Hosford (8 and 4 equal within
+// noise, 32: -8 %), 8 for the network surfaces (+3 % over 16; 32: -15 %)
 #ifndef CM_POOL_REFILL
 #define CM_POOL_REFILL 16
 #endif
-constexpr int kPoolRefill = CM_POOL_REFILL;
+#ifndef CM_POOL_REFILL_NN
+#define CM_POOL_REFILL_NN 8
+#endif
 constexpr int kPoolHalf = 32;            // points per staged half (one LDS-DMA instruction moves 4 rows of it in 16-byte pieces)
 
 template <int DEF, int YK>
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NIN = NU + NX;
+    constexpr int kRefill = is_dense_yield(YK) ? CM_POOL_REFILL_NN : CM_POOL_REFILL;
     __shared__ double ring[2 * NIN * kPoolHalf];                 // [half & 1][row][32 points]
     __shared__ double ls_stage[LS ? 2 * NX * 64 : 1];
     const LaneStage stage = lane_stage(ls_stage, LS ? threadIdx.x : 0, 64);
@@ -286,7 +291,15 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
         const uint64_t idle_mask = __ballot(!running);
         const int nidle = __popcll(idle_mask);
         const bool more = cons_half < next_issue;                // uniform: issued points not yet handed out
-        if (nidle == 64 || (more && nidle >= kPoolRefill)) {
+        if (nidle == 64 || (more && nidle >= kRefill)) {
+            // Order matters for what the wave waits on.  (1) Confirm the copies issued at EARLIER steps (a pass or more ago: they
+            // have landed, and so have the stores of the previous retire -- the wait is free), (2) retire, (3) hand out points of
+            // confirmed halves only, (4) issue the copies for the ring slots this step freed.  Nothing waits for a memory
+            // operation issued in this same step (round 3's first version waited vmcnt(0) behind the retire's stores).
+            if (ready < next_issue) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ready = next_issue;
+            }
             if (!running && pt >= 0) {                           // retire: state, stress and status of the finished point
                 Eval<DEF> ev;
                 strain_stress<DEF>(m, eg, z, x, ev);
@@ -312,11 +325,7 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
                 int need = nidle, first = 0, slot = -1;
-                while (need > 0 && cons_half < next_issue) {     // uniform; at most three halves per refill
-                    if (cons_half >= ready) {                    // first use of this half: its copy (and all before it) has landed
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        ready = next_issue;
-                    }
+                while (need > 0 && cons_half < ready) {          // uniform; confirmed halves only (at most two per refill)
                     const int64_t g0 = CM_HALF_BASE(cons_half);
                     const int vc = (B - g0 < kPoolHalf) ? (int)(B - g0) : kPoolHalf;     // >= 1: only halves that start below B are issued
                     const int avail = vc - cons_off;
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
                 CM_TRY_ISSUE()
             }
         }
-        if (!__any(running)) break;                              // nothing running => nothing left (a refill always hands out >= 1 point)
+        if (!__any(running)) break;          // nothing running => nothing left: a step with 64 idle lanes confirms and hands out >= 1 point
         newton_pass<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, st, running, stage);
     }
 #undef CM_TRY_ISSUE
@@ -1136,14 +1145,25 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     return true;
 }
 
-// Combinations the rate-form entry points have no specialisation for (checked at run time BEFORE any launch, so that an entry
-// point never returns CM_OK without having written its outputs): the arithmetic-T / forward-mode kernels of the rate form with a
-// dense yield surface, and the 12-dof UNIAXIAL_STRESS rate form with a dense yield surface.
+// Rate-form model x dense yield surfaces (Barlat, the network surfaces).  Round 3 builds them for every entry point
+// (small_rate_elastic_plastic.py:116-126 takes any effective_stress_fun); -DCM_RATE_DENSE=0 / -DCM_RATE_UNIAXIAL_DENSE=0 leave
+// them out of a build (smaller library), in which case the entry points refuse the combination at run time BEFORE any launch
+// -- an entry point never returns CM_OK without having written its outputs.
+#ifndef CM_RATE_DENSE
+#define CM_RATE_DENSE 1             // reverse / history / direct / second-order / extended-parameter entries
+#endif
+#ifndef CM_RATE_UNIAXIAL_DENSE
+#define CM_RATE_UNIAXIAL_DENSE 1    // the 12-dof UNIAXIAL_STRESS rate form (forward-mode blocks of the arithmetic-T model)
+#endif
+template <int MK, int Y>
+constexpr bool has_rate_dense() { return CM_RATE_DENSE != 0 || !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y)); }
+template <int D, int Y>
+constexpr bool has_rate_uniaxial_dense() { return CM_RATE_UNIAXIAL_DENSE != 0 || !(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y)); }
 inline bool rate_dense(const cm_model_desc* m, int model_kind) {
-    return model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind);
+    return CM_RATE_DENSE == 0 && model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind);
 }
 inline bool rate_uniaxial_dense(const cm_model_desc* m) {
-    return m->def_type == CM_UNIAXIAL_STRESS && is_dense_yield(m->yield_kind);
+    return CM_RATE_UNIAXIAL_DENSE == 0 && m->def_type == CM_UNIAXIAL_STRESS && is_dense_yield(m->yield_kind);
 }
 
 // calls F.template operator()<DEF, YK, ROT>() for the runtime (def_type, yield_kind, rotation) triple
@@ -1214,6 +1234,11 @@ inline int pool_resident_waves(const void* kernel) {
     return cus * per_cu;
 }
 
+// The J2 subspace iterations (newton_j2_line / newton_j2_plane) treat a full step as the Armijo search's first trial; under
+// the legacy backtracking (CM_LS_LEGACY) the acceptance test is another one, so those configurations run the general path.
+static inline bool use_subspace_newton(const cm_model_desc* m) {
+    return !(m->solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m->ls_max_evals > 0 && m->ls_kind == CM_LS_LEGACY);
+}
 // Iteration-bound configurations (the network surfaces, Hosford under the line search: pool_pays<>) run cm_update on the work
 // pool.  The fused entry points below take the same route for them -- work-pool update, then the reverse sweep as a second
 // kernel over the stored states -- instead of the lockstep fused kernel, whose wavefronts wait for their slowest point
@@ -1288,7 +1313,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     }
     const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (has_fast_newton<D, Y, LS>()) {
-            if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+            if (use_subspace_newton(m)) {
                 hipLaunchKernelGGL((k_update<D, Y, R, LS, TANGENT, true>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, dsig, status);
                 return;
             }
@@ -1336,7 +1361,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         static const unsigned dyn_lds = [] { const char* e = getenv("CM_DEBUG_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
         const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (has_fast_newton<D, Y, LS>() && (MODE == 1 || MODE == 3)) {
-                if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                if (use_subspace_newton(m)) {
                     hipLaunchKernelGGL((k_reverse<D, Y, R, LS, MODE, true>), grid, block, dyn_lds, s, md, B, gradu, xi_prev, xi_in, sd, w,
                                        hist_in, xi_out, sigma_out, xpbar, gbar, partials);
                     return;
@@ -1363,7 +1388,7 @@ int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, 
     if (B > 0 && (!gradu || !gradu_prev || !xi_prev || !sd)) return CM_ERR_BAD_ARG;
     if (B > 0 && (MODE == 0 || MODE == 2) && !xi_in) return CM_ERR_BAD_ARG;
     if ((MODE == 1 || MODE == 2) && !wsq6) return CM_ERR_BAD_ARG;
-    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || rate_dense(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || rate_uniaxial_dense(m)) return CM_ERR_UNSUPPORTED;
     if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* partials = (double*)workspace;
@@ -1374,7 +1399,7 @@ int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, 
     if (B > 0) {
         const dim3 grid((unsigned)nb), block(kBlock);
         const bool found = dispatch<true, 2>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (!is_dense_yield(Y))
+            if constexpr (has_rate_dense<CM_SMALL_RATE_ELASTIC_PLASTIC, Y>() && has_rate_uniaxial_dense<D, Y>())
                 hipLaunchKernelGGL((k_reverse_rate<D, Y, R, (MODE == 1 || MODE == 3) ? LS : false, MODE>), grid, block, 0, s, md, B,
                                    gradu, gradu_prev, xi_prev, xi_in, sd, w, hist_in, xi_out, sigma_out, xpbar, gbar, partials);
         });
@@ -1394,7 +1419,7 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
                    int out_offset = 0) {
     if (!m || B < 0 || K < 1 || !out || !workspace || (!wsq6 && !hc.sbar_hist)) return CM_ERR_BAD_ARG;
     if (B > 0 && (!gradu_hist || (!data_hist && !hc.sbar_hist) || !xi0 || !xi_hist)) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind))) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m))) return CM_ERR_UNSUPPORTED;
     if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* partials = (double*)workspace;
@@ -1406,12 +1431,12 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
         const dim3 grid((unsigned)nb), block(kBlock);
         const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<D, Y, LS>()) {
-                if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+                if (use_subspace_newton(m)) {
                     hipLaunchKernelGGL((k_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
                     return;
                 }
             }
-            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))
                 hipLaunchKernelGGL((k_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, data_hist, w, xi0, xi_hist, partials, hc);
         });
         if (!found) return CM_ERR_UNSUPPORTED;
@@ -1427,7 +1452,7 @@ template <int MK>
 int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi0,
                           double* xi_hist, double* sigma_hist, uint32_t* status_hist, void* stream) {
     if (!m || B < 0 || K < 1) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind))) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m))) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu_hist || !xi0 || (!xi_hist && !sigma_hist)) return CM_ERR_BAD_ARG;
     const cm_model_desc md = *m;
@@ -1436,12 +1461,12 @@ int launch_primal_history(const cm_model_desc* m, int64_t B, int K, const double
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true, (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? 2 : 1>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<D, Y, LS>()) {
-            if (!(m->solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+            if (use_subspace_newton(m)) {
                 hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK, true>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
                 return;
             }
         }
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))
             hipLaunchKernelGGL((k_primal_history<D, Y, R, LS, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1452,7 +1477,7 @@ template <int MK>
 int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                        const double* xi, const double* dxp_dp, double* dx_dp, double* ds_dp, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind)))
+    if (!supported(m, MK) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m)))
         return CM_ERR_UNSUPPORTED;                  // never a silent no-op: the dispatch below has no such specialisation
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi || !dx_dp || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
@@ -1461,7 +1486,7 @@ int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, c
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))
             hipLaunchKernelGGL((k_direct_step<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1473,7 +1498,7 @@ int launch_direct_history(const cm_model_desc* m, int64_t B, int K, const double
                           const double* sbar_hist, const double* xibar_hist, double* dx_dp_hist, double* ds_dp_hist,
                           double* grad_p, void* workspace, int64_t wbytes, void* stream) {
     if (!m || B < 0 || K < 1) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind)))
+    if (!supported(m, MK) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m)))
         return CM_ERR_UNSUPPORTED;
     if (grad_p && (!sbar_hist || !workspace)) return CM_ERR_BAD_ARG;
     if (grad_p && wbytes < cm_direct_workspace_bytes(B)) return CM_ERR_WORKSPACE;
@@ -1486,7 +1511,7 @@ int launch_direct_history(const cm_model_desc* m, int64_t B, int K, const double
     if (B > 0) {
         const dim3 grid((unsigned)((B + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || !is_dense_yield(Y))
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))
                 hipLaunchKernelGGL((k_direct_history<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist,
                                    sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist, rows);
         });
@@ -1507,7 +1532,7 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
                     const double* xi_prev, const double* xi,
                     double* d2C, double* d2S, double* dC, double* dS, double* C0, double* S0, void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m))) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     const int nx = cm_num_xi(m), nq = 2 * nx + CM_NUM_PARAMS;
@@ -1517,7 +1542,7 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
     const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y)))
+        if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())))
             hipLaunchKernelGGL((k_hessians<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi,
                                d2C, d2S, dC, dS, C0, S0);
     });
@@ -1530,8 +1555,8 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
                            const double* lam_hist, const double* dx_dp_hist, const double* sbar_hist, const double* hss6,
                            double* out, void* workspace, int64_t wbytes, void* stream) {
     if (!m || B < 0 || K < 1 || !out || !workspace || !hss6) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) ||
-        (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(m->yield_kind)))
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK) ||
+        (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m)))
         return CM_ERR_UNSUPPORTED;
     if (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !dx_dp_hist || !sbar_hist)) return CM_ERR_BAD_ARG;
     if (wbytes < cm_hessian_workspace_bytes(m, B, K)) return CM_ERR_WORKSPACE;
@@ -1548,7 +1573,7 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
         const int64_t nthreads = nps * (int64_t)(nq * (nq + 1) / 2);
         const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y))) {
+            if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))) {
                 hipLaunchKernelGGL((k_hessian_weights<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist, lam_hist,
                                    sbar_hist, h, W);
                 hipLaunchKernelGGL((k_hessian_quadform<nx_of<D, MK>()>), dim3((unsigned)nps), dim3(192), 0, s, B, K, W, dx_dp_hist, part);
@@ -1568,7 +1593,7 @@ template <int MK>
 int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu,
                         const double* gradu_prev, const double* xi_prev, const double* xi, double* dC, double* dS, void* stream) {
     if (!m || B < 0 || n_ep < 0) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m))) return CM_ERR_UNSUPPORTED;
     if (B == 0 || n_ep == 0) return CM_OK;
     if (!ep_index || !gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     const cm_model_desc md = *m;
@@ -1576,7 +1601,7 @@ int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32
     const dim3 grid((unsigned)((B * n_ep + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y)))
+        if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())))
             hipLaunchKernelGGL((k_param_blocks<D, Y, MK>), grid, block, 0, s, md, B, n_ep, ep_index, gradu, gradu_prev, xi_prev, xi, dC, dS);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1588,7 +1613,7 @@ int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n
                                  const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* sbar_hist,
                                  double* grad_ep, void* workspace, int64_t wbytes, void* stream) {
     if (!m || B < 0 || K < 1 || n_ep < 0 || !grad_ep) return CM_ERR_BAD_ARG;
-    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK)) return CM_ERR_UNSUPPORTED;
+    if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m))) return CM_ERR_UNSUPPORTED;
     if (n_ep == 0) return CM_OK;
     if (!workspace || wbytes < (B > 0 ? B : 1) * (int64_t)n_ep * (int64_t)sizeof(double)) return CM_ERR_WORKSPACE;
     if (!ep_index || (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !sbar_hist))) return CM_ERR_BAD_ARG;
@@ -1599,7 +1624,7 @@ int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n
     if (B > 0) {
         const dim3 grid((unsigned)((B * n_ep + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (has_generic_eval(Y) && !(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(Y)))
+            if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())))
                 hipLaunchKernelGGL((k_param_adjoint_history<D, Y, MK>), grid, block, 0, s, md, B, K, n_ep, ep_index, gradu_hist, xi_hist,
                                    lam_hist, sbar_hist, rows);
         });
@@ -1675,7 +1700,7 @@ int cm_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const
     const cm_model_desc md = *m;
     (void)hipGetLastError();
     const bool found = dispatch<true, 2>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y)))
+        if constexpr (has_rate_uniaxial_dense<D, Y>())
         hipLaunchKernelGGL((k_update_rate<D, Y, R, LS, false>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma, nullptr, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1696,7 +1721,7 @@ int cm_update_rate_tangent(const cm_model_desc* m, int64_t B, const double* grad
     const cm_model_desc md = *m;
     (void)hipGetLastError();
     const bool found = dispatch<true, 2>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y)))
+        if constexpr (has_rate_uniaxial_dense<D, Y>())
         hipLaunchKernelGGL((k_update_rate<D, Y, R, LS, true>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, sigma,
                            dsigma_dgradu, status);
     });
@@ -1849,7 +1874,7 @@ int cm_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double*
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y)))
+        if constexpr (has_rate_uniaxial_dense<D, Y>())
         hipLaunchKernelGGL((k_evaluate_rate<D, Y, kColdRot>), grid, block, 0, s, md, B, which, gradu, gradu_prev, xi_prev, xi,
                            C, jac, sigma, dsigma);
     });

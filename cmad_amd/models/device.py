@@ -170,6 +170,14 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     d.ls_c1 = float(ls.get("sufficient decrease", 1e-4))
     d.ls_lo = float(ls.get("min backtrack factor", 0.5))
     d.ls_hi = float(ls.get("max backtrack factor", 0.9))
+    # "kind": "legacy" = the backtracking of the imperative newton_solve(max_ls_evals > 0) (nonlinear_solver.py:55-81), whose
+    # beta = 1e-4 and eta = 0.5 travel in ls_c1 / ls_lo; default: the Armijo search of cmad/util/line_search.py
+    kind = ls.get("kind", "armijo")
+    if kind not in ("armijo", "legacy"):
+        raise ValueError(f"line search kind '{kind}'")
+    d.ls_kind = _lib.LS_LEGACY if kind == "legacy" else _lib.LS_ARMIJO
+    if kind == "legacy":
+        d.ls_c1, d.ls_lo = 1e-4, 0.5
     d.solver_flags = (0 if getattr(newton, "j2_radial_line", True) else _lib.SOLVER_GENERAL_NEWTON) | \
                      (_lib.SOLVER_LOCKSTEP if getattr(newton, "lockstep", False) else 0)
     info = {"elastic_names": names, "lame_jac": J, "yield_type": ytype}

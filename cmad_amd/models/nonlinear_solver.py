@@ -1,9 +1,9 @@
 """Local Newton drivers with the reference's names (/root/reference/cmad/models/nonlinear_solver.py).
 
-* `newton_solve(model, ...)` (:14-85): the imperative solve used by the material-point objectives.  With
-  `max_ls_evals == 0` (the default everywhere in the reference) the whole iteration runs in ONE `cm_update`
-  launch; with the legacy backtracking (`max_ls_evals > 0`) the reference's Python loop is kept, each
-  `model.evaluate()` being a `cm_evaluate` launch.
+* `newton_solve(model, ...)` (:14-85): the imperative solve used by the material-point objectives.  The whole iteration
+  is ONE `cm_update` launch on the gathered state, with plain Newton steps (`max_ls_evals == 0`, the default everywhere in
+  the reference) or with the legacy backtracking of :55-81 (`max_ls_evals > 0`: the kernels' CM_LS_LEGACY line search,
+  include/cmad_hip.h).
 * `make_newton_solve(residual, ...)` (:88-174): returns `solve(xi_prev, params, U, U_prev) -> xi` backed by
   `cm_update` with the quadratic Armijo line search; `residual` must be a bound `Model._residual`.
 """
@@ -16,52 +16,12 @@ from .device import DEFAULT_LINE_SEARCH_SETTINGS, NewtonSettings
 
 def newton_solve(model, max_iters: int = 10, abs_tol: float = 1e-14, rel_tol: float = 1e-14,
                  max_ls_evals: int = 0):
-    if max_ls_evals == 0 and hasattr(model, "device_newton") and getattr(model, "has_device_newton", True):
-        iters, _ = model.device_newton(max_iters, abs_tol, rel_tol)
-        model.seed_none()
-        model.evaluate()
-        return iters, float(np.linalg.norm(model.C()))
-
-    converged = False
-    ii = 0
-    C_norm_0 = 1.
-    C_norm = 0.
-    beta, eta = 1e-4, 0.5
-    while ii < max_iters and not converged:
-        model.seed_none()
-        model.evaluate()
-        Cv = model.C()
-        C_norm = np.linalg.norm(Cv)
-        C_norm_rel = 1. if ii == 0 else C_norm / C_norm_0
-        if ii == 0:
-            C_norm_0 = C_norm
-        if C_norm_rel < rel_tol or C_norm < abs_tol:
-            converged = True
-            break
-        model.seed_xi()
-        model.evaluate()
-        delta_xi = np.linalg.solve(model.Jac(), -Cv)
-        model.add_to_xi(delta_xi)
-        if max_ls_evals > 0:
-            model.seed_none()
-            model.evaluate()
-            psi_0 = 0.5 * C_norm ** 2
-            psi_0_deriv = -2. * psi_0
-            jj = 1
-            alpha_j = 1.
-            psi_j = 0.5 * np.linalg.norm(model.C()) ** 2
-            while psi_j >= ((1. - 2. * beta * alpha_j) * psi_0):
-                alpha_prev = alpha_j
-                alpha_j = max(eta * alpha_j, -(alpha_j ** 2 * psi_0_deriv) / (2. * (psi_j - psi_0 - alpha_j * psi_0_deriv)))
-                if jj == max_ls_evals:
-                    print("reached max ls evals")
-                    break
-                jj += 1
-                model.add_to_xi((alpha_j - alpha_prev) * delta_xi)
-                model.evaluate()
-                psi_j = 0.5 * np.linalg.norm(model.C()) ** 2
-        ii += 1
-    return ii, float(C_norm)
+    """Returns (iterations, norm of the residual at the returned state) like the reference; the state is left in the model."""
+    search = {"max evals": int(max_ls_evals), "kind": "legacy"} if max_ls_evals > 0 else None
+    iters, _ = model.device_newton(max_iters, abs_tol, rel_tol, line_search=search)
+    model.seed_none()
+    model.evaluate()
+    return iters, float(np.linalg.norm(model.C()))
 
 
 def make_newton_solve(residual, max_iters: int = 10, abs_tol: float = 1e-14, rel_tol: float = 1e-14,

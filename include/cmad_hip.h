@@ -73,6 +73,15 @@ enum cm_param_index {
  * stream, same results and reduction order) instead of one lockstep fused kernel; CM_SOLVER_LOCKSTEP keeps the single kernel. */
 #define CM_SOLVER_LOCKSTEP 4
 
+/* Which line search damps the Newton step when ls_max_evals > 0:
+ * CM_LS_ARMIJO   make_newton_solve's search (cmad/util/line_search.py:95-189): quadratic interpolation clipped to
+ *                [ls_lo, ls_hi] alpha, sufficient decrease ls_c1, lowest-merit step when no trial passes;
+ * CM_LS_LEGACY   the backtracking loop of the imperative newton_solve(max_ls_evals > 0) (cmad/models/nonlinear_solver.py:55-81):
+ *                accept when psi_j < (1 - 2 beta alpha_j) psi_0, else alpha_j <- max(eta alpha_j, quadratic minimiser), at most
+ *                ls_max_evals residual evaluations, and the state stays at the last EVALUATED alpha when they run out
+ *                (beta = ls_c1 = 1e-4 and eta = ls_lo = 0.5 in the reference; ls_hi is not used). */
+typedef enum { CM_LS_ARMIJO = 0, CM_LS_LEGACY = 1 } cm_line_search_kind;
+
 /* status word written per point by cm_update* (all optional outputs may be NULL) */
 #define CM_STATUS_ITERS_MASK 0xFFFFu
 #define CM_STATUS_CONVERGED  (1u << 16)
@@ -124,7 +133,7 @@ typedef struct cm_model_desc {
     double  beta_equivalent_stress;
     double  beta_abs_tol, beta_rel_tol;     /* default 1e-14 / 1e-14 */
     int32_t beta_max_iters;                 /* default 10 */
-    int32_t reserved0;
+    int32_t ls_kind;                        /* cm_line_search_kind, read when ls_max_evals > 0 (was reserved0: 0 keeps the Armijo search) */
 } cm_model_desc;
 
 /* library / build info */

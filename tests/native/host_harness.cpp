@@ -48,7 +48,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
             done = true;
         }
         if constexpr (has_fast_newton<DEF, YK, false>()) {          // same choice as launch_update (cmad_hip.hip)
-            if (!done && !g_dense && !(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+            if (!done && !g_dense && (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY))) {
                 st = ls ? newton_any<DEF, YK, true, true, true>(m, eg, z, xp, x, true, stage)
                         : newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
                 done = true;
@@ -127,7 +127,7 @@ static void run_vjp_rate(const cm_model_desc& m, int64_t B, const double* gradu,
                          const double* xi, const double* sbar, const double* xin, double* grad, double* xpbar, double* gbar) {
     constexpr int NX = nx_of<DEF, CM_SMALL_RATE_ELASTIC_PLASTIC>(), NU = Dims<DEF>::NU;
     for (int k = 0; k < CM_NUM_PARAMS; ++k) grad[k] = 0.0;
-    if constexpr (!is_dense_yield(YK)) {
+    if constexpr (true) {
         for (int64_t b = 0; b < B; ++b) {
             double G[NU], xp[NX], x[NX], deg[6], z[Dims<DEF>::NZ], sb[6], sbm[6], pb[CM_NUM_PARAMS], xb[NX], eb[6], xi_in[NX];
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
@@ -271,7 +271,7 @@ template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                          double* d2C, double* d2S, double* dC, double* dS, double* C0 = nullptr, double* S0 = nullptr) {
     constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
-    if constexpr (!(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && is_dense_yield(YK))) {
+    if constexpr (true) {
         for (int64_t pt = 0; pt < B; ++pt) {
             double G[NU], xp[NX], x[NX], oC[NX], oS[6], oCa[NX], oSa[6], oC0[NX], oS0[6];
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt] - (gradu_prev ? gradu_prev[k * B + pt] : 0.0);
@@ -318,7 +318,7 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
         const HostRowsIO io{B, b};
         bool done = false;
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<DEF, YK, false>()) {   // same choice as launch_history
-            if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+            if ((!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY))) {
                 if (ls) history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
                 else history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
                 done = true;
@@ -341,7 +341,7 @@ static void run_primal_history(const cm_model_desc& m, int64_t B, int K, const d
         const HostRowsIO io{B, b};
         bool done = false;
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<DEF, YK, false>()) {
-            if (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON)) {
+            if ((!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY))) {
                 if (ls) primal_history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
                 else primal_history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
                 done = true;
@@ -401,7 +401,7 @@ int hh_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const double*
 #if HH_HAS(2)
 int hh_update_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev, const double* xi_prev,
                    double* xi, double* sigma, uint32_t* status) {
-    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y))) run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_update_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, sigma, status); });
 }
 #endif
 #if HH_HAS(2)
@@ -413,13 +413,13 @@ int hh_vjp_rate(const cm_model_desc* m, int64_t B, const double* gradu, const do
 #if HH_HAS(2)
 int hh_tangent_rate(const cm_model_desc* m, int64_t B, const double* gradu, const double* gradu_prev,
                     const double* xi_prev, const double* xi, double* dsig) {
-    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y))) run_tangent_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, dsig); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_tangent_rate<D, Y, R>(*m, B, gradu, gradu_prev, xi_prev, xi, dsig); });
 }
 #endif
 #if HH_HAS(2)
 int hh_evaluate_rate(const cm_model_desc* m, int64_t B, int which, const double* gradu, const double* gradu_prev,
                      const double* xi_prev, const double* xi, double* C, double* J, double* s, double* S) {
-    return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!(D == CM_UNIAXIAL_STRESS && is_dense_yield(Y))) run_evaluate_rate<D, Y, R>(*m, B, which, gradu, gradu_prev, xi_prev, xi, C, J, s, S); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { run_evaluate_rate<D, Y, R>(*m, B, which, gradu, gradu_prev, xi_prev, xi, C, J, s, S); });
 }
 #endif
 #if HH_HAS(4)
@@ -446,7 +446,7 @@ int hh_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_his
                const double* wsq6, const double* xi0, double* xi_hist, double* out) {
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         return dispatch<true>(m, [&]<int D, int Y, bool R>() {
-            if constexpr (!is_dense_yield(Y)) run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
+            run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() {
         run_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, out); });
 }
@@ -456,7 +456,7 @@ int hh_primal_history(const cm_model_desc* m, int64_t B, int K, const double* gr
                       double* xi_hist, double* sigma_hist, uint32_t* status_hist) {
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         return dispatch<true>(m, [&]<int D, int Y, bool R>() {
-            if constexpr (!is_dense_yield(Y)) run_primal_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
+            run_primal_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() {
         run_primal_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist); });
 }
@@ -479,7 +479,7 @@ int hh_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const
         }
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
@@ -493,7 +493,7 @@ int hh_adjoint_history(const cm_model_desc* m, int64_t B, int K, const double* g
     int rc;
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         rc = dispatch<true>(m, [&]<int D, int Y, bool R>() {
-            if constexpr (!is_dense_yield(Y)) run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, nullptr, wsq0, xi0, xi_hist, out, hc); });
+            run_history<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, nullptr, wsq0, xi0, xi_hist, out, hc); });
     else
         rc = dispatch<true>(m, [&]<int D, int Y, bool R>() {
             run_history<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(*m, B, K, gradu_hist, nullptr, wsq0, xi0, xi_hist, out, hc); });
@@ -514,7 +514,7 @@ int hh_direct_history(const cm_model_desc* m, int64_t B, int K, const double* gr
         }
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
@@ -544,7 +544,7 @@ int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* g
         }
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
@@ -564,7 +564,7 @@ int hh_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* 
         }
     };
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return dispatch<true>(m, [&]<int D, int Y, bool R>() { if constexpr (!is_dense_yield(Y)) body.template operator()<D, Y, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif

