@@ -35,6 +35,7 @@ class ModelDesc(C.Structure):
         ("nn_weights", C.c_void_p), ("nn_nlayers", C.c_int32), ("nn_widths", C.c_int32 * 7),
         ("beta_equivalent_stress", C.c_double), ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double),
         ("beta_max_iters", C.c_int32), ("ls_kind", C.c_int32),
+        ("hnn_width", C.c_int32), ("hnn_offset", C.c_int32),
     ]
 
 
@@ -97,7 +98,7 @@ def lib():
     L.cm_direct_workspace_bytes.argtypes = [i64]; L.cm_direct_workspace_bytes.restype = i64
     L.cm_direct_history.argtypes = [md, i64, C.c_int32, dp, dp, dp, dp, dp, dp, dp, vp, i64, vp]; L.cm_direct_history.restype = C.c_int
     L.cm_hessian_workspace_bytes.argtypes = [md, i64, C.c_int32]; L.cm_hessian_workspace_bytes.restype = i64
-    L.cm_hessian_history.argtypes = [md, i64, C.c_int32, dp, dp, dp, dp, dp, C.POINTER(C.c_double), dp, vp, i64, vp]
+    L.cm_hessian_history.argtypes = [md, i64, C.c_int32, dp, dp, dp, dp, dp, C.POINTER(C.c_double), dp, dp, dp, vp, i64, vp]
     L.cm_hessian_history.restype = C.c_int
     L.cm_param_blocks.argtypes = [md, i64, C.c_int32, vp, dp, dp, dp, dp, dp, dp, vp]; L.cm_param_blocks.restype = C.c_int
     L.cm_param_adjoint_history.argtypes = [md, i64, C.c_int32, C.c_int32, vp, dp, dp, dp, dp, dp, vp, i64, vp]

@@ -874,6 +874,39 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 
 // ---- hardening  cmad/models/hardening.py:9-34 --------------------------------------------------
 struct Hard { double H, dH, expo; };
+// The network hardening law (widths [1, H, 1], include/cmad_hip.h hnn_width): value and derivative of
+//   out_scale * sum_u W2[u] (sigmoid(W1[u] in_scale alpha + b1[u]) - sigmoid(b1[u])).
+// Deliberately NOT inlined on the device: every kernel evaluates the hardening laws inside its Newton loop, and inlining this
+// loop there costs the Voce / linear configurations scalar registers (measured: -4 % on the fused J2 objective and
+// PLANE_STRESS kernels, profiles/r03_hnn_ab.txt).  As a call it is one uniform branch that those configurations never take.
+struct HnnTerm { double H, dH; };
+#if defined(CM_HOST_BUILD)
+inline
+#else
+__device__ __attribute__((noinline))
+#endif
+HnnTerm hardening_network(const double* wv, int Hn, double alpha) {
+#if !defined(CM_HOST_BUILD)
+    // arguments of a real call arrive in vector registers: back to scalars (they are wave-uniform) so that the weights are
+    // read by scalar loads
+    Hn = __builtin_amdgcn_readfirstlane(Hn);
+    const uint64_t a64 = (uint64_t)wv;
+    wv = (const double*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a64 >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a64 & 0xffffffffu)));
+#endif
+    const cm_uniform_ptr w = uniform_ptr(wv);
+    const double si = w[3 * Hn + 1], so = w[3 * Hn + 2];
+    double acc = 0.0, dacc = 0.0;
+    for (int u = 0; u < Hn; ++u) {
+        const double w1 = w[u] * si, b1 = w[Hn + u], w2 = w[2 * Hn + u], sg0 = w[3 * Hn + 3 + u];
+        const double a = __builtin_fma(w1, alpha, b1);
+        const double e = exp_s(-fabs(a)), inv = rcp(1.0 + e);
+        const double sg = (a >= 0.0) ? inv : e * inv;           // sigmoid(a)
+        acc = __builtin_fma(w2, sg - sg0, acc);
+        dacc = __builtin_fma(w2 * w1, sg * (1.0 - sg), dacc);
+    }
+    return HnnTerm{so * acc, so * dacc};
+}
 CM_D Hard hardening(const cm_model_desc& m, double alpha) {
     Hard h; h.H = 0.0; h.dH = 0.0; h.expo = 0.0;
     if (m.has_voce) {
@@ -882,6 +915,14 @@ CM_D Hard hardening(const cm_model_desc& m, double alpha) {
         h.dH += m.voce_S * m.voce_D * h.expo;
     }
     if (m.has_linear) { h.H += m.lin_K * alpha; h.dH += m.lin_K; }
+#ifndef CM_HNN
+#define CM_HNN 1                                                // 0: build without the network hardening law (A/B measurements)
+#endif
+    if (CM_HNN && m.hnn_width > 0) {                            // uniform: the network hardening law, widths [1, H, 1] (cmad_hip.h)
+        const HnnTerm t = hardening_network(m.nn_weights + m.hnn_offset, m.hnn_width, alpha);
+        h.H += t.H;
+        h.dH += t.dH;
+    }
     return h;
 }
 

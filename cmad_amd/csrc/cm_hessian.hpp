@@ -139,6 +139,33 @@ CM_D void softplus_T(const T& a, T& sp, T& sg) {
     sp = pos ? a + l : l;
     sg = pos ? inv : e * inv;
 }
+// the isotropic hardening laws in arithmetic T (cm::hardening; cmad/models/hardening.py:9-34 and the network law of
+// cmad/neural_networks/simple_neural_network.py:13-46, widths [1, H, 1], weights from the nn blob: every weight can carry the
+// derivative direction)
+template <class T>
+CM_D T hardening_T(const cm_model_desc& m, const MatT<T>& p, const T& alpha) {
+    T H = t_const<T>(0.0);
+    if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * alpha)));
+    if (m.has_linear) H = H + p.K * alpha;
+    if (m.hnn_width > 0) {
+        const int Hn = m.hnn_width, o = m.hnn_offset;
+        const double si = p.nn[o + 3 * Hn + 1], so = p.nn[o + 3 * Hn + 2];
+        auto sigmoid = [](const T& a) {
+            const bool pos = t_val(a) > 0.0;
+            const T e = t_exp(pos ? -a : a);
+            const T inv = 1.0 / (1.0 + e);
+            return pos ? inv : e * inv;
+        };
+        T acc = t_const<T>(0.0);
+        for (int u = 0; u < Hn; ++u) {
+            const T w1 = p.nn_at(o + u), b1 = p.nn_at(o + Hn + u), w2 = p.nn_at(o + 2 * Hn + u);
+            acc = acc + w2 * (sigmoid(w1 * (si * alpha) + b1) - sigmoid(b1));
+        }
+        H = H + so * acc;
+    }
+    return H;
+}
+
 template <class T>
 CM_D void icnn_yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& val, T g6[6]) {
     const int H = m.nn_widths[1];
@@ -422,9 +449,7 @@ CM_D void residual_T(const cm_model_desc& m, const MatT<T>& p, const T eg[6], co
     for (int k = 0; k < 6; ++k) { s[k] = twomu * e[k]; if (kDiag[k]) s[k] = s[k] + p.lambda * tr; }
     T phi, gt[6];
     yield_T<YK, T>(m, p, s, phi, gt);
-    T H = T{0.0};
-    if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
-    if (m.has_linear) H = H + p.K * x[6];
+    const T H = hardening_T<T>(m, p, x[6]);
     const T f = (phi - (p.Y + H)) / twomu;
     const T dg = x[6] - xp[6];
     const double fv = t_val(f);
@@ -462,9 +487,7 @@ CM_D void residual_rate_T(const cm_model_desc& m, const MatT<T>& p, const T deg[
     const T twomu = 2.0 * p.mu;
     T phi, gt[6];
     yield_T<YK, T>(m, p, s, phi, gt);
-    T H = T{0.0};
-    if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
-    if (m.has_linear) H = H + p.K * x[6];
+    const T H = hardening_T<T>(m, p, x[6]);
     const T f = (phi - (p.Y + H)) / twomu;
     const T dg = x[6] - xp[6];
     const double fv = t_val(f);
@@ -518,9 +541,7 @@ CM_D void residual_rate_uniaxial_T(const cm_model_desc& m, const MatT<T>& p, con
     const T twomu = 2.0 * p.mu;
     T phi, gt[6];
     yield_T<YK, T>(m, p, s, phi, gt);
-    T H = T{0.0};
-    if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * x[6])));
-    if (m.has_linear) H = H + p.K * x[6];
+    const T H = hardening_T<T>(m, p, x[6]);
     const T f = (phi - (p.Y + H)) / twomu;
     const T dg = x[6] - xp[6];
     const double fv = t_val(f);

@@ -1011,7 +1011,8 @@ __global__ __launch_bounds__(64) void k_direct_history(cm_model_desc m, int64_t 
 template <int DEF, int YK, bool ROT, int MK>
 __global__ __launch_bounds__(64) void k_hessian_weights(cm_model_desc m, int64_t B, int K,
         const double* __restrict__ gradu_hist, const double* __restrict__ xi_hist, const double* __restrict__ lam_hist,
-        const double* __restrict__ sbar_hist, Wsq hss, double* __restrict__ W) {
+        const double* __restrict__ sbar_hist, Wsq hss, const double* __restrict__ hss_hist, const double* __restrict__ hxx_hist,
+        double* __restrict__ W) {
     constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU, NQ = 2 * NX + CM_NUM_PARAMS, NPAIR = NQ * (NQ + 1) / 2;
     const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (tid >= B * K * NPAIR) return;
@@ -1032,7 +1033,12 @@ __global__ __launch_bounds__(64) void k_hessian_weights(cm_model_desc m, int64_t
         lam[k] = lam_hist[((int64_t)step * NX + k) * B + pt];
     }
     for (int r = 0; r < 6; ++r) sbar[r] = sbar_hist[((int64_t)step * 6 + r) * B + pt];
-    const double w = hessian_weight<DEF, YK, ROT, MK>(m, G, x, xp, lam, sbar, hss.w, a, b);
+    // QoI curvature: diagonal in the six stored stress entries (per step when hss_hist is given: UniaxialCalibration's weights
+    // change from step to step) and, for QoIs with an explicit dJ/dxi, diagonal in the state entries of the current step
+    double hs[6];
+    for (int r = 0; r < 6; ++r) hs[r] = hss_hist ? hss_hist[step * 6 + r] : hss.w[r];
+    double w = hessian_weight<DEF, YK, ROT, MK>(m, G, x, xp, lam, sbar, hs, a, b);
+    if (hxx_hist && a == b && a < NX) w += hxx_hist[step * NX + a];
     W[(ps * NQ + a) * NQ + b] = w;
     W[(ps * NQ + b) * NQ + a] = w;
 }
@@ -1136,6 +1142,7 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     if (m->model_kind != model_kind) return false;
     if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS && m->def_type != CM_UNIAXIAL_STRESS) return false;
     if (m->def_type == CM_UNIAXIAL_STRESS && (m->uniaxial_idx < 0 || m->uniaxial_idx > 2)) return false;
+    if (m->hnn_width < 0 || (m->hnn_width > 0 && (!m->nn_weights || m->hnn_offset < 0))) return false;   // network hardening law
     if (m->yield_kind == CM_YIELD_SCALED_HYBRID_HILL_NN && !(m->beta_equivalent_stress > 0.0 && m->beta_max_iters >= 0)) return false;
     if (is_nn_yield(m->yield_kind))                    // one hidden layer [6, H, 1], weights resident on the device
         return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
@@ -1553,8 +1560,9 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
 template <int MK>
 int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi_hist,
                            const double* lam_hist, const double* dx_dp_hist, const double* sbar_hist, const double* hss6,
+                           const double* hss_hist, const double* hxx_hist,
                            double* out, void* workspace, int64_t wbytes, void* stream) {
-    if (!m || B < 0 || K < 1 || !out || !workspace || !hss6) return CM_ERR_BAD_ARG;
+    if (!m || B < 0 || K < 1 || !out || !workspace || (!hss6 && !hss_hist)) return CM_ERR_BAD_ARG;
     if (!supported(m, MK) || !has_generic_eval(m->yield_kind) || rate_dense(m, MK) ||
         (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m)))
         return CM_ERR_UNSUPPORTED;
@@ -1565,7 +1573,7 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
     const int64_t nps = B * (int64_t)K;
     double* W = (double*)workspace;
     double* part = W + nps * nq * nq;
-    Wsq h; for (int k = 0; k < 6; ++k) h.w[k] = hss6[k];
+    Wsq h; for (int k = 0; k < 6; ++k) h.w[k] = hss6 ? hss6[k] : 0.0;
     const cm_model_desc md = *m;
     (void)hipGetLastError();
     hipStream_t s = (hipStream_t)stream;
@@ -1575,7 +1583,7 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))) {
                 hipLaunchKernelGGL((k_hessian_weights<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist, lam_hist,
-                                   sbar_hist, h, W);
+                                   sbar_hist, h, hss_hist, hxx_hist, W);
                 hipLaunchKernelGGL((k_hessian_quadform<nx_of<D, MK>()>), dim3((unsigned)nps), dim3(192), 0, s, B, K, W, dx_dp_hist, part);
             }
         });
@@ -1646,7 +1654,7 @@ int cmi_objective_from_state(const cm_model_desc* m, int64_t B, const double* gr
 
 
 #if CM_HAS_PART(1)
-int cm_abi_version(void) { return 4; }
+int cm_abi_version(void) { return 5; }
 #endif
 
 #if CM_HAS_PART(1)
@@ -1797,13 +1805,14 @@ int cm_direct_history(const cm_model_desc* m, int64_t B, int32_t K, const double
 #if CM_HAS_PART(6)
 int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K, const double* gradu_hist, const double* xi_hist,
                        const double* lam_hist, const double* dxi_dp_hist, const double* sigma_bar_hist, const double* hss6,
+                       const double* hss_hist, const double* hxx_hist,
                        double* hess_pp, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!m) return CM_ERR_BAD_ARG;
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
         return launch_hessian_history<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi_hist, lam_hist, dxi_dp_hist,
-                                                                     sigma_bar_hist, hss6, hess_pp, workspace, workspace_bytes, stream);
+                                                                     sigma_bar_hist, hss6, hss_hist, hxx_hist, hess_pp, workspace, workspace_bytes, stream);
     return launch_hessian_history<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sigma_bar_hist,
-                                                            hss6, hess_pp, workspace, workspace_bytes, stream);
+                                                            hss6, hss_hist, hxx_hist, hess_pp, workspace, workspace_bytes, stream);
 }
 #endif
 

@@ -113,8 +113,12 @@ class ScaledHybridHillEffectiveStress(HybridHillEffectiveStress):
 
 
 def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, uniaxial_stress_idx=0,
-               newton: NewtonSettings | None = None, effective_stress_type: str | None = None, hybrid=None):
+               newton: NewtonSettings | None = None, effective_stress_type: str | None = None, hybrid=None,
+               hardening_nn=None):
     """Flatten a CMAD parameter tree into a `cm_model_desc`.
+
+    hardening_nn: (input_scale, output_scale) of the `SimpleNeuralNetwork` whose parameters sit under
+    params["plastic"]["flow stress"]["hardening"]["neural network"] (the model extracts them from hardening_funs).
 
     Returns (desc, info) where info carries what the sensitivity mapping needs:
     elastic names and d(lambda, mu)/d(elastic pair)."""
@@ -143,8 +147,10 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     d.Y = float(fs["initial yield"]["Y"])
     hard = fs.get("hardening", {}) or {}
     for k in hard:
-        if k not in ("voce", "linear"):
+        if k not in ("voce", "linear", "neural network"):
             raise NotImplementedError(f"hardening '{k}'")
+    if "neural network" in hard and hardening_nn is None:
+        raise KeyError("hardening 'neural network' needs hardening_funs={'neural network': SimpleNeuralNetwork(...).evaluate}")
     d.has_voce = int("voce" in hard)
     d.has_linear = int("linear" in hard)
     if d.has_voce:
@@ -189,6 +195,14 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
         info["yield_type"] = "hybrid"
         info["nn_widths"] = [int(w) for w in widths]
         info["nn_packed"] = np.ascontiguousarray(packed, dtype=np.float64)   # the caller places it and sets d.nn_weights
+    if "neural network" in hard:
+        # the hardening network travels in the same device buffer, after the yield network's pack (if any)
+        from ..neural_networks.simple_neural_network import pack_hardening_network
+        Hn, hpack = pack_hardening_network(hard["neural network"], *hardening_nn)
+        base = info.get("nn_packed", np.zeros(0))
+        d.hnn_width, d.hnn_offset = int(Hn), int(base.size)
+        info["hnn"] = (int(Hn), int(base.size))
+        info["nn_packed"] = np.ascontiguousarray(np.concatenate([base, hpack]), dtype=np.float64)
     return d, info
 
 
@@ -238,6 +252,15 @@ def leaf_ep_index(path, info):
         flat = idx[0] if len(idx) == 1 else 3 * idx[0] + idx[1]
         return EP_Q0 + int(flat)
     names = [k for k in path if isinstance(k, str)]
+    if "hardening" in names and "neural network" in names:
+        # [1, H, 1] hardening network in the nn buffer at info["hnn"] = (H, offset): W1[H], b1[H], W2[H], b2
+        Hn, off = info["hnn"]
+        ints = [k for k in path if isinstance(k, (int, np.integer))]
+        layer, elem = int(ints[0]), (int(ints[-1]) if len(ints) > 1 else 0)
+        what = names[-1]
+        if layer == 0:
+            return EP_NN0 + off + (elem if what == "weights" else Hn + elem)
+        return EP_NN0 + off + (2 * Hn + elem if what == "weights" else 3 * Hn)
     if "neural network" in names:
         widths = info.get("nn_widths")
         if widths is None or len(widths) != 3:
@@ -597,8 +620,10 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_direct_history")
         return g, dx, ds
 
-    def hessian_history(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sigma_bar_hist, hss6):
-        """`cm_hessian_history`: d2J/dp2 (12, 12) device tensor, KP order, summed over the batch and the steps."""
+    def hessian_history(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sigma_bar_hist, hss, hxx=None):
+        """`cm_hessian_history`: d2J/dp2 (12, 12) device tensor, KP order, summed over the batch and the steps.
+        `hss`: the QoI's diagonal stress curvature, (6,) constant in time or (K+1, 6) per step; `hxx`: (K+1, n_xi) diagonal
+        curvature in the state entries of a QoI with an explicit dJ/dxi, or None."""
         torch = _torch()
         K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
         NP = _lib.CM_NUM_PARAMS
@@ -614,9 +639,21 @@ class DeviceEvaluator:
         if need < 0:
             _lib.check(int(need), "cm_hessian_workspace_bytes")
         ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
-        h = (C.c_double * 6)(*[float(v) for v in hss6])
+        hss = np.asarray(hss, dtype=np.float64)
+        h6, hs_dev, hx_dev = None, None, None
+        if hss.ndim == 1:
+            h6 = (C.c_double * 6)(*[float(v) for v in hss])
+        else:
+            if hss.shape != (K + 1, 6):
+                raise ValueError(f"hss: expected (6,) or ({K + 1}, 6)")
+            hs_dev = torch.from_numpy(np.ascontiguousarray(hss)).to(dev)
+        if hxx is not None:
+            hxx = np.asarray(hxx, dtype=np.float64)
+            if hxx.shape != (K + 1, self.nx):
+                raise ValueError(f"hxx: expected ({K + 1}, {self.nx})")
+            hx_dev = torch.from_numpy(np.ascontiguousarray(hxx)).to(dev)
         rc = self.L.cm_hessian_history(C.byref(self.desc), B, K, _ptr(gradu_hist), _ptr(xi_hist), _ptr(lam_hist), _ptr(dxi_dp_hist),
-                                       _ptr(sigma_bar_hist), h, _ptr(H), _ptr(ws), need, self._stream())
+                                       _ptr(sigma_bar_hist), h6, _ptr(hs_dev), _ptr(hx_dev), _ptr(H), _ptr(ws), need, self._stream())
         _lib.check(rc, "cm_hessian_history")
         return H
 

@@ -45,45 +45,32 @@ class ElasticConstants:
 
     @classmethod
     def from_params(cls, elastic: dict) -> "ElasticConstants":
-        given = tuple(n for n in _CONSTANT_NAMES if n in elastic)
-        if len(given) != 2:
-            raise ValueError(f"ElasticConstants needs exactly two of {_CONSTANT_NAMES}; got {given}")
-        pair = frozenset(given)
-        if pair == frozenset(("lambda", "mu")):
-            lmbda, mu = elastic["lambda"], elastic["mu"]
-        elif pair == frozenset(("E", "nu")):
-            E, nu = elastic["E"], elastic["nu"]
-            lmbda, mu = compute_lambda(E, nu), compute_mu(E, nu)
-        elif pair == frozenset(("mu", "kappa")):
-            mu, kappa = elastic["mu"], elastic["kappa"]
-            lmbda = kappa - 2. * mu / 3.
-        elif pair == frozenset(("E", "mu")):
-            E, mu = elastic["E"], elastic["mu"]
-            lmbda = mu * (E - 2. * mu) / (3. * mu - E)
-        elif pair == frozenset(("E", "kappa")):
-            E, kappa = elastic["E"], elastic["kappa"]
-            mu = 3. * kappa * E / (9. * kappa - E)
-            lmbda = 3. * kappa * (3. * kappa - E) / (9. * kappa - E)
-        elif pair == frozenset(("mu", "nu")):
-            mu, nu = elastic["mu"], elastic["nu"]
-            lmbda = 2. * mu * nu / (1. - 2. * nu)
-        elif pair == frozenset(("kappa", "nu")):
-            kappa, nu = elastic["kappa"], elastic["nu"]
-            mu = 3. * kappa * (1. - 2. * nu) / (2. * (1. + nu))
-            lmbda = 3. * kappa * nu / (1. + nu)
-        elif pair == frozenset(("lambda", "nu")):
-            lmbda, nu = elastic["lambda"], elastic["nu"]
-            mu = lmbda * (1. - 2. * nu) / (2. * nu)
-        elif pair == frozenset(("lambda", "kappa")):
-            lmbda, kappa = elastic["lambda"], elastic["kappa"]
-            mu = 3. * (kappa - lmbda) / 2.
-        elif pair == frozenset(("E", "lambda")):
-            E, lmbda = elastic["E"], elastic["lambda"]
-            R = _sqrt(E ** 2 + 9. * lmbda ** 2 + 2. * E * lmbda)
-            mu = (E - 3. * lmbda + R) / 4.
-        else:
-            raise ValueError(f"unsupported elastic-constant pair: {given}")
+        """Any two of {E, nu, mu, kappa, lambda} -> the Lame pair, by table lookup (`_TO_LAME`)."""
+        names = sorted(n for n in _CONSTANT_NAMES if n in elastic)
+        if len(names) != 2:
+            raise ValueError(f"ElasticConstants needs exactly two of {_CONSTANT_NAMES}; got {tuple(names)}")
+        lmbda, mu = _TO_LAME[tuple(names)](elastic[names[0]], elastic[names[1]])
         return cls(lmbda=lmbda, mu=mu)
+
+
+def _from_E_lambda(E, lam):
+    root = _sqrt(E * E + 9. * lam * lam + 2. * E * lam)         # the one pair that needs a quadratic root
+    return lam, (E - 3. * lam + root) / 4.
+
+
+# (first, second) in alphabetical order of the names -> (lambda, mu); the textbook conversions between isotropic constants
+_TO_LAME = {
+    ("E", "nu"): lambda E, nu: (compute_lambda(E, nu), compute_mu(E, nu)),
+    ("E", "mu"): lambda E, mu: (mu * (E - 2. * mu) / (3. * mu - E), mu),
+    ("E", "kappa"): lambda E, k: (3. * k * (3. * k - E) / (9. * k - E), 3. * k * E / (9. * k - E)),
+    ("E", "lambda"): _from_E_lambda,
+    ("lambda", "mu"): lambda lam, mu: (lam, mu),
+    ("kappa", "mu"): lambda k, mu: (k - 2. * mu / 3., mu),
+    ("mu", "nu"): lambda mu, nu: (2. * mu * nu / (1. - 2. * nu), mu),
+    ("kappa", "nu"): lambda k, nu: (3. * k * nu / (1. + nu), 3. * k * (1. - 2. * nu) / (2. * (1. + nu))),
+    ("lambda", "nu"): lambda lam, nu: (lam, lam * (1. - 2. * nu) / (2. * nu)),
+    ("kappa", "lambda"): lambda k, lam: (lam, 3. * (k - lam) / 2.),
+}
 
 
 class _D2:

@@ -61,9 +61,9 @@ class HistoryEngine:
                                            None if xibar_hist is None else self._dev(xibar_hist), want_blocks=want_blocks)
         return g.cpu().numpy(), (dx.cpu().numpy() if want_blocks else None)
 
-    def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss6):
+    def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss, hxx=None):
         H = self._ev.hessian_history(self._dev(gradu_hist, "g"), self._dev(xi_hist), self._dev(lam_hist), self._dev(dxi_dp_hist),
-                                     self._dev(sbar_hist), hss6)
+                                     self._dev(sbar_hist), hss, hxx)
         return H.cpu().numpy()
 
     def extended(self, ep_index, gradu_hist, xi_hist, lam_hist, sbar_hist):

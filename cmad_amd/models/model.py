@@ -52,6 +52,7 @@ class Model(ABC):
     _yield_tol: float = 1e-14
     _uniaxial_stress_idx: int = 0
     _hybrid = None                       # HybridHillEffectiveStress or None
+    _hardening_nn = None                 # (input_scale, output_scale) of the network hardening law, or None
 
     @classmethod
     def from_deck(cls, model_section: dict, parameters: Parameters, def_type: int) -> "Model":
@@ -76,7 +77,7 @@ class Model(ABC):
         return build_desc(self.parameters.values if params is None else params, def_type=self._def_type,
                           model_kind=self._model_kind, yield_tol=self._yield_tol,
                           uniaxial_stress_idx=self._uniaxial_stress_idx, newton=newton or self.newton_settings,
-                          hybrid=self._hybrid)
+                          hybrid=self._hybrid, hardening_nn=self._hardening_nn)
 
     def device_evaluator(self, newton: NewtonSettings | None = None) -> DeviceEvaluator:
         """A `DeviceEvaluator` for the CURRENT parameter values (rebuilt per call: parameters change between

@@ -17,8 +17,8 @@ from .var_types import VarType, get_num_eqs
 
 
 class SmallElasticPlastic(Model):
-    """Elastic: isotropic linear elasticity.  Plastic: J2 / Hill / Hosford effective stress, Voce and/or
-    linear isotropic hardening."""
+    """Elastic: isotropic linear elasticity.  Plastic: J2 / Hill / Hosford / Barlat / hybrid Hill + network effective stress;
+    Voce, linear and / or neural-network isotropic hardening."""
 
     supports_mixed: ClassVar[bool] = True
     registry_name: ClassVar[str] = "small_elastic_plastic"     # reference :94
@@ -29,9 +29,13 @@ class SmallElasticPlastic(Model):
         from .device import HybridHillEffectiveStress
         if isinstance(effective_stress_fun, HybridHillEffectiveStress):
             self._hybrid, effective_stress_fun = effective_stress_fun, None
-        if elastic_stress_fun is not None or effective_stress_fun is not None or hardening_funs is not None:
+        if hardening_funs is not None:
+            # {"neural network": SimpleNeuralNetwork(...).evaluate} (reference :115, examples/noisy_calibration.py:245-252)
+            from ..neural_networks.simple_neural_network import hardening_network_scales
+            self._hardening_nn = hardening_network_scales(hardening_funs)
+        if elastic_stress_fun is not None or effective_stress_fun is not None:
             # the reference lets callers inject JAX callables (:112-115); the HIP path has a fixed kernel menu
-            raise NotImplementedError("custom elastic/effective-stress/hardening callables have no HIP kernel; "
+            raise NotImplementedError("custom elastic / effective-stress callables have no HIP kernel; "
                                       "select the yield surface through params['plastic']['effective stress']")
         self._is_complex = is_complex
         self.dtype = complex if is_complex else float

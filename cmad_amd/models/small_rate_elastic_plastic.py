@@ -34,8 +34,12 @@ class SmallRateElasticPlastic(Model):
     def __init__(self, parameters: Parameters, def_type: int = DefType.FULL_3D,
                  elastic_stress_fun=None, effective_stress_fun=None, hardening_funs=None,
                  yield_tol: float = 1e-14, uniaxial_stress_idx: int = 0, is_complex: bool = False) -> None:
-        if elastic_stress_fun is not None or effective_stress_fun is not None or hardening_funs is not None:
-            raise NotImplementedError("custom elastic/effective-stress/hardening callables have no HIP kernel")
+        if hardening_funs is not None:
+            # {"neural network": SimpleNeuralNetwork(...).evaluate}: the reference's examples/noisy_calibration.py:245-252
+            from ..neural_networks.simple_neural_network import hardening_network_scales
+            self._hardening_nn = hardening_network_scales(hardening_funs)
+        if elastic_stress_fun is not None or effective_stress_fun is not None:
+            raise NotImplementedError("custom elastic / effective-stress callables have no HIP kernel")
         self._is_complex = is_complex
         self.dtype = complex if is_complex else float
         self._def_type = int(def_type)

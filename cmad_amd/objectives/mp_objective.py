@@ -111,20 +111,20 @@ class MPDirectAdjointObjective(MPObjective):
 
         d2J/dp2 = sum_k D_k^T ( d2J_k/dq2 - sum_r lam_k[r] d2C_k[r]/dq2 ) D_k
 
-    evaluated per step on the device (`cm_hessian_history`)."""
+    evaluated per step on the device (`cm_hessian_history`).  The QoI supplies its own first derivatives (dJ/dsigma, explicit
+    dJ/dxi) and its diagonal curvatures in the stress and in the state (`stress_curvature`, `state_curvature`), so QoIs with
+    an explicit state term (UniaxialCalibration) take the second-order pass too (reference cmad/qois/qoi.py:47-57)."""
 
     def _evaluate(self, engine) -> HessianResult:
         qoi, model = self._qoi, self._model
-        hss6 = qoi.stress_curvature()
+        hss, hxx = qoi.stress_curvature(), qoi.state_curvature()
         xi0, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
-        if xibar is not None:
-            raise NotImplementedError("the second-order pass takes QoIs of the stress only")
         if model.extended_active(engine.info):
             raise NotImplementedError("second-order sensitivities cover the 12 native parameters (no rotation matrix, Hosford "
                                       "exponent, network-surface coefficients or weights)")
-        g_kp, lam_hist = engine.adjoint(self._gradu_hist, sbar, xi0, want_lam=True)
-        _, dxi_dp_hist = engine.direct(self._gradu_hist, xi_hist, sbar, want_blocks=True)
-        H_kp = engine.hessian(self._gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar, hss6)
+        g_kp, lam_hist = engine.adjoint(self._gradu_hist, sbar, xi0, xibar, want_lam=True)
+        _, dxi_dp_hist = engine.direct(self._gradu_hist, xi_hist, sbar, xibar, want_blocks=True)
+        H_kp = engine.hessian(self._gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar, hss, hxx)
         grad, native_grad = self._canonical_gradient(g_kp, engine.info)
         hessian = model.active_hessian_from_kp(H_kp, g_kp, engine.info)
         hessian = 0.5 * (hessian + hessian.T)

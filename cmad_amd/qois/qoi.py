@@ -44,8 +44,12 @@ class QoI(ABC):
         raise NotImplementedError
 
     def stress_curvature(self):
-        """Diagonal d2J_k/dsigma_r^2 over the 6 stored entries (constant in time), for the second-order pass."""
+        """Diagonal d2J_k/dsigma_r^2 over the 6 stored entries, (6,) constant in time or (K+1, 6) per step, for the second-order pass."""
         raise NotImplementedError("this QoI has no second-order pass")
+
+    def state_curvature(self):
+        """Diagonal d2J_k/dxi_i^2 per step, (K+1, n_xi), of a QoI with an explicit dJ/dxi; None for QoIs of the stress only."""
+        return None
 
     def fused_calibration(self):
         """(wsq6, data6_hist (K+1, 6, 1), constant) when the QoI is the weighted stress mismatch the kernels fuse

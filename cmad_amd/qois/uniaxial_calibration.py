@@ -54,6 +54,24 @@ class UniaxialCalibration(QoI):
         xibar[:, off + 1, :] = cot[:, 2, :]
         return J, sbar, xibar
 
+    def stress_curvature(self):
+        """d2J_k/dsigma_aa^2 = w_0k^2 per step (the weights change from step to step): (K+1, 6)."""
+        w = np.asarray(self._weight, dtype=np.float64)
+        h = np.zeros((w.shape[1], 6))
+        h[:, (0, 3, 5)[self._idx]] = w[0] ** 2
+        h[0] = 0.0
+        return h
+
+    def state_curvature(self):
+        """d2J_k/d(stretch_i)^2 = w_ik^2 at the two lateral-stretch entries of the state: (K+1, n_xi)."""
+        w = np.asarray(self._weight, dtype=np.float64)
+        off = self._model.delta_xi_offset(self._svar, 0)
+        h = np.zeros((w.shape[1], self._model.num_dofs))
+        h[:, off] = w[1] ** 2
+        h[:, off + 1] = w[2] ** 2
+        h[0] = 0.0
+        return h
+
     def evaluate(self, step) -> None:
         """reference qoi.py:80-110 with `_qoi` of uniaxial_calibration.py:70-85."""
         model = self._model

@@ -134,10 +134,20 @@ typedef struct cm_model_desc {
     double  beta_abs_tol, beta_rel_tol;     /* default 1e-14 / 1e-14 */
     int32_t beta_max_iters;                 /* default 10 */
     int32_t ls_kind;                        /* cm_line_search_kind, read when ls_max_evals > 0 (was reserved0: 0 keeps the Armijo search) */
+    /* neural-network hardening law: hardening_funs = {"neural network": SimpleNeuralNetwork(...).evaluate}
+     * (cmad/neural_networks/simple_neural_network.py:13-46 through cmad/models/small_elastic_plastic.py:115,
+     * cmad/models/hardening.py:27-34), layer widths [1, H, 1], sigmoid hidden units:
+     *   H(alpha) = out_scale * (forward(in_scale * alpha) - forward(0)),  forward(x) = sum_u W2[u] sigmoid(W1[u] x + b1[u]) + b2.
+     * hnn_width = H (0: no such law).  The weights sit in the nn_weights buffer at doubles offset hnn_offset:
+     *   W1[H], b1[H], W2[H], b2, in_scale, out_scale, then sigmoid(b1[u]) for u < H (table for the kernels).
+     * Added to the Voce / linear terms when those are present as well. */
+    int32_t hnn_width;
+    int32_t hnn_offset;
 } cm_model_desc;
 
 /* library / build info */
-int  cm_abi_version(void);                       /* 4: + cm_adjoint_history, cm_direct_history, cm_hessian_history */
+int  cm_abi_version(void);                       /* 5: cm_model_desc.ls_kind (CM_LS_LEGACY), hnn_width / hnn_offset (network hardening); cm_hessian_history takes per-step stress curvature and
+                                                  * a state curvature; nn_weights layout carries the per-unit records */
 const char* cm_last_hip_error(void);             /* name of the last HIP error behind a CM_ERR_LAUNCH */
 int  cm_sizeof_model_desc(void);                 /* sizeof(cm_model_desc) as compiled, for binding checks */
 int  cm_num_xi(const cm_model_desc* m);          /* local dofs per point, <0 if unsupported */
@@ -412,18 +422,23 @@ int cm_direct_history(const cm_model_desc* m, int64_t B, int32_t K,
  * With q = [xi_k, xi_{k-1}, p] and D_k = dq/dp = [dxi_k/dp ; dxi_{k-1}/dp ; I]:
  *     hess_pp = sum_b sum_k D_k^T W_k D_k ,
  *     W_k[a][b] = sigma_bar_k . d2sigma/dq_a dq_b + sum_r hss_r dsigma_r/dq_a dsigma_r/dq_b - lam_k . d2C_k/dq_a dq_b
- * (the reference's 13 einsum terms are the blocks of this one quadratic form).  hss6[6] (HOST) is the diagonal
- * d2J_k/dsigma_r^2 of the QoI in the 6 stored entries (Calibration: the folded squared weights, as wsq6).
+ * (the reference's 13 einsum terms are the blocks of this one quadratic form).  The QoI enters through sigma_bar (its
+ * first derivative), through the diagonal d2J_k/dsigma_r^2 in the 6 stored entries -- hss6[6] (HOST; constant in time,
+ * Calibration: the folded squared weights, as wsq6) or hss_hist[(K+1)][6] (DEVICE, per step; takes precedence; slot 0
+ * unused) -- and, for a QoI with an explicit dJ/dxi (UniaxialCalibration's lateral stretches,
+ * cmad/qois/uniaxial_calibration.py:70-85, differentiated there by hessian(qoi_fun), cmad/qois/qoi.py:47-57), through the
+ * diagonal d2J_k/dxi_i^2 of the current step's state, hxx_hist[(K+1)][n_xi] (DEVICE, may be NULL), which is added to W_k[i][i].
+ * lam_hist must then come from cm_adjoint_history with the QoI's xi_bar_hist.
  *   in : gradu_hist, xi_hist (converged), lam_hist (cm_adjoint_history), dxi_dp_hist (cm_direct_history), sigma_bar_hist
  *   out: hess_pp[CM_NUM_PARAMS * CM_NUM_PARAMS] row-major, KP order
  *   workspace: cm_hessian_workspace_bytes(m, B, K)
- * Every yield surface; both model kinds (rate form: FULL_3D, PLANE_STRESS, J2 / Hill / Hosford).
+ * Every yield surface; both model kinds.
  */
 int64_t cm_hessian_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K);
 int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K,
                        const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* dxi_dp_hist,
-                       const double* sigma_bar_hist, const double* hss6, double* hess_pp,
-                       void* workspace, int64_t workspace_bytes, void* stream);
+                       const double* sigma_bar_hist, const double* hss6, const double* hss_hist, const double* hxx_hist,
+                       double* hess_pp, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Extended parameter sensitivities.  The hand-derived kernels differentiate w.r.t. the 12 native parameters of

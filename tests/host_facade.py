@@ -34,8 +34,8 @@ class HostHistoryEngine:
         g, dx, _ = hh.direct_history(self._desc, gradu_hist, xi_hist, sbar_hist, xibar_hist, want_blocks=want_blocks)
         return g, dx
 
-    def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss6):
-        return hh.hessian_history(self._desc, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss6)
+    def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss, hxx=None):
+        return hh.hessian_history(self._desc, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss, hxx)
 
     def extended(self, ep_index, gradu_hist, xi_hist, lam_hist, sbar_hist):
         K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
@@ -51,6 +51,12 @@ class HostHistoryEngine:
 class HostSmallElasticPlastic(SmallElasticPlastic):
     def history_engine(self, newton=None):
         return HostHistoryEngine(self, newton)
+
+    def _desc(self, params=None, newton=None):
+        desc, info = super()._desc(params, newton)
+        if "nn_packed" in info:                          # the host build reads the network weights from host memory (info keeps them alive)
+            desc.nn_weights = info["nn_packed"].ctypes.data
+        return desc, info
 
     def _point_evaluate(self, which, xi, xi_prev, params, U, want_jac=True, U_prev=None):
         desc, info = self._desc(params)

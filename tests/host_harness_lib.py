@@ -158,17 +158,19 @@ def direct_history(desc, gradu_hist, xi_hist, sbar_hist=None, xibar_hist=None, w
     return grad, dx, ds
 
 
-def hessian_history(desc, gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss6):
+def hessian_history(desc, gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss, hxx=None):
     """cm_hessian_history on the host build: stage 1 (W per point and step) by cm::hessian_weight, the quadratic form
     sum D^T W D in numpy.  Returns hess (12, 12), KP order."""
     L = lib()
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-    gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss6 = map(c, (gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss6))
+    gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss = map(c, (gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, hss))
+    hxx = None if hxx is None else c(hxx)
     K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
     nq = 2 * nx + 12
     W = np.zeros((K, B, nq, nq))
+    hss6, hss_hist = (hss, None) if hss.ndim == 1 else (None, hss)            # (6,) constant or (K+1, 6) per step
     rc = L.hh_hessian_weights(C.byref(desc), C.c_int64(B), C.c_int(K), _p(gradu_hist), _p(xi_hist), _p(lam_hist), _p(sbar_hist),
-                              _p(hss6), _p(W))
+                              _p(hss6), _p(hss_hist), _p(hxx), _p(W))
     assert rc == 0
     H = np.zeros((12, 12))
     for k in range(1, K + 1):

@@ -521,7 +521,8 @@ int hh_direct_history(const cm_model_desc* m, int64_t B, int K, const double* gr
 #if HH_HAS(4)
 // stage 1 of cm_hessian_history: W[(step-1)*B + pt][NQ][NQ] (cm::hessian_weight per pair)
 int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* gradu_hist, const double* xi_hist,
-                       const double* lam_hist, const double* sbar_hist, const double* hss6, double* W) {
+                       const double* lam_hist, const double* sbar_hist, const double* hss6, const double* hss_hist,
+                       const double* hxx_hist, double* W) {
     auto body = [&]<int D, int Y, bool R, int MK>() {
         constexpr int NX = nx_of<D, MK>(), NU = Dims<D>::NU, NQ = 2 * NX + CM_NUM_PARAMS;
         for (int step = 1; step <= K; ++step) for (int64_t pt = 0; pt < B; ++pt) {
@@ -537,8 +538,11 @@ int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* g
             }
             for (int r = 0; r < 6; ++r) sbar[r] = sbar_hist[((int64_t)step * 6 + r) * B + pt];
             const int64_t ps = (int64_t)(step - 1) * B + pt;
+            double hs[6];                       // as k_hessian_weights: per-step stress curvature, state curvature on the diagonal
+            for (int r = 0; r < 6; ++r) hs[r] = hss_hist ? hss_hist[step * 6 + r] : hss6[r];
             for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
-                const double w = hessian_weight<D, Y, true, MK>(*m, G, x, xp, lam, sbar, hss6, a, b);
+                double w = hessian_weight<D, Y, true, MK>(*m, G, x, xp, lam, sbar, hs, a, b);
+                if (hxx_hist && a == b && a < NX) w += hxx_hist[step * NX + a];
                 W[(ps * NQ + a) * NQ + b] = w; W[(ps * NQ + b) * NQ + a] = w;
             }
         }

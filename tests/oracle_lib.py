@@ -37,7 +37,8 @@ class Desc(C.Structure):
                 ("uniaxial_idx", C.c_int), ("hardening_order", C.c_int), ("yield_tol", C.c_double),
                 ("nn_nlayers", C.c_int), ("nn_widths", C.c_int * 8), ("nn_w", C.POINTER(C.c_double)),
                 ("beta_equivalent_stress", C.c_double), ("beta_max_iters", C.c_int),
-                ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double), ("barlat", C.c_double * 19)]
+                ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double), ("barlat", C.c_double * 19),
+                ("hnn_width", C.c_int), ("hnn_w", C.POINTER(C.c_double))]
 
 
 class Newton(C.Structure):
@@ -165,9 +166,11 @@ class Material:
     """
 
     def __init__(self, values, def_type=FULL_3D, model_kind=SMALL_EP, yield_tol=1e-14, uniaxial_idx=0,
-                 nn=None, scaled=None):
+                 nn=None, scaled=None, hardening_nn=None):
         """nn = (layer_widths, packed weights) selects the hybrid Hill + ICNN surface; scaled = (equivalent_stress,
-        max_iters, abs_tol, rel_tol) wraps it in `scaled_effective_stress` (effective_stress.py:97-146)."""
+        max_iters, abs_tol, rel_tol) wraps it in `scaled_effective_stress` (effective_stress.py:97-146);
+        hardening_nn = (H, packed [W1[H], b1[H], W2[H], b2, in_scale, out_scale]) adds the network hardening law
+        (simple_neural_network.py:13-46 as hardening_funs["neural network"])."""
         self.values = values
         p = np.zeros(NP)
         p[P_Q:P_Q + 9] = np.asarray(values.get("rotation matrix", np.eye(3)), dtype=float).reshape(9)
@@ -201,6 +204,12 @@ class Material:
         self.elastic_names = given
         self.desc = Desc(model_kind, def_type, yk, ELASTIC_PAIRS[given], has_voce, has_lin, uniaxial_idx, order,
                          yield_tol, 0, (C.c_int * 8)(), None)
+        self._hnn_keep = None
+        if hardening_nn is not None:
+            Hn, hp = hardening_nn
+            self._hnn_keep = f64(hp)
+            self.desc.hnn_width = int(Hn)
+            self.desc.hnn_w = _p(self._hnn_keep)
         self._nn_keep = None
         if nn is not None:
             widths, packed = nn

@@ -630,6 +630,83 @@ def check_legacy_line_search(backend, def_type=ol.FULL_3D, yield_kind="hosford",
         assert np.mean(it_d == it_o) > 0.97, np.bincount(np.abs(it_d - it_o))
 
 
+def nn_hardening_values(H=5, with_voce=False, seed=4):
+    """J2 + the network hardening law of examples/noisy_calibration.py:245-252 (SimpleNeuralNetwork [1, H, 1], input_scale 2,
+    output_scale 1e2), weights perturbed off the constant-bias initialisation: (values, network, packed [W1, b1, W2, b2, si, so])."""
+    from cmad_amd.neural_networks import SimpleNeuralNetwork
+    net = SimpleNeuralNetwork([1, H, 1], input_scale=2., output_scale=1e2)
+    rng = np.random.default_rng(seed)
+    for layer in net.params:
+        layer["weights"] = layer["weights"] * rng.uniform(0.6, 1.6, size=layer["weights"].shape) * 6.0
+        layer["biases"] = layer["biases"] + rng.normal(0., 0.5, size=layer["biases"].shape)
+    values = ol.j2_voce_values()
+    hard = {"neural network": net.params}
+    if with_voce:
+        hard = {"voce": {"S": 120., "D": 15.}, "neural network": net.params}
+    values["plastic"]["flow stress"]["hardening"] = hard
+    packed = np.concatenate([net.params[0]["weights"].ravel(), net.params[0]["biases"], net.params[1]["weights"].ravel(),
+                             net.params[1]["biases"], [net.input_scale, net.output_scale]])
+    return values, net, packed
+
+
+def check_nn_hardening(backend, param_blocks, def_type=ol.FULL_3D, with_voce=False, B=512):
+    """The network hardening law (cmad/neural_networks/simple_neural_network.py:13-46 as hardening_funs["neural network"],
+    cmad/models/small_elastic_plastic.py:115) in the hand-derived kernels -- update over two load steps (states, stresses,
+    iteration counts), reverse sweep (cotangents; gradient w.r.t. E, nu, Y) -- against the oracle, and the sensitivities
+    w.r.t. every network weight (cm_param_blocks: forward-mode evaluation) against central differences of the oracle."""
+    from cmad_amd.models.device import EP_NN0, NewtonSettings, build_desc, kp_to_leaf_grad
+    from cmad_amd.synthetic import gauss_point_batch
+    values, net, packed = nn_hardening_values(with_voce=with_voce)
+    Hn = net.layer_widths[1]
+
+    class S:
+        pass
+    sc = S()
+    sc.values = values
+    sc.mat = ol.Material(values, def_type=def_type, hardening_nn=(Hn, packed))
+    sc.st_o, sc.st_d = settings_pair(False)
+    sc.desc, sc.info = build_desc(values, def_type=def_type, newton=sc.st_d, hardening_nn=(net.input_scale, net.output_scale))
+    assert sc.desc.hnn_width == Hn and sc.info["hnn"] == (Hn, 0)
+    nd = 3 if def_type == ol.FULL_3D else 2
+    g0 = gauss_point_batch(B, seed=22, skew=True, ndims=nd)
+    g1 = gauss_point_batch(B, seed=23, skew=True, ndims=nd)
+    sc.gradu0, sc.gradu = g0, 1.4 * g0 + 0.2 * g1
+    sc.xi0 = np.tile(sc.mat.init_xi()[:, None], (1, B))
+    sc.xi1, sc.sig1, sc.it1, sc.cv1 = sc.mat.update_batch(sc.st_o, sc.gradu0, sc.xi0)
+    sc.xi2, sc.sig2, sc.it2, sc.cv2 = sc.mat.update_batch(sc.st_o, sc.gradu, sc.xi1)
+    assert sc.cv1.all() and sc.cv2.all()
+    assert np.abs(sc.xi2[6]).max() > 1e-4                        # the law is exercised: plastic flow happened
+    check_update(backend, sc)
+    sbar = np.random.default_rng(5).normal(size=(6, B))
+    g_o, xb_o, ub_o = sc.mat.update_vjp_batch(sc.gradu, sc.xi1, sc.xi2, sbar)
+    g_d, xb_d, ub_d = backend.vjp(sc, sc.gradu, sc.xi1, sc.xi2, sbar)
+    np.testing.assert_allclose(xb_d, xb_o, rtol=1e-9, atol=1e-9 * np.abs(xb_o).max())
+    np.testing.assert_allclose(ub_d, ub_o, rtol=1e-9, atol=1e-9 * np.abs(ub_o).max())
+    for path in (("elastic", "E"), ("elastic", "nu"), ("plastic", "flow stress", "initial yield", "Y")):
+        np.testing.assert_allclose(kp_to_leaf_grad(path, g_d, sc.info), g_o[sc.mat.param_index(path)], rtol=1e-9, err_msg=str(path))
+    # sensitivities w.r.t. the network weights at a plastic state away from the yield surface (half-way between the previous
+    # and the converged state: f > 0 by a margin, so central differences do not cross the branch select): dC/dw by
+    # forward-mode evaluation vs central differences of the oracle
+    b = int(np.argmax(sc.xi2[6] - sc.xi1[6]))
+    xi_mid = 0.5 * (sc.xi1 + sc.xi2)
+    assert sc.mat.yield_state(xi_mid[:, b], sc.gradu[:, b])[1] > 1e-6
+    nw = 3 * Hn + 1
+    ep = [EP_NN0 + i for i in range(nw)]
+    if "nn_packed" in sc.info:
+        sc.desc.nn_weights = sc.info["nn_packed"].ctypes.data           # host build reads host memory; the GPU wrapper re-places it
+    dC, dS = param_blocks(sc.desc, ep, sc.gradu[:, b:b + 1], sc.xi1[:, b:b + 1], xi_mid[:, b:b + 1], sc.mat.nx, info=sc.info)
+    assert not dS.any()                                              # the stress does not see the hardening law
+    for i in range(nw):
+        h = 1e-6 * max(1.0, abs(packed[i]))
+        wp, wm = packed.copy(), packed.copy()
+        wp[i] += h; wm[i] -= h
+        Cp = ol.Material(values, def_type=def_type, hardening_nn=(Hn, wp)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
+        Cm = ol.Material(values, def_type=def_type, hardening_nn=(Hn, wm)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
+        fd = (Cp - Cm) / (2 * h)
+        np.testing.assert_allclose(dC[i, :, 0], fd, rtol=2e-6, atol=1e-7 * np.abs(dC).max(), err_msg=f"weight {i}")
+    assert np.abs(dC[:, 6, 0]).max() > 0                             # ... and they are not all zero: the yield row sees every weight
+
+
 def check_edge_cases(backend, def_type=ol.FULL_3D):
     """Zero strain (sigma = 0: the reference's normal is NaN there and masked by the branch select), iteration cap
     reached without convergence (the reference returns the last iterate silently; status reports it: with caps of 1, 2 and 3

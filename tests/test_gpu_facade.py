@@ -823,3 +823,94 @@ def test_gradient_of_extended_leaves(yield_kind, active_rotation):
         xp_[k] += h; xm_[k] -= h
         g_fd[k] = (MPAdjointObjective(qoi, F).evaluate(xp_).J - MPAdjointObjective(qoi, F).evaluate(xm_).J) / (2 * h)
     np.testing.assert_allclose(ga, g_fd, rtol=2e-5, atol=1e-7 * np.abs(ga).max())
+
+
+def test_direct_adjoint_hessian_of_the_uniaxial_calibration_qoi():
+    """Second-order pass for a QoI with an explicit state term: UniaxialCalibration (axial stress + the two lateral stretches,
+    per-step weights; cmad/qois/uniaxial_calibration.py:70-85, differentiated twice in the reference by hessian(qoi_fun),
+    cmad/qois/qoi.py:47-57) on a UNIAXIAL_STRESS Hill model.  MPDirectAdjointObjective's gradient equals the adjoint one and
+    its Hessian is symmetric and matches central differences of the adjoint gradient."""
+    from cmad_amd.models import DefType, mp_U_from_F, newton_solve
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectAdjointObjective
+    from cmad_amd.qois import UniaxialCalibration
+    K = 10
+    F = np.repeat(np.eye(1)[:, :, None], K + 1, axis=2)
+    F[0, 0, :] += np.linspace(0., 0.006, K + 1)
+    model = _models()[1](params_J2_voce(yield_kind="hill"), DefType.UNIAXIAL_STRESS, uniaxial_stress_idx=1)
+    data = np.zeros((3, K + 1))
+    model.set_xi_to_init_vals()
+    for step in range(1, K + 1):
+        model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+        newton_solve(model)
+        model.evaluate_cauchy()
+        data[:, step] = [model.Sigma()[1, 1], model.xi()[2][0] - 1., model.xi()[2][1] - 1.]
+        model.advance_xi()
+    weight = np.ones((3, K + 1)); weight[1:, :] = 1e4
+    weight[:, 1::2] *= 0.5                                         # weights that change from step to step
+    qoi = UniaxialCalibration(model, data, weight, uniaxial_stress_idx=1, stretch_var_idx=2)
+    model.parameters.set_active_values_from_flat(1.1 * model.parameters.flat_active_values(False), False)
+    x = model.parameters.flat_active_values(True)
+    J, grad, H = MPDirectAdjointObjective(qoi, F).evaluate(x)
+    Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
+    assert abs(J - Ja) <= 1e-12 * abs(J) and J > 0
+    np.testing.assert_allclose(grad, ga, rtol=1e-9, atol=1e-11 * np.abs(ga).max())
+    np.testing.assert_allclose(H, H.T, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+    n, h = x.size, 1e-5
+    H_fd = np.zeros((n, n))
+    for k in range(n):
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        H_fd[:, k] = (MPAdjointObjective(qoi, F).evaluate(xp_).grad - MPAdjointObjective(qoi, F).evaluate(xm_).grad) / (2 * h)
+    np.testing.assert_allclose(H, H_fd, rtol=5e-5, atol=5e-6 * np.abs(H).max())
+    # the state term matters: without it the Hessian differs by more than the finite-difference check tolerates
+    class StressOnly(UniaxialCalibration):
+        def state_curvature(self):
+            return None
+    q2 = StressOnly(model, data, weight, uniaxial_stress_idx=1, stretch_var_idx=2)
+    H2 = MPDirectAdjointObjective(q2, F).evaluate(x).hessian
+    assert np.abs(H2 - H).max() > 1e-4 * np.abs(H).max()
+    assert not np.allclose(H2, H_fd, rtol=5e-5, atol=5e-6 * np.abs(H).max())
+
+
+def test_network_hardening_law_through_the_model_api():
+    """`SmallElasticPlastic(parameters, def_type, hardening_funs={"neural network": SimpleNeuralNetwork([1, 5, 1], ...).evaluate})`
+    as examples/noisy_calibration.py:245-252 builds it: the adjoint and the direct objective agree, and the gradient w.r.t.
+    the initial yield and EVERY network weight and bias (active leaves of the params pytree) matches central differences."""
+    import copy
+    from cmad_amd.models import DefType, SmallElasticPlastic, SmallRateElasticPlastic
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectObjective
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.parameters.parameters import tree_map
+    from cmad_amd.qois import Calibration
+    import parity_cases as pc
+    values, net, _ = pc.nn_hardening_values()
+    flags = tree_map(lambda a: False, copy.deepcopy(values))
+    flags["plastic"]["flow stress"] = tree_map(lambda a: True, flags["plastic"]["flow stress"])
+    params = Parameters(values, flags, tree_map(lambda a: None, copy.deepcopy(values)))
+    F = plane_stress_F(0.02, 3)
+    model = SmallElasticPlastic(params, DefType.PLANE_STRESS, hardening_funs={"neural network": net.evaluate})
+    cauchy = _compute_cauchy(model, F)
+    assert np.abs(cauchy).max() > 100.0
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    qoi = Calibration(model, cauchy + np.random.default_rng(3).normal(0., 2., cauchy.shape), weight)
+    x = 1.05 * model.parameters.flat_active_values(True)
+    n = x.size
+    assert n == 1 + 3 * 5 + 1                                       # Y, W1[5], b1[5], W2[5], b2
+    ra = MPAdjointObjective(qoi, F).evaluate(x)
+    rd = MPDirectObjective(qoi, F).evaluate(x)
+    assert abs(ra.J - rd.J) <= 1e-12 * abs(ra.J)
+    np.testing.assert_allclose(rd.grad, ra.grad, rtol=1e-8, atol=1e-10 * np.abs(ra.grad).max())
+    for k in range(n):
+        h = 1e-6 * max(1.0, abs(x[k]))
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        fd = (MPAdjointObjective(qoi, F).evaluate(xp_).J - MPAdjointObjective(qoi, F).evaluate(xm_).J) / (2 * h)
+        np.testing.assert_allclose(ra.grad[k], fd, rtol=5e-5, atol=1e-7 * np.abs(ra.grad).max(), err_msg=f"active parameter {k}")
+    assert np.count_nonzero(np.abs(ra.grad) > 1e-9 * np.abs(ra.grad).max()) >= n - 1      # all but the output bias matter
+    # the rate-form model, as the reference's example uses the law
+    rmodel = SmallRateElasticPlastic(params, DefType.PLANE_STRESS, hardening_funs={"neural network": net.evaluate})
+    rq = Calibration(rmodel, qoi.data(), weight)
+    rra = MPAdjointObjective(rq, F).evaluate(x)
+    rrd = MPDirectObjective(rq, F).evaluate(x)
+    np.testing.assert_allclose(rrd.grad, rra.grad, rtol=1e-8, atol=1e-10 * np.abs(rra.grad).max())
+    np.testing.assert_allclose(rra.J, ra.J, rtol=1e-6)                                    # same material, two formulations

@@ -685,3 +685,13 @@ def test_j2_voce_analytical_golden(golden_dir, model_kind, def_type, yield_kind)
             cauchy[i, j] = cauchy[j, i] = s6[:, r]
         assert np.linalg.norm(xh.cpu().numpy()[1:, 6, 0] - alpha) < 1e-6
         assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6
+
+
+@pytest.mark.parametrize("with_voce", [False, True])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_network_hardening_law(backend, def_type, with_voce):
+    """hardening_funs = {"neural network": SimpleNeuralNetwork([1, H, 1]).evaluate} (cmad/models/small_elastic_plastic.py:115,
+    cmad/neural_networks/simple_neural_network.py:13-46): update, reverse sweep and weight sensitivities through the C-ABI
+    against the oracle; also on the J2 subspace kernels (the default for J2) and the general path."""
+    import gpu_api
+    pc.check_nn_hardening(backend, gpu_api.param_blocks, def_type, with_voce=with_voce, B=1500)

@@ -578,3 +578,14 @@ def test_rate_form_with_a_dense_yield_surface(def_type, solver_variant):
         pc.check_history_second_order(lambda desc, info: HostHistoryEngine(desc=desc, info=info),
                                       lambda values, dt, mk: build_desc(values, def_type=dt, model_kind=mk),
                                       def_type, yk, kw, rate=True)
+
+
+@pytest.mark.parametrize("with_voce", [False, True])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
+def test_network_hardening_law(def_type, with_voce, solver_variant):
+    import host_harness_lib as hh
+    if def_type == ol.UNIAXIAL_STRESS and solver_variant != "structured":
+        pytest.skip("one solver form under UNIAXIAL_STRESS")
+    if def_type == ol.UNIAXIAL_STRESS:
+        pytest.skip("covered through the facade")
+    pc.check_nn_hardening(BACKEND, hh.param_blocks, def_type, with_voce=with_voce, B=192)
