@@ -6,7 +6,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcmad_hip.so")
 SOURCES = ["cmad_hip.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "cmad_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + [os.path.join("..", "..", "include", "cmad_hip.h")]
 
 
 def hipcc_path():
@@ -33,9 +33,14 @@ def build(force=False, verbose=False, jobs=None):
         return LIB
     hipcc = hipcc_path()
     src = os.path.join(CSRC, SOURCES[0])
-    objs = [os.path.join(CSRC, f"cmad_hip_part{k}.o") for k in range(NPARTS)]
+    # two builds of every part (see the top of cmad_hip.hip): BASE (no network hardening law) and HNN (with it, without the dense
+    # yield surfaces); the heavy base parts first so that the short HNN parts fill the tail of the schedule
+    objs = [os.path.join(CSRC, f"cmad_hip_part{k}.o") for k in range(NPARTS)] + \
+           [os.path.join(CSRC, f"cmad_hip_hnn_part{k}.o") for k in range(NPARTS)]
     cmds = [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-c", src, "-o", objs[k]]
-            for k in range(NPARTS)]
+            for k in range(NPARTS)] + \
+           [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-DCM_HNN_VARIANT=1", "-c", src, "-o",
+             objs[NPARTS + k]] for k in range(NPARTS)]
     jobs = jobs or min(NPARTS, os.cpu_count() or 1)
     procs, failed = [], []
     pending = list(cmds)

@@ -876,24 +876,14 @@ CM_D void yield_eval(const cm_model_desc& m, const double s[6], double& phi, dou
 struct Hard { double H, dH, expo; };
 // The network hardening law (widths [1, H, 1], include/cmad_hip.h hnn_width): value and derivative of
 //   out_scale * sum_u W2[u] (sigmoid(W1[u] in_scale alpha + b1[u]) - sigmoid(b1[u])).
-// Deliberately NOT inlined on the device: every kernel evaluates the hardening laws inside its Newton loop, and inlining this
-// loop there costs the Voce / linear configurations scalar registers (measured: -4 % on the fused J2 objective and
-// PLANE_STRESS kernels, profiles/r03_hnn_ab.txt).  As a call it is one uniform branch that those configurations never take.
+// Compiled only into the HNN build of the library (CM_HNN = 1, cmad_hip.hip): every kernel evaluates the hardening laws inside
+// its Newton loop, and this loop there costs the Voce / linear configurations scalar registers and spill traffic whether it
+// is inlined or called (profiles/r03_hnn_ab.txt).  The host build (tests) always has it.
+#ifndef CM_HNN
+#define CM_HNN 1
+#endif
 struct HnnTerm { double H, dH; };
-#if defined(CM_HOST_BUILD)
-inline
-#else
-__device__ __attribute__((noinline))
-#endif
-HnnTerm hardening_network(const double* wv, int Hn, double alpha) {
-#if !defined(CM_HOST_BUILD)
-    // arguments of a real call arrive in vector registers: back to scalars (they are wave-uniform) so that the weights are
-    // read by scalar loads
-    Hn = __builtin_amdgcn_readfirstlane(Hn);
-    const uint64_t a64 = (uint64_t)wv;
-    wv = (const double*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a64 >> 32)) << 32) |
-                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a64 & 0xffffffffu)));
-#endif
+CM_D HnnTerm hardening_network(const double* wv, int Hn, double alpha) {
     const cm_uniform_ptr w = uniform_ptr(wv);
     const double si = w[3 * Hn + 1], so = w[3 * Hn + 2];
     double acc = 0.0, dacc = 0.0;
@@ -915,13 +905,12 @@ CM_D Hard hardening(const cm_model_desc& m, double alpha) {
         h.dH += m.voce_S * m.voce_D * h.expo;
     }
     if (m.has_linear) { h.H += m.lin_K * alpha; h.dH += m.lin_K; }
-#ifndef CM_HNN
-#define CM_HNN 1                                                // 0: build without the network hardening law (A/B measurements)
-#endif
-    if (CM_HNN && m.hnn_width > 0) {                            // uniform: the network hardening law, widths [1, H, 1] (cmad_hip.h)
-        const HnnTerm t = hardening_network(m.nn_weights + m.hnn_offset, m.hnn_width, alpha);
-        h.H += t.H;
-        h.dH += t.dH;
+    if constexpr (CM_HNN != 0) {
+        if (m.hnn_width > 0) {                                  // uniform: the network hardening law, widths [1, H, 1] (cmad_hip.h)
+            const HnnTerm t = hardening_network(m.nn_weights + m.hnn_offset, m.hnn_width, alpha);
+            h.H += t.H;
+            h.dH += t.dH;
+        }
     }
     return h;
 }
@@ -2317,6 +2306,72 @@ CM_D bool direct_point(const cm_model_desc& m, const double* G, const double* Gp
             double t = Sp[r * NP_ + j];
             for (int k = 0; k < NX; ++k) t += Sx[r * NX + k] * rhs[k];
             ds_dp[r * NP_ + j] = t;
+        }
+    }
+    return ok;
+}
+
+// ---- one COLUMN of the forward sensitivities of a converged step ------------------------------------------------------
+// The same recursion as direct_point for ONE native parameter j (KP order):  d = dxi/dp_j = -A^-1 (dC/dp_j + dC/dxi_prev d_prev),
+// ds = dsigma/dp_j|_xi + dsigma/dxi d.  One thread per (point, parameter): twelve lanes share a point instead of one lane
+// carrying a 7..9 x 12 block through runtime-indexed (scratch) arrays -- every array here is indexed by compile-time
+// constants after unrolling (the column of the parameter block is picked by selects), and the twelve columns of a point
+// advance in parallel, which is what the one-point-at-a-time material-point objectives need (cmad/objectives/
+// mp_objective.py:158-215 with B = 1).  d_prev: the carried column (null = 0 on the first step).
+template <int MK, int DEF, int YK, bool ROT>
+CM_D bool direct_column(const cm_model_desc& m, const double* G, const double* Gp, const double* x, const double* xp, int j,
+                        const double* d_prev, double* d, double* ds) {
+    constexpr int NX = Dims<DEF>::NX, NP_ = CM_NUM_PARAMS;
+    double C[NX], sg[6], rhs[NX], sp[6];
+    {   // dC/dp_j and dsigma/dp_j: the parameter block, column j picked by selects (no runtime-indexed array)
+        double Cp[NX * NP_], Sp[6 * NP_];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, CM_W_PARAMS, C, Cp, sg, Sp);
+        else evaluate_blocks<DEF, YK, ROT>(m, G, x, xp, CM_W_PARAMS, C, Cp, sg, Sp);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < NP_; ++jj) v = (jj == j) ? Cp[i * NP_ + jj] : v;
+            rhs[i] = -v;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < NP_; ++jj) v = (jj == j) ? Sp[r * NP_ + jj] : v;
+            sp[r] = v;
+        }
+    }
+    if (d_prev) {
+        double Axp[NX * NX];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, CM_W_XI_PREV, C, Axp, sg, nullptr);
+        else evaluate_blocks<DEF, YK, ROT>(m, G, x, xp, CM_W_XI_PREV, C, Axp, sg, nullptr);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) t += Axp[i * NX + k] * d_prev[k];
+            rhs[i] -= t;
+        }
+    }
+    double Ax[NX * NX], Sx[6 * NX], A[NX][NX];
+    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, CM_W_XI, C, Ax, sg, Sx);
+    else evaluate_blocks<DEF, YK, ROT>(m, G, x, xp, CM_W_XI, C, Ax, sg, Sx);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int k = 0; k < NX; ++k) A[i][k] = Ax[i * NX + k];
+    const bool ok = lu_factor<NX>(A);
+    lu_subst<NX>(A, rhs);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) d[i] = rhs[i];
+    if (ds) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double t = sp[r];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) t += Sx[r * NX + k] * rhs[k];
+            ds[r] = t;
         }
     }
     return ok;

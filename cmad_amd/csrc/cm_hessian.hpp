@@ -147,7 +147,7 @@ CM_D T hardening_T(const cm_model_desc& m, const MatT<T>& p, const T& alpha) {
     T H = t_const<T>(0.0);
     if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * alpha)));
     if (m.has_linear) H = H + p.K * alpha;
-    if (m.hnn_width > 0) {
+    if (CM_HNN != 0 && m.hnn_width > 0) {                      // (only the HNN build of the library carries the law, cm_device.hpp)
         const int Hn = m.hnn_width, o = m.hnn_offset;
         const double si = p.nn[o + 3 * Hn + 1], so = p.nn[o + 3 * Hn + 2];
         auto sigmoid = [](const T& a) {
@@ -290,9 +290,26 @@ CM_D void barlat_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& ph
 }
 
 // effective stress value and 6-vector gradient gt in arithmetic T (the closed forms of yield_eval)
+// YK = CM_YIELD_ANY: the surface is chosen at run time from m.yield_kind (a wave-uniform switch).  The kernels built on this
+// model (second derivatives, extended parameter sensitivities: cold, one thread per derivative direction) are instantiated
+// once per deformation type and model kind instead of once per yield surface as well.
+constexpr int CM_YIELD_ANY = -1;
 template <int YK, class T>
 CM_D void yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& phi, T gt[6]) {
-    if constexpr (YK == CM_YIELD_BARLAT) {
+    if constexpr (YK == CM_YIELD_ANY) {
+        switch (m.yield_kind) {
+            case CM_YIELD_J2: yield_T<CM_YIELD_J2, T>(m, p, s, phi, gt); break;
+            case CM_YIELD_HILL: yield_T<CM_YIELD_HILL, T>(m, p, s, phi, gt); break;
+#if defined(CM_HNN_VARIANT) && CM_HNN_VARIANT             // the HNN build of the library has no dense surfaces (cmad_hip.hip)
+            default: yield_T<CM_YIELD_HOSFORD, T>(m, p, s, phi, gt); break;
+#else
+            case CM_YIELD_HOSFORD: yield_T<CM_YIELD_HOSFORD, T>(m, p, s, phi, gt); break;
+            case CM_YIELD_HYBRID_HILL_NN: yield_T<CM_YIELD_HYBRID_HILL_NN, T>(m, p, s, phi, gt); break;
+            case CM_YIELD_SCALED_HYBRID_HILL_NN: yield_T<CM_YIELD_SCALED_HYBRID_HILL_NN, T>(m, p, s, phi, gt); break;
+            default: yield_T<CM_YIELD_BARLAT, T>(m, p, s, phi, gt); break;
+#endif
+        }
+    } else if constexpr (YK == CM_YIELD_BARLAT) {
         barlat_T<T>(m, p, s, phi, gt);
     } else if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
         yield_T<CM_YIELD_HILL, T>(m, p, s, phi, gt);

@@ -785,11 +785,17 @@ CM_D void reverse_j2_plane(const cm_model_desc& m, const double eg[6], const dou
     for (int j = 0; j < 6; ++j) pbar[CM_P_YC0 + j] = 0.0;
 }
 
+#if defined(CM_HNN_VARIANT) && CM_HNN_VARIANT
+#define CM_HNN_BUILD_HAS_SUBSPACE false
+#else
+#define CM_HNN_BUILD_HAS_SUBSPACE true
+#endif
 // which (def_type, yield, line search) combinations have a Newton iteration restricted to its invariant subspace
 // (newton_j2_line, newton_j2_plane): the launchers pick the RL = true kernel variants for them unless CM_SOLVER_GENERAL_NEWTON
 template <int DEF, int YK, bool LS>
 constexpr bool has_j2_subspace() {
-    return YK == CM_YIELD_J2 && (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS);
+    // (the HNN build of the library -- network hardening law, a rarely used configuration -- keeps only the general kernels)
+    return CM_HNN_BUILD_HAS_SUBSPACE && YK == CM_YIELD_J2 && (DEF == CM_FULL_3D || DEF == CM_PLANE_STRESS);
 }
 // what the launchers test to pick the RL = true kernel variants (UNIAXIAL_STRESS needs no variant: its kernels always take the
 // 9 x 9 Newton step through the 4 x 4 form, uniaxial_solve in cm_device.hpp, which is the same step)

@@ -3,6 +3,19 @@
 // element [k*B + b] -> every global access is a 512-byte contiguous row per wave instruction.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+// Two builds of this file make the library (cmad_amd/build.py): the BASE build (CM_HNN_VARIANT = 0) without the network hardening
+// law -- so that law costs the Voce / linear configurations nothing, not an instruction and not a register (inlined into every
+// Newton loop it cost the fused J2 objective and PLANE_STRESS kernels 4 %, as a call 15-20 % more VALU instructions per
+// wavefront: profiles/r03_hnn_ab.txt) -- and the HNN build (CM_HNN_VARIANT = 1) with it, for J2 / Hill / Hosford.  Every launching
+// entry point is defined under a suffixed name (cm_update_base / cm_update_hnn: the renames of cm_entries.inc); the public symbols
+// of include/cmad_hip.h are wrappers that pick the build from cm_model_desc.hnn_width (bottom of this file, compiled once).
+#ifndef CM_HNN_VARIANT
+#define CM_HNN_VARIANT 0
+#endif
+#define CM_HNN CM_HNN_VARIANT
+#define CM_ENTRIES_RENAME
+#include "cm_entries.inc"
+#undef CM_ENTRIES_RENAME
 #include "cm_pool.hpp"
 #include "cm_hessian.hpp"
 
@@ -17,7 +30,7 @@
 #define CM_HAS_PART(k) (CM_PART == -1 || CM_PART == (k))
 
 extern int g_cm_last_hip_error;
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 int g_cm_last_hip_error = 0;
 #endif
 
@@ -937,6 +950,96 @@ __global__ __launch_bounds__(64) void k_direct_step(cm_model_desc m, int64_t B,
     if (ds_dp) for (int i = 0; i < 6 * NP_; ++i) ds_dp[(int64_t)i * B + b] = dsig[i];
 }
 
+// ---- cm_direct_step / cm_direct_history by columns: one thread per (point, native parameter) ---------------------------
+// (cm::direct_column).  Points are the fast index: the lanes of a wavefront share the parameter for B >= 64; for the
+// material-point objectives (B = 1) the twelve columns of the one point advance side by side.  The 12-dof rate form under
+// UNIAXIAL_STRESS keeps the one-thread-per-point kernels above (its blocks come from forward-mode evaluation).
+template <int DEF, int YK, bool ROT, int MK>
+__global__ __launch_bounds__(64) void k_direct_step_cols(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev,
+        const double* __restrict__ xi, const double* __restrict__ dxp_dp, double* __restrict__ dx_dp, double* __restrict__ ds_dp) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * NP_) return;
+    const int64_t b = tid % B;
+    const int j = (int)(tid / B);
+    double G[NU], Gp[NU], xp[NX], x[NX], dprev[NX], d[NX], dsc[6];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) { G[k] = gradu[(int64_t)k * B + b]; Gp[k] = gradu_prev ? gradu_prev[(int64_t)k * B + b] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[(int64_t)k * B + b]; x[k] = xi[(int64_t)k * B + b]; }
+    if (dxp_dp) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) dprev[k] = dxp_dp[(int64_t)(k * NP_ + j) * B + b];
+    }
+    direct_column<MK, DEF, YK, ROT>(m, G, Gp, x, xp, j, dxp_dp ? dprev : nullptr, d, ds_dp ? dsc : nullptr);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) dx_dp[(int64_t)(k * NP_ + j) * B + b] = d[k];
+    if (ds_dp) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ds_dp[(int64_t)(r * NP_ + j) * B + b] = dsc[r];
+    }
+}
+
+template <int DEF, int YK, bool ROT, int MK>
+__global__ __launch_bounds__(64) void k_direct_history_cols(cm_model_desc m, int64_t B, int K,
+        const double* __restrict__ gradu_hist, const double* __restrict__ xi_hist,
+        const double* __restrict__ sbar_hist, const double* __restrict__ xibar_hist,
+        double* __restrict__ dx_dp_hist, double* __restrict__ ds_dp_hist, double* __restrict__ rows) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NP_ = CM_NUM_PARAMS;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * NP_) return;
+    const int64_t b = tid % B;
+    const int j = (int)(tid / B);
+    double d[NX], dn[NX], dsc[6], g = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) d[k] = 0.0;
+    if (dx_dp_hist) {                                            // slot 0: no sensitivity before the first step
+#pragma unroll
+        for (int k = 0; k < NX; ++k) dx_dp_hist[(int64_t)(k * NP_ + j) * B + b] = 0.0;
+    }
+    if (ds_dp_hist) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ds_dp_hist[(int64_t)(r * NP_ + j) * B + b] = 0.0;
+    }
+    for (int step = 1; step <= K; ++step) {
+        double G[NU], Gp[NU], xp[NX], x[NX];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            G[k] = gradu_hist[((int64_t)step * NU + k) * B + b];
+            Gp[k] = gradu_hist[((int64_t)(step - 1) * NU + k) * B + b];
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            x[k] = xi_hist[((int64_t)step * NX + k) * B + b];
+            xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + b];
+        }
+        direct_column<MK, DEF, YK, ROT>(m, G, Gp, x, xp, j, step > 1 ? d : nullptr, dn, dsc);
+        if (dx_dp_hist) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) dx_dp_hist[((int64_t)step * NX * NP_ + k * NP_ + j) * B + b] = dn[k];
+        }
+        if (ds_dp_hist) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) ds_dp_hist[((int64_t)step * 6 * NP_ + r * NP_ + j) * B + b] = dsc[r];
+        }
+        if (sbar_hist) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) g += sbar_hist[((int64_t)step * 6 + r) * B + b] * dsc[r];
+        }
+        if (xibar_hist) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) g += xibar_hist[((int64_t)step * NX + k) * B + b] * dn[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) d[k] = dn[k];
+    }
+    if (rows) {
+        if (j == 0) rows[b * kRed] = 0.0;
+        rows[b * kRed + 1 + j] = g;
+    }
+}
+
 // ---- cm_hessians: one thread per (point, pair of differentiation variables) -----------------------------------
 template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 __global__ __launch_bounds__(64) void k_hessians(cm_model_desc m, int64_t B,
@@ -1143,6 +1246,7 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS && m->def_type != CM_UNIAXIAL_STRESS) return false;
     if (m->def_type == CM_UNIAXIAL_STRESS && (m->uniaxial_idx < 0 || m->uniaxial_idx > 2)) return false;
     if (m->hnn_width < 0 || (m->hnn_width > 0 && (!m->nn_weights || m->hnn_offset < 0))) return false;   // network hardening law
+    if (CM_HNN_VARIANT && is_dense_yield(m->yield_kind)) return false;       // the HNN build: J2 / Hill / Hosford (see the top of the file)
     if (m->yield_kind == CM_YIELD_SCALED_HYBRID_HILL_NN && !(m->beta_equivalent_stress > 0.0 && m->beta_max_iters >= 0)) return false;
     if (is_nn_yield(m->yield_kind))                    // one hidden layer [6, H, 1], weights resident on the device
         return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
@@ -1181,7 +1285,7 @@ inline bool rate_uniaxial_dense(const cm_model_desc* m) {
 // products; 2: none (the rate form, whose dense LU dwarfs them).  With Q = I the rotation products reproduce the plain
 // result exactly (products with 1, sums with 0), so this only trades a few instructions for a smaller library.
 template <int ROTP, int D, int Y>
-constexpr bool always_rotates() { return ROTP == 2 || (ROTP == 1 && (is_dense_yield(Y) || D == CM_UNIAXIAL_STRESS)); }
+constexpr bool always_rotates() { return CM_HNN_VARIANT != 0 || ROTP == 2 || (ROTP == 1 && (is_dense_yield(Y) || D == CM_UNIAXIAL_STRESS)); }   // (the HNN build keeps one variant per configuration)
 
 template <bool UNI = false, int ROTP = 0, class F>
 inline bool dispatch(const cm_model_desc* m, F&& f) {
@@ -1201,19 +1305,23 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_J2)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HILL)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
+#if !CM_HNN_VARIANT                    // the HNN build leaves the dense surfaces out (supported() refuses them there)
     CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_FULL_3D, CM_YIELD_SCALED_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
     CM_CASE(CM_FULL_3D, CM_YIELD_BARLAT)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_BARLAT)
+#endif
     if constexpr (UNI) {
-        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_BARLAT)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_J2)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)
+#if !CM_HNN_VARIANT
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_BARLAT)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HYBRID_HILL_NN)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
+#endif
     }
 #undef CM_CASE
     return false;
@@ -1493,8 +1601,13 @@ int launch_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, c
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))
-            hipLaunchKernelGGL((k_direct_step<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
+        if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())) {
+            if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS)
+                hipLaunchKernelGGL((k_direct_step<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
+            else
+                hipLaunchKernelGGL((k_direct_step_cols<D, Y, kColdRot, MK>), dim3((unsigned)((B * CM_NUM_PARAMS + 63) / 64)), block, 0, s,
+                                   md, B, gradu, gradu_prev, xi_prev, xi, dxp_dp, dx_dp, ds_dp);
+        }
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
@@ -1518,9 +1631,14 @@ int launch_direct_history(const cm_model_desc* m, int64_t B, int K, const double
     if (B > 0) {
         const dim3 grid((unsigned)((B + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))
-                hipLaunchKernelGGL((k_direct_history<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist,
-                                   sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist, rows);
+            if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())) {
+                if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS)
+                    hipLaunchKernelGGL((k_direct_history<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist,
+                                       sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist, rows);
+                else
+                    hipLaunchKernelGGL((k_direct_history_cols<D, Y, kColdRot, MK>), dim3((unsigned)((B * CM_NUM_PARAMS + 63) / 64)), block, 0, s,
+                                       md, B, K, gradu_hist, xi_hist, sbar_hist, xibar_hist, dx_dp_hist, ds_dp_hist, rows);
+            }
         });
         if (!found) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
@@ -1550,7 +1668,7 @@ int launch_hessians(const cm_model_desc* m, int64_t B, const double* gradu, cons
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())))
-            hipLaunchKernelGGL((k_hessians<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi,
+            hipLaunchKernelGGL((k_hessians<D, CM_YIELD_ANY, kColdRot, MK>), grid, block, 0, s, md, B, gradu, gradu_prev, xi_prev, xi,
                                d2C, d2S, dC, dS, C0, S0);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
@@ -1582,7 +1700,7 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
         const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>()))) {
-                hipLaunchKernelGGL((k_hessian_weights<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist, lam_hist,
+                hipLaunchKernelGGL((k_hessian_weights<D, CM_YIELD_ANY, kColdRot, MK>), grid, block, 0, s, md, B, K, gradu_hist, xi_hist, lam_hist,
                                    sbar_hist, h, hss_hist, hxx_hist, W);
                 hipLaunchKernelGGL((k_hessian_quadform<nx_of<D, MK>()>), dim3((unsigned)nps), dim3(192), 0, s, B, K, W, dx_dp_hist, part);
             }
@@ -1610,7 +1728,7 @@ int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
         if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())))
-            hipLaunchKernelGGL((k_param_blocks<D, Y, MK>), grid, block, 0, s, md, B, n_ep, ep_index, gradu, gradu_prev, xi_prev, xi, dC, dS);
+            hipLaunchKernelGGL((k_param_blocks<D, CM_YIELD_ANY, MK>), grid, block, 0, s, md, B, n_ep, ep_index, gradu, gradu_prev, xi_prev, xi, dC, dS);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
@@ -1633,7 +1751,7 @@ int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n
         const dim3 grid((unsigned)((B * n_ep + 63) / 64)), block(64);
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())))
-                hipLaunchKernelGGL((k_param_adjoint_history<D, Y, MK>), grid, block, 0, s, md, B, K, n_ep, ep_index, gradu_hist, xi_hist,
+                hipLaunchKernelGGL((k_param_adjoint_history<D, CM_YIELD_ANY, MK>), grid, block, 0, s, md, B, K, n_ep, ep_index, gradu_hist, xi_hist,
                                    lam_hist, sbar_hist, rows);
         });
         if (!found) return CM_ERR_UNSUPPORTED;
@@ -1653,15 +1771,15 @@ int cmi_objective_from_state(const cm_model_desc* m, int64_t B, const double* gr
                              const double* data, const double* wsq6, double* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 int cm_abi_version(void) { return 5; }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 const char* cm_last_hip_error(void) { return hipGetErrorName((hipError_t)g_cm_last_hip_error); }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 int cm_num_xi(const cm_model_desc* m) {
     if (!m) return CM_ERR_BAD_ARG;
     if (m->def_type == CM_FULL_3D) return 7;
@@ -1671,7 +1789,7 @@ int cm_num_xi(const cm_model_desc* m) {
 }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 int cm_num_gradu(const cm_model_desc* m) {
     if (!m) return CM_ERR_BAD_ARG;
     if (m->def_type == CM_FULL_3D) return 9;
@@ -1681,7 +1799,7 @@ int cm_num_gradu(const cm_model_desc* m) {
 }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 int64_t cm_workspace_bytes(int64_t B) {
     if (B < 0) return CM_ERR_BAD_ARG;
     const int64_t nb = B == 0 ? 1 : nblocks_of(B);
@@ -1771,11 +1889,11 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
 }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 int cm_sizeof_model_desc(void) { return (int)sizeof(cm_model_desc); }
 #endif
 
-#if CM_HAS_PART(1)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 int64_t cm_direct_workspace_bytes(int64_t B) {
     if (B < 0) return CM_ERR_BAD_ARG;
     return ((B > 0 ? B : 1) + kRedBlocks + 1) * kRed * (int64_t)sizeof(double);      // one row per point + stage rows
@@ -2033,3 +2151,10 @@ int cm_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, const doubl
 #endif
 
 }  // extern "C"
+
+// ---- the public entry points: pick the build by the hardening law (cm_entries.inc, section 2) -------------------------------
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
+#define CM_ENTRIES_PUBLIC
+#include "cm_entries.inc"
+#undef CM_ENTRIES_PUBLIC
+#endif

@@ -278,7 +278,7 @@ static void run_hessians(const cm_model_desc& m, int64_t B, const double* gradu,
             for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + pt]; x[k] = xi[k * B + pt]; }
             for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
                 const bool first = (a == 0 && b == 0);
-                hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa, first ? oC0 : nullptr, first ? oS0 : nullptr);
+                hessian_pair<DEF, CM_YIELD_ANY, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa, first ? oC0 : nullptr, first ? oS0 : nullptr);
                 for (int k = 0; k < NX; ++k) { d2C[((pt * NX + k) * NQ + a) * NQ + b] = oC[k]; d2C[((pt * NX + k) * NQ + b) * NQ + a] = oC[k]; }
                 for (int k = 0; k < 6; ++k) { d2S[((pt * 6 + k) * NQ + a) * NQ + b] = oS[k]; d2S[((pt * 6 + k) * NQ + b) * NQ + a] = oS[k]; }
                 if (a == b) {
@@ -472,8 +472,19 @@ int hh_direct_step(const cm_model_desc* m, int64_t B, const double* gradu, const
             for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + b]; x[k] = xi[k * B + b]; }
             if (dxp_dp) for (int i = 0; i < NX * NP_; ++i) din[i] = dxp_dp[(int64_t)i * B + b];
             if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS) ru_direct<Y>(*m, G[0] - Gp[0], x, xp, dxp_dp ? din : nullptr, dout, dsig);
-            else
-            direct_point<MK, D, Y, R>(*m, G, Gp, x, xp, dxp_dp ? din : nullptr, dout, dsig);
+            else {
+                // column by column, as k_direct_step_cols / k_direct_history_cols do (cm::direct_column; hh_direct_history below
+                // runs the block form cm::direct_point: both are checked against the oracle)
+                if constexpr (NX == Dims<D>::NX) {
+                    for (int j = 0; j < NP_; ++j) {
+                        double dprev[NX], dcol[NX], dscol[6];
+                        for (int k = 0; k < NX; ++k) dprev[k] = dxp_dp ? din[k * NP_ + j] : 0.0;
+                        direct_column<MK, D, Y, R>(*m, G, Gp, x, xp, j, dxp_dp ? dprev : nullptr, dcol, dscol);
+                        for (int k = 0; k < NX; ++k) dout[k * NP_ + j] = dcol[k];
+                        for (int r = 0; r < 6; ++r) dsig[r * NP_ + j] = dscol[r];
+                    }
+                }
+            }
             for (int i = 0; i < NX * NP_; ++i) dx_dp[(int64_t)i * B + b] = dout[i];
             for (int i = 0; i < 6 * NP_; ++i) ds_dp[(int64_t)i * B + b] = dsig[i];
         }
@@ -541,7 +552,7 @@ int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* g
             double hs[6];                       // as k_hessian_weights: per-step stress curvature, state curvature on the diagonal
             for (int r = 0; r < 6; ++r) hs[r] = hss_hist ? hss_hist[step * 6 + r] : hss6[r];
             for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
-                double w = hessian_weight<D, Y, true, MK>(*m, G, x, xp, lam, sbar, hs, a, b);
+                double w = hessian_weight<D, CM_YIELD_ANY, true, MK>(*m, G, x, xp, lam, sbar, hs, a, b);
                 if (hxx_hist && a == b && a < NX) w += hxx_hist[step * NX + a];
                 W[(ps * NQ + a) * NQ + b] = w; W[(ps * NQ + b) * NQ + a] = w;
             }
@@ -562,7 +573,7 @@ int hh_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* 
             double G[NU], xp[NX], x[NX], oC[NX], oS[6];
             for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + pt] - (gradu_prev ? gradu_prev[k * B + pt] : 0.0);
             for (int k = 0; k < NX; ++k) { xp[k] = xi_prev[k * B + pt]; x[k] = xi[k * B + pt]; }
-            param_direction<D, Y, MK>(*m, G, x, xp, ep_index[j], oC, oS);
+            param_direction<D, CM_YIELD_ANY, MK>(*m, G, x, xp, ep_index[j], oC, oS);
             for (int k = 0; k < NX; ++k) dC[((int64_t)j * NX + k) * B + pt] = oC[k];
             for (int k = 0; k < 6; ++k) dS[((int64_t)j * 6 + k) * B + pt] = oS[k];
         }

@@ -15,6 +15,7 @@ for k in 0 1 2 3 4 5 6 7 8 9; do
   else
     OBJS="$OBJS $CSRC/cmad_hip_part$k.o"
   fi
+  OBJS="$OBJS $CSRC/cmad_hip_hnn_part$k.o"        # the HNN build's objects are linked as they are
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$NAME.so $OBJS
