@@ -795,26 +795,46 @@ CM_D void yield_eval_p(const cm_model_desc& m, const double s[6], double& phi, d
         // u_i^a (u_i in [0,1]); (|d_i|/phi)^(a-2) = u_i^a Sr^2 / (u_i^2 S) -- no further pow.
         // Integer exponents (the usual case: 6, 8, 100) by repeated squaring, ~log2(a) multiplications per term
         // and a few ulp; anything else as exp(a log u).  `a` is a kernel argument, so the branch is uniform.
-        double ua[3];
+        double ua[3], uam2[3];                                      // u_i^a and u_i^(a-2)
         const int ai = (int)a;
         const bool int_pow = (a == (double)ai && ai >= 2 && ai <= 65536);
         if (int_pow) {
+            // u^(a-2) by repeated squaring, then u^a = u^(a-2) u^2: the (a-2)-th power is what the gradient and the Hessian
+            // need (no reciprocal of u_i afterwards)
             double base[3] = {u[0], u[1], u[2]};
-            ua[0] = ua[1] = ua[2] = 1.0;
-            for (int e = ai; e != 0; e >>= 1) {
-                if (e & 1) { ua[0] *= base[0]; ua[1] *= base[1]; ua[2] *= base[2]; }
+            uam2[0] = uam2[1] = uam2[2] = 1.0;
+            for (int e = ai - 2; e != 0; e >>= 1) {
+                if (e & 1) { uam2[0] *= base[0]; uam2[1] *= base[1]; uam2[2] *= base[2]; }
                 base[0] *= base[0]; base[1] *= base[1]; base[2] *= base[2];
             }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ua[i] = uam2[i] * (u[i] * u[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) ua[i] = (u[i] > 0.0) ? exp(a * log(u[i])) : 0.0;
+            for (int i = 0; i < 3; ++i) {
+                ua[i] = (u[i] > 0.0) ? exp(a * log(u[i])) : 0.0;
+                uam2[i] = (u[i] > 0.0) ? ua[i] / (u[i] * u[i]) : ((a == 2.0) ? 1.0 : 0.0);
+            }
         }
         const double S = 0.5 * (ua[0] + ua[1] + ua[2]);
         // S^(1/a): max u_i = 1 puts S in [1/2, 3/2] whenever it is non-zero, so the short logarithm applies; reciprocals by
-        // rcp (1 ulp) instead of the IEEE division sequence on the integer-exponent path (7 of them per evaluation)
+        // rcp (1 ulp) instead of the IEEE division sequence on the integer-exponent path
         double Sr, iSr, iS;
         if (int_pow) {
-            Sr = (S > 0.0) ? exp_s(log_near_one(S) * rcp(a)) : 0.0;
+            const double xl = log_near_one(S) * rcp(a);             // |xl| <= 0.7 / a
+            if (a >= 64.0) {
+                // |xl| < 2^-6.5: e^x by its Taylor polynomial of degree 7 (truncation below 1e-19 relative) -- no range reduction
+                double pe = CM_SCALAR(1.0 / 5040.0);
+                pe = __builtin_fma(xl, pe, CM_SCALAR(1.0 / 720.0));
+                pe = __builtin_fma(xl, pe, CM_SCALAR(1.0 / 120.0));
+                pe = __builtin_fma(xl, pe, CM_SCALAR(1.0 / 24.0));
+                pe = __builtin_fma(xl, pe, CM_SCALAR(1.0 / 6.0));
+                pe = __builtin_fma(xl, pe, 0.5);
+                pe = __builtin_fma(xl, pe, 1.0);
+                Sr = (S > 0.0) ? __builtin_fma(xl, pe, 1.0) : 0.0;
+            } else {
+                Sr = (S > 0.0) ? exp_s(xl) : 0.0;
+            }
             iSr = (S > 0.0) ? rcp(Sr) : 0.0;
             iS = (S > 0.0) ? rcp(S) : 0.0;
         } else {
@@ -829,8 +849,7 @@ CM_D void yield_eval_p(const cm_model_desc& m, const double s[6], double& phi, d
         for (int i = 0; i < 3; ++i) {
             r[i] = u[i] * iSr;                                  // |d_i| / phi
             sg[i] = (dd[i] > 0.0) ? 1.0 : ((dd[i] < 0.0) ? -1.0 : 0.0);
-            const double iu = (u[i] > 0.0) ? (int_pow ? rcp(u[i]) : 1.0 / u[i]) : 0.0;
-            ram2[i] = (u[i] > 0.0) ? ua[i] * c2 * iu * iu : ((a == 2.0) ? 1.0 : 0.0);
+            ram2[i] = uam2[i] * c2;                             // (|d_i| / phi)^(a-2) = u_i^(a-2) Sr^2 / S   (a = 2: u^0 = 1)
             p[i] = 0.5 * ram2[i] * r[i] * sg[i];               // d phi / d d_i
         }
 #pragma unroll
@@ -840,7 +859,7 @@ CM_D void yield_eval_p(const cm_model_desc& m, const double s[6], double& phi, d
 #pragma unroll
             for (int k = 0; k < 21; ++k) Hp[k] = 0.0;
             double Hd[3][3];
-            const double ip = (phi > 0.0) ? rcp(phi) : 0.0;
+            const double ip = imx * iSr;                            // 1 / phi (both factors vanish with phi)
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll

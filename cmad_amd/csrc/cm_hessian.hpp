@@ -85,7 +85,10 @@ template <> CM_D D1 t_const<D1>(double c) { return D1{c, 0.0}; }
 template <> CM_D HD t_const<HD>(double c) { return HD{c, 0.0, 0.0, 0.0}; }
 CM_D void t_seed(double&) {}
 CM_D void t_seed(D1& x) { x.d = 1.0; }
-CM_D void t_seed(HD&) {}
+CM_D void t_seed(HD& x) { x.a = 1.0; }         // first differentiation direction of a hyper-dual ...
+CM_D void t_seed2(double&) {}
+CM_D void t_seed2(D1&) {}
+CM_D void t_seed2(HD& x) { x.b = 1.0; }        // ... and the second one
 
 // parameters as scalars of type T, KP order (include/cmad_hip.h cm_param_index)
 // yc: the yield-surface coefficients as cm_model_desc.yc (Hill F..N | Hosford a | Barlat 18 + a), Q: the rotation matrix,
@@ -94,10 +97,11 @@ template <class T>
 struct MatT {
     T lambda, mu, Y, S, D, K, yc[19], Q[9];
     const double* nn;
-    int nn_seed;
+    int nn_seed, nn_seed2;           // packed-weight index carrying the (first / second) derivative direction, or -1
     CM_D T nn_at(int i) const {
         T w = t_const<T>(nn[i]);
         if (i == nn_seed) t_seed(w);
+        if (i == nn_seed2) t_seed2(w);
         return w;
     }
 };
@@ -109,7 +113,7 @@ CM_D void mat_from_desc(const cm_model_desc& m, MatT<T>& p) {
     p.S = t_const<T>(m.voce_S); p.D = t_const<T>(m.voce_D); p.K = t_const<T>(m.lin_K);
     for (int k = 0; k < 19; ++k) p.yc[k] = t_const<T>(m.yc[k]);
     for (int k = 0; k < 9; ++k) p.Q[k] = t_const<T>(m.Q[k]);
-    p.nn = m.nn_weights; p.nn_seed = -1;
+    p.nn = m.nn_weights; p.nn_seed = -1; p.nn_seed2 = -1;
 }
 
 // Extended parameter ("EP") index of the sensitivities beyond the 12 of cm_param_index: 0..11 = KP order,
@@ -640,22 +644,35 @@ CM_D void model_eval_T(const cm_model_desc& m, const MatT<T>& p, const double* G
 template <int DEF, int YK, bool ROT, int MK = CM_SMALL_ELASTIC_PLASTIC>
 CM_D void hessian_pair(const cm_model_desc& m, const double* G, const double* xv, const double* xpv, int a, int b,
                        double* out_C, double* out_S, double* out_Ca, double* out_Sa,
-                       double* out_C0 = nullptr, double* out_S0 = nullptr, double* out_Sb = nullptr) {
+                       double* out_C0 = nullptr, double* out_S0 = nullptr, double* out_Sb = nullptr,
+                       const int32_t* ep_index = nullptr) {
     constexpr int NX = nx_of<DEF, MK>();
     HD x[NX], xp[NX], C[NX], sg[6];
     MatT<HD> p;
     mat_from_desc<HD>(m, p);
     for (int k = 0; k < NX; ++k) { x[k] = hd(xv[k]); xp[k] = hd(xpv[k]); }
-    // q = [xi, xi_prev, p (KP)]: direction a in the first derivative slot, b in the second
-    auto slot = [&](int i) -> HD& {
-        if (i < NX) return x[i];
-        if (i < 2 * NX) return xp[i - NX];
-        const int e = i - 2 * NX;
-        return e == CM_P_LAMBDA ? p.lambda : e == CM_P_MU ? p.mu : e == CM_P_Y ? p.Y : e == CM_P_VOCE_S ? p.S :
-               e == CM_P_VOCE_D ? p.D : e == CM_P_LIN_K ? p.K : p.yc[e - CM_P_YC0];
+    // q = [xi, xi_prev, p (KP), extended parameters ep_index[0 .. n_ep)]: direction a in the first derivative slot, b in the second
+    auto seed = [&](int i, bool second) {
+        HD* t = nullptr;
+        if (i < NX) t = &x[i];
+        else if (i < 2 * NX) t = &xp[i - NX];
+        else {
+            int e = i - 2 * NX;
+            if (e >= CM_NUM_PARAMS) e = ep_index[e - CM_NUM_PARAMS];          // EP index (mat_seed): yc[6..18], Q, network weights
+            if (e == CM_P_LAMBDA) t = &p.lambda;
+            else if (e == CM_P_MU) t = &p.mu;
+            else if (e == CM_P_Y) t = &p.Y;
+            else if (e == CM_P_VOCE_S) t = &p.S;
+            else if (e == CM_P_VOCE_D) t = &p.D;
+            else if (e == CM_P_LIN_K) t = &p.K;
+            else if (e < CM_EP_Q0) t = &p.yc[e - CM_P_YC0];
+            else if (e < CM_EP_NN0) t = &p.Q[e - CM_EP_Q0];
+            else { if (second) p.nn_seed2 = e - CM_EP_NN0; else p.nn_seed = e - CM_EP_NN0; }
+        }
+        if (t) { if (second) t->b = 1.0; else t->a = 1.0; }
     };
-    slot(a).a = 1.0;
-    slot(b).b = 1.0;
+    seed(a, false);
+    seed(b, true);
     model_eval_T<DEF, YK, MK, HD>(m, p, G, x, xp, C, sg);
     for (int k = 0; k < NX; ++k) { out_C[k] = C[k].ab; out_Ca[k] = C[k].a; }
     for (int k = 0; k < 6; ++k) { out_S[k] = sg[k].ab; out_Sa[k] = sg[k].a; }
@@ -690,14 +707,56 @@ CM_D void param_direction(const cm_model_desc& m, const double* G, const double*
 // cmad/objectives/mp_objective.py:255-281.  G: grad u (rate form: grad u - grad u_prev).
 template <int DEF, int YK, bool ROT, int MK>
 CM_D double hessian_weight(const cm_model_desc& m, const double* G, const double* x, const double* xp, const double* lam,
-                           const double sbar[6], const double hss[6], int a, int b) {
+                           const double sbar[6], const double hss[6], int a, int b, const int32_t* ep_index = nullptr) {
     constexpr int NX = nx_of<DEF, MK>();
     double oC[NX], oS[6], oCa[NX], oSa[6], oSb[6];
-    hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa, nullptr, nullptr, oSb);
+    hessian_pair<DEF, YK, ROT, MK>(m, G, x, xp, a, b, oC, oS, oCa, oSa, nullptr, nullptr, oSb, ep_index);
     double w = 0.0;
     for (int k = 0; k < NX; ++k) w -= lam[k] * oC[k];
     for (int r = 0; r < 6; ++r) w += sbar[r] * oS[r] + hss[r] * oSa[r] * oSb[r];
     return w;
+}
+
+// ---- forward sensitivity column of one EXTENDED parameter (EP index e) at a converged step ---------------------------------
+// d = dxi/dp_e = -A^-1 (dC/dp_e + dC/dxi_prev d_prev): cm::direct_column with the parameter column taken from the forward-mode
+// evaluation of the whole model (param_direction) instead of the closed-form block -- what the second-order pass needs for the
+// leaves outside the 12 native parameters (D_k = dq_k/dp in cm_hessian_history_ep).  FULL_3D / PLANE_STRESS / UNIAXIAL_STRESS
+// (total form), FULL_3D / PLANE_STRESS (rate form).
+template <int MK, int DEF, int YK, bool ROT>
+CM_D bool direct_column_ep(const cm_model_desc& m, const double* G, const double* Gp, const double* x, const double* xp, int e,
+                           const double* d_prev, double* d) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    static_assert(!(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && DEF == CM_UNIAXIAL_STRESS), "12-dof rate form: not built");
+    double C[NX], sg[6], rhs[NX], dS[6], Geff[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) Geff[k] = (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) ? G[k] - Gp[k] : G[k];
+    param_direction<DEF, YK, MK>(m, Geff, x, xp, e, rhs, dS);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rhs[i] = -rhs[i];
+    if (d_prev) {
+        double Axp[NX * NX];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, CM_W_XI_PREV, C, Axp, sg, nullptr);
+        else evaluate_blocks<DEF, YK, ROT>(m, G, x, xp, CM_W_XI_PREV, C, Axp, sg, nullptr);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) t += Axp[i * NX + k] * d_prev[k];
+            rhs[i] -= t;
+        }
+    }
+    double Ax[NX * NX], A[NX][NX];
+    if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) evaluate_blocks_rate<DEF, YK, ROT>(m, G, Gp, x, xp, CM_W_XI, C, Ax, sg, nullptr);
+    else evaluate_blocks<DEF, YK, ROT>(m, G, x, xp, CM_W_XI, C, Ax, sg, nullptr);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int k = 0; k < NX; ++k) A[i][k] = Ax[i * NX + k];
+    const bool ok = lu_factor<NX>(A);
+    lu_subst<NX>(A, rhs);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) d[i] = rhs[i];
+    return ok;
 }
 
 }  // namespace cm

@@ -1146,6 +1146,104 @@ __global__ __launch_bounds__(64) void k_hessian_weights(cm_model_desc m, int64_t
     W[(ps * NQ + b) * NQ + a] = w;
 }
 
+// ---- second-order pass including EXTENDED parameters (cm_direct_history_ep, cm_hessian_history_ep) -------------------------
+// q = [xi_k, xi_{k-1}, p (12 native), pe (n_ep extended)], NQ = 2 NX + 12 + n_ep (run time), D_k = dq/d[p, pe].
+template <int DEF, int YK, bool ROT, int MK>
+__global__ __launch_bounds__(64) void k_direct_history_ep(cm_model_desc m, int64_t B, int K, int n_ep, const int32_t* __restrict__ ep_index,
+        const double* __restrict__ gradu_hist, const double* __restrict__ xi_hist, double* __restrict__ dxe_hist) {
+    constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * n_ep) return;
+    const int64_t b = tid % B;
+    const int j = (int)(tid / B), e = ep_index[j];
+    double d[NX], dn[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) { d[k] = 0.0; dxe_hist[(int64_t)(k * n_ep + j) * B + b] = 0.0; }        // slot 0
+    for (int step = 1; step <= K; ++step) {
+        double G[NU], Gp[NU], xp[NX], x[NX];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            G[k] = gradu_hist[((int64_t)step * NU + k) * B + b];
+            Gp[k] = gradu_hist[((int64_t)(step - 1) * NU + k) * B + b];
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            x[k] = xi_hist[((int64_t)step * NX + k) * B + b];
+            xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + b];
+        }
+        direct_column_ep<MK, DEF, YK, ROT>(m, G, Gp, x, xp, e, step > 1 ? d : nullptr, dn);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) { dxe_hist[((int64_t)step * NX * n_ep + k * n_ep + j) * B + b] = dn[k]; d[k] = dn[k]; }
+    }
+}
+
+template <int DEF, int YK, bool ROT, int MK>
+__global__ __launch_bounds__(64) void k_hessian_weights_ep(cm_model_desc m, int64_t B, int K, int n_ep, const int32_t* __restrict__ ep_index,
+        const double* __restrict__ gradu_hist, const double* __restrict__ xi_hist, const double* __restrict__ lam_hist,
+        const double* __restrict__ sbar_hist, Wsq hss, const double* __restrict__ hss_hist, const double* __restrict__ hxx_hist,
+        double* __restrict__ W) {
+    constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU;
+    const int NQ = 2 * NX + CM_NUM_PARAMS + n_ep, NPAIR = NQ * (NQ + 1) / 2;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= B * K * NPAIR) return;
+    const int64_t ps = tid / NPAIR;
+    const int64_t pt = ps % B;
+    const int step = (int)(ps / B) + 1;
+    int rem = (int)(tid % NPAIR), a = 0;
+    while (rem >= NQ - a) { rem -= NQ - a; ++a; }
+    const int b = a + rem;
+    double G[NU], xp[NX], x[NX], lam[NX], sbar[6], hs[6];
+    for (int k = 0; k < NU; ++k) {
+        G[k] = gradu_hist[((int64_t)step * NU + k) * B + pt];
+        if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_hist[((int64_t)(step - 1) * NU + k) * B + pt];
+    }
+    for (int k = 0; k < NX; ++k) {
+        xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + pt];
+        x[k] = xi_hist[((int64_t)step * NX + k) * B + pt];
+        lam[k] = lam_hist[((int64_t)step * NX + k) * B + pt];
+    }
+    for (int r = 0; r < 6; ++r) { sbar[r] = sbar_hist[((int64_t)step * 6 + r) * B + pt]; hs[r] = hss_hist ? hss_hist[step * 6 + r] : hss.w[r]; }
+    double w = hessian_weight<DEF, YK, ROT, MK>(m, G, x, xp, lam, sbar, hs, a, b, ep_index);
+    if (hxx_hist && a == b && a < NX) w += hxx_hist[step * NX + a];
+    W[(ps * NQ + a) * NQ + b] = w;
+    W[(ps * NQ + b) * NQ + a] = w;
+}
+
+// part[ps][i][j] = sum_ab D[a][i] W[a][b] D[b][j] over NPT = 12 + n_ep parameter directions; dynamic LDS: W (NQ x NQ), D (NQ x NPT)
+template <int NX>
+__global__ __launch_bounds__(256) void k_hessian_quadform_ep(int64_t B, int K, int n_ep, const double* __restrict__ W,
+        const double* __restrict__ dx_dp_hist, const double* __restrict__ dxe_hist, double* __restrict__ part) {
+    extern __shared__ double sm[];
+    constexpr int NP_ = CM_NUM_PARAMS;
+    const int NPT = NP_ + n_ep, NQ = 2 * NX + NPT;
+    double* sW = sm;
+    double* sD = sm + NQ * NQ;
+    const int64_t ps = blockIdx.x, pt = ps % B;
+    const int step = (int)(ps / B) + 1;
+    for (int i = threadIdx.x; i < NQ * NQ; i += 256) sW[i] = W[ps * NQ * NQ + i];
+    for (int i = threadIdx.x; i < NQ * NPT; i += 256) {
+        const int r = i / NPT, j = i % NPT;
+        double v;
+        if (r < 2 * NX) {
+            const int st = (r < NX) ? step : step - 1, rr = (r < NX) ? r : r - NX;
+            v = (j < NP_) ? dx_dp_hist[(((int64_t)st * NX + rr) * NP_ + j) * B + pt]
+                          : dxe_hist[(((int64_t)st * NX + rr) * n_ep + (j - NP_)) * B + pt];
+        } else v = (r - 2 * NX == j) ? 1.0 : 0.0;
+        sD[i] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < NPT * NPT; o += 256) {
+        const int i = o / NPT, j = o % NPT;
+        double acc = 0.0;
+        for (int a = 0; a < NQ; ++a) {
+            double t = 0.0;
+            for (int b = 0; b < NQ; ++b) t += sW[a * NQ + b] * sD[b * NPT + j];
+            acc += sD[a * NPT + i] * t;
+        }
+        part[ps * (NPT * NPT) + o] = acc;
+    }
+}
+
 template <int NX>
 __global__ __launch_bounds__(192) void k_hessian_quadform(int64_t B, int K, const double* __restrict__ W,
         const double* __restrict__ dx_dp_hist, double* __restrict__ part) {
@@ -1715,6 +1813,62 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
 
 
 #if CM_HAS_PART(9)
+constexpr int kMaxEp = 64;           // extended parameter directions per second-order pass (dynamic LDS of the quadratic form)
+template <int MK>
+int launch_direct_history_ep(const cm_model_desc* m, int64_t B, int K, int n_ep, const int32_t* ep_index, const double* gradu_hist,
+                             const double* xi_hist, double* dxe_hist, void* stream) {
+    if (!m || B < 0 || K < 1 || n_ep < 0 || n_ep > kMaxEp) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS)) return CM_ERR_UNSUPPORTED;
+    if (B == 0 || n_ep == 0) return CM_OK;
+    if (!ep_index || !gradu_hist || !xi_hist || !dxe_hist) return CM_ERR_BAD_ARG;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((B * n_ep + 63) / 64)), block(64);
+    const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+        if constexpr (!(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS) && has_rate_dense<MK, Y>())
+            hipLaunchKernelGGL((k_direct_history_ep<D, Y, kColdRot, MK>), grid, block, 0, s, md, B, K, n_ep, ep_index, gradu_hist, xi_hist, dxe_hist);
+    });
+    if (!found) return CM_ERR_UNSUPPORTED;
+    return check_launch();
+}
+
+template <int MK>
+int launch_hessian_history_ep(const cm_model_desc* m, int64_t B, int K, int n_ep, const int32_t* ep_index, const double* gradu_hist,
+                              const double* xi_hist, const double* lam_hist, const double* dx_dp_hist, const double* dxe_hist,
+                              const double* sbar_hist, const double* hss6, const double* hss_hist, const double* hxx_hist,
+                              double* out, void* workspace, int64_t wbytes, void* stream) {
+    if (!m || B < 0 || K < 1 || n_ep < 0 || n_ep > kMaxEp || !out || !workspace || (!hss6 && !hss_hist)) return CM_ERR_BAD_ARG;
+    if (!supported(m, MK) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && m->def_type == CM_UNIAXIAL_STRESS)) return CM_ERR_UNSUPPORTED;
+    if (B > 0 && (!gradu_hist || !xi_hist || !lam_hist || !dx_dp_hist || !sbar_hist || (n_ep > 0 && (!ep_index || !dxe_hist)))) return CM_ERR_BAD_ARG;
+    if (wbytes < cm_hessian_ep_workspace_bytes(m, B, K, n_ep)) return CM_ERR_WORKSPACE;
+    const int nx = cm_num_xi(m), npt = CM_NUM_PARAMS + n_ep, nq = 2 * nx + npt;
+    const int64_t nps = B * (int64_t)K;
+    double* W = (double*)workspace;
+    double* part = W + nps * nq * nq;
+    Wsq h; for (int k = 0; k < 6; ++k) h.w[k] = hss6 ? hss6[k] : 0.0;
+    const cm_model_desc md = *m;
+    (void)hipGetLastError();
+    hipStream_t s = (hipStream_t)stream;
+    if (nps > 0) {
+        const int64_t nthreads = nps * (int64_t)(nq * (nq + 1) / 2);
+        const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
+        const size_t lds = (size_t)(nq * nq + nq * npt) * sizeof(double);
+        const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
+            if constexpr (!(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS) && has_rate_dense<MK, Y>()) {
+                hipLaunchKernelGGL((k_hessian_weights_ep<D, CM_YIELD_ANY, kColdRot, MK>), grid, block, 0, s, md, B, K, n_ep, ep_index, gradu_hist,
+                                   xi_hist, lam_hist, sbar_hist, h, hss_hist, hxx_hist, W);
+                hipLaunchKernelGGL((k_hessian_quadform_ep<nx_of<D, MK>()>), dim3((unsigned)nps), dim3(256), lds, s, B, K, n_ep, W, dx_dp_hist,
+                                   dxe_hist, part);
+            }
+        });
+        if (!found) return CM_ERR_UNSUPPORTED;
+        if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)((npt * npt + 255) / 256)), dim3(256), 0, s, part, nps, npt * npt, out);
+    return check_launch();
+}
+
 template <int MK>
 int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu,
                         const double* gradu_prev, const double* xi_prev, const double* xi, double* dC, double* dS, void* stream) {
@@ -1898,6 +2052,13 @@ int64_t cm_direct_workspace_bytes(int64_t B) {
     if (B < 0) return CM_ERR_BAD_ARG;
     return ((B > 0 ? B : 1) + kRedBlocks + 1) * kRed * (int64_t)sizeof(double);      // one row per point + stage rows
 }
+int64_t cm_hessian_ep_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep) {
+    if (!m || B < 0 || K < 1 || n_ep < 0) return CM_ERR_BAD_ARG;
+    const int nx = cm_num_xi(m);
+    if (nx < 0) return CM_ERR_UNSUPPORTED;
+    const int64_t npt = CM_NUM_PARAMS + n_ep, nq = 2 * nx + npt, nps = (B > 0 ? B : 1) * (int64_t)K;
+    return nps * (nq * nq + npt * npt) * (int64_t)sizeof(double);
+}
 int64_t cm_hessian_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K) {
     if (!m || B < 0 || K < 1) return CM_ERR_BAD_ARG;
     const int nx = cm_num_xi(m);
@@ -1935,6 +2096,25 @@ int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K, const doubl
 #endif
 
 #if CM_HAS_PART(9)
+int cm_direct_history_ep(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
+                         const double* gradu_hist, const double* xi_hist, double* dxi_dpe_hist, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return launch_direct_history_ep<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, n_ep, ep_index, gradu_hist, xi_hist, dxi_dpe_hist, stream);
+    return launch_direct_history_ep<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, n_ep, ep_index, gradu_hist, xi_hist, dxi_dpe_hist, stream);
+}
+int cm_hessian_history_ep(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
+                          const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* dxi_dp_hist,
+                          const double* dxi_dpe_hist, const double* sigma_bar_hist, const double* hss6, const double* hss_hist,
+                          const double* hxx_hist, double* hess, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!m) return CM_ERR_BAD_ARG;
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return launch_hessian_history_ep<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, K, n_ep, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist,
+                                                                        dxi_dpe_hist, sigma_bar_hist, hss6, hss_hist, hxx_hist, hess, workspace,
+                                                                        workspace_bytes, stream);
+    return launch_hessian_history_ep<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, n_ep, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxi_dpe_hist,
+                                                               sigma_bar_hist, hss6, hss_hist, hxx_hist, hess, workspace, workspace_bytes, stream);
+}
 int cm_param_blocks(const cm_model_desc* m, int64_t B, int32_t n_ep, const int32_t* ep_index,
                     const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                     double* dC_dp, double* dsigma_dp, void* stream) {

@@ -657,6 +657,44 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_hessian_history")
         return H
 
+    def direct_history_ep(self, ep_index, gradu_hist, xi_hist):
+        """`cm_direct_history_ep`: forward sensitivities dxi_k/dp_e of the extended parameters over a stored history,
+        (K+1, n_xi, n_ep, B) device tensor."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        self._check_hist(gradu_hist, self.nu, K, B, "gradu_hist")
+        self._check_hist(xi_hist, self.nx, K, B, "xi_hist")
+        dev = gradu_hist.device
+        ep = torch.tensor([int(e) for e in ep_index], dtype=torch.int32, device=dev)
+        dxe = torch.empty((K + 1, self.nx, len(ep_index), B), dtype=torch.float64, device=dev)
+        rc = self.L.cm_direct_history_ep(C.byref(self.desc), B, K, len(ep_index), _ptr(ep), _ptr(gradu_hist), _ptr(xi_hist), _ptr(dxe),
+                                         self._stream())
+        _lib.check(rc, "cm_direct_history_ep")
+        return dxe
+
+    def hessian_history_ep(self, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxi_dpe_hist, sigma_bar_hist, hss, hxx=None):
+        """`cm_hessian_history_ep`: d2J/d[p, pe]2, (12 + n_ep, 12 + n_ep) device tensor (native parameters first, KP order)."""
+        torch = _torch()
+        K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
+        ne = len(ep_index)
+        npt = _lib.CM_NUM_PARAMS + ne
+        dev = gradu_hist.device
+        ep = torch.tensor([int(e) for e in ep_index], dtype=torch.int32, device=dev)
+        H = torch.empty((npt, npt), dtype=torch.float64, device=dev)
+        need = self.L.cm_hessian_ep_workspace_bytes(C.byref(self.desc), B, K, ne)
+        if need < 0:
+            _lib.check(int(need), "cm_hessian_ep_workspace_bytes")
+        ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
+        hss = np.asarray(hss, dtype=np.float64)
+        h6 = (C.c_double * 6)(*[float(v) for v in hss]) if hss.ndim == 1 else None
+        hs_dev = None if hss.ndim == 1 else torch.from_numpy(np.ascontiguousarray(hss)).to(dev)
+        hx_dev = None if hxx is None else torch.from_numpy(np.ascontiguousarray(hxx, dtype=np.float64)).to(dev)
+        rc = self.L.cm_hessian_history_ep(C.byref(self.desc), B, K, ne, _ptr(ep), _ptr(gradu_hist), _ptr(xi_hist), _ptr(lam_hist),
+                                          _ptr(dxi_dp_hist), _ptr(dxi_dpe_hist), _ptr(sigma_bar_hist), h6, _ptr(hs_dev), _ptr(hx_dev),
+                                          _ptr(H), _ptr(ws), need, self._stream())
+        _lib.check(rc, "cm_hessian_history_ep")
+        return H
+
     def param_blocks(self, ep_index, gradu, xi_prev, xi, gradu_prev=None):
         """`cm_param_blocks`: (dC_dp (n_ep, n_xi, B), dsigma_dp (n_ep, 6, B)) for the extended parameter indices."""
         torch = _torch()

@@ -8,6 +8,7 @@ axis is last, B = 1 for the reference's material-point drivers, any B for batche
     adjoint      cm_adjoint_history           the adjoint recursion for any QoI (the caller supplies dJ/dsigma, dJ/dxi)
     direct       cm_direct_history            the forward-sensitivity recursion + gradient contraction
     hessian      cm_hessian_history           the second-order (direct-adjoint) quadratic form
+    direct_ep, hessian_ep  cm_direct_history_ep, cm_hessian_history_ep  the same with leaves outside the 12 native parameters
     extended     cm_param_adjoint_history     gradient share of the leaves differentiated by forward-mode evaluation
 
 There is no CPU implementation behind it.  tests/host_facade.py substitutes a host build of the same kernel arithmetic
@@ -64,6 +65,16 @@ class HistoryEngine:
     def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss, hxx=None):
         H = self._ev.hessian_history(self._dev(gradu_hist, "g"), self._dev(xi_hist), self._dev(lam_hist), self._dev(dxi_dp_hist),
                                      self._dev(sbar_hist), hss, hxx)
+        return H.cpu().numpy()
+
+    def direct_ep(self, ep_index, gradu_hist, xi_hist):
+        """cm_direct_history_ep: (K+1, n_xi, n_ep, B) forward sensitivities of the extended parameters."""
+        return self._ev.direct_history_ep(ep_index, self._dev(gradu_hist, "g"), self._dev(xi_hist)).cpu().numpy()
+
+    def hessian_ep(self, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxi_dpe_hist, sbar_hist, hss, hxx=None):
+        """cm_hessian_history_ep: (12 + n_ep, 12 + n_ep) Hessian, native parameters first."""
+        H = self._ev.hessian_history_ep(ep_index, self._dev(gradu_hist, "g"), self._dev(xi_hist), self._dev(lam_hist),
+                                        self._dev(dxi_dp_hist), self._dev(dxi_dpe_hist), self._dev(sbar_hist), hss, hxx)
         return H.cpu().numpy()
 
     def extended(self, ep_index, gradu_hist, xi_hist, lam_hist, sbar_hist):

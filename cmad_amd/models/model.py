@@ -95,11 +95,19 @@ class Model(ABC):
         x0 = np.concatenate([np.atleast_1d(np.asarray(b, dtype=np.float64)) for b in self._init_xi])
         return np.repeat(x0[:, None], B, axis=1)
 
-    def active_hessian_from_kp(self, H_kp, g_kp, info=None):
-        """Kernel-order Hessian (12, 12) + gradient (12,) -> Hessian w.r.t. the NATIVE active parameters: the chain rule
-        through the elastic-constant map (lambda, mu)(E, nu, ...) adds sum_kp g_kp d2 kp / dp_i dp_j."""
+    def active_hessian_from_kp(self, H_kp, g_kp, info=None, ext=None):
+        """Kernel-order Hessian + gradient (12,) -> Hessian w.r.t. the NATIVE active parameters: the chain rule through the
+        elastic-constant map (lambda, mu)(E, nu, ...) adds sum_kp g_kp d2 kp / dp_i dp_j.  With `ext` = `extended_active()`
+        the Hessian is (12 + n_ext)^2 (cm_hessian_history_ep: native parameters first, then the extended leaves in `ext`
+        order); each extended leaf IS an active parameter (identity column)."""
         info = info or self._desc()[1]
-        T1, T2 = self._param_chain(info)
+        ext = ext or []
+        T1, T2 = self._param_chain(info, skip={pos for pos, _ in ext})
+        if ext:
+            E = np.zeros((len(ext), T1.shape[1]))
+            for i, (pos, _) in enumerate(ext):
+                E[i, pos] = 1.0
+            T1 = np.vstack([T1, E])
         return T1.T @ np.asarray(H_kp) @ T1 + np.einsum("k,kij->ij", np.asarray(g_kp), T2)
 
     @staticmethod
@@ -200,7 +208,7 @@ class Model(ABC):
             self._Jac = J
 
     # ------------------------------------------------------------------ reference :245-270
-    def _param_chain(self, info):
+    def _param_chain(self, info, skip=()):
         """First- and second-order maps from the kernel's KP parameters to the active parameters:
         T1[kp, i] = d kp / d p_i ; T2[kp, i, j] = d2 kp / d p_i d p_j (non-zero only for lambda, mu)."""
         from .elastic_constants import lame_second_derivs
@@ -211,6 +219,8 @@ class Model(ABC):
         names, H = lame_second_derivs(self.parameters.values["elastic"])
         el_pos = {}
         for i, path in enumerate(paths):
+            if i in skip:                                    # an extended leaf: no native kernel parameter depends on it
+                continue
             unit = np.zeros(_lib.CM_NUM_PARAMS)
             for kp in range(_lib.CM_NUM_PARAMS):
                 unit[:] = 0.0; unit[kp] = 1.0

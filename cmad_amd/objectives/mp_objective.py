@@ -10,7 +10,9 @@ objective here is a fixed, small number of launches over the WHOLE history (`Mod
                               any other QoI   : 2 launches cm_update_history -> qoi.history_cotangents -> cm_adjoint_history
     MPDirectObjective         2 launches      cm_update_history -> qoi.history_cotangents -> cm_direct_history
     MPDirectAdjointObjective  4 launches      cm_update_history, cm_adjoint_history (keeps lam_k), cm_direct_history
-                                              (keeps dxi_k/dp), cm_hessian_history (sum_k D_k^T W_k D_k)
+                                              (keeps dxi_k/dp), cm_hessian_history (sum_k D_k^T W_k D_k); with active leaves
+                                              outside the 12 native parameters: + cm_param_adjoint_history, cm_direct_history_ep,
+                                              and cm_hessian_history_ep in place of cm_hessian_history
 
 The QoI differentiates only its own formula (dJ/dsigma, explicit dJ/dxi, diagonal curvature in sigma); the model
 derivatives, the recursions over the steps and the reductions happen in the kernels.  Sensitivities leave the kernels
@@ -119,14 +121,19 @@ class MPDirectAdjointObjective(MPObjective):
         qoi, model = self._qoi, self._model
         hss, hxx = qoi.stress_curvature(), qoi.state_curvature()
         xi0, xi_hist, J, sbar, xibar = self._primal_and_cotangents(engine)
-        if model.extended_active(engine.info):
-            raise NotImplementedError("second-order sensitivities cover the 12 native parameters (no rotation matrix, Hosford "
-                                      "exponent, network-surface coefficients or weights)")
+        ext = model.extended_active(engine.info)      # leaves outside the 12 native parameters (rotation matrix, Hosford exponent, ...)
         g_kp, lam_hist = engine.adjoint(self._gradu_hist, sbar, xi0, xibar, want_lam=True)
         _, dxi_dp_hist = engine.direct(self._gradu_hist, xi_hist, sbar, xibar, want_blocks=True)
-        H_kp = engine.hessian(self._gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar, hss, hxx)
-        grad, native_grad = self._canonical_gradient(g_kp, engine.info)
-        hessian = model.active_hessian_from_kp(H_kp, g_kp, engine.info)
+        g_ext = None
+        if ext:
+            ep = [e for _, e in ext]
+            g_ext = self._extended_gradient(engine, xi0, xi_hist, sbar, xibar, lam_hist)
+            dxe_hist = engine.direct_ep(ep, self._gradu_hist, xi_hist)
+            H_kp = engine.hessian_ep(ep, self._gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxe_hist, sbar, hss, hxx)
+        else:
+            H_kp = engine.hessian(self._gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar, hss, hxx)
+        grad, native_grad = self._canonical_gradient(g_kp, engine.info, g_ext)
+        hessian = model.active_hessian_from_kp(H_kp, g_kp, engine.info, ext)
         hessian = 0.5 * (hessian + hessian.T)
         self._parameters.transform_hessian(hessian, native_grad)
         return HessianResult(J=float(J), grad=grad, hessian=hessian)

@@ -441,6 +441,28 @@ int cm_hessian_history(const cm_model_desc* m, int64_t B, int32_t K,
                        double* hess_pp, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * The second-order pass including parameter-tree leaves OUTSIDE the 12 native parameters (rotation matrix, Hosford exponent,
+ * Barlat / network-surface coefficients, network weights: "EP" indices as cm_param_blocks; reference: Model.evaluate_hessians
+ * takes Hessians over the whole params pytree, cmad/models/model.py:133-147, which MPDirectAdjointObjective contracts,
+ * cmad/objectives/mp_objective.py:218-345).
+ * cm_direct_history_ep: forward sensitivities dxi_k/dp_e of the requested extended parameters over a stored history
+ *   (the recursion of cm_direct_history with the parameter column from forward-mode evaluation of the model):
+ *   out dxi_dpe_hist[(K+1)][n_xi*n_ep][B], entry (i, j) of step k at row k*n_xi*n_ep + i*n_ep + j (slot 0 = 0).
+ * cm_hessian_history_ep: cm_hessian_history over q = [xi_k, xi_{k-1}, p (12), pe (n_ep)]:
+ *   hess[(12 + n_ep)^2] row-major, native parameters first (KP order), then the extended ones in ep_index order;
+ *   n_ep = 0 reproduces cm_hessian_history.  ep_index: DEVICE int32[n_ep], n_ep <= 64.
+ *   workspace: cm_hessian_ep_workspace_bytes(m, B, K, n_ep).
+ * Total form: every deformation type; rate form: FULL_3D / PLANE_STRESS.
+ */
+int64_t cm_hessian_ep_workspace_bytes(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep);
+int cm_direct_history_ep(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
+                         const double* gradu_hist, const double* xi_hist, double* dxi_dpe_hist, void* stream);
+int cm_hessian_history_ep(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
+                          const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* dxi_dp_hist,
+                          const double* dxi_dpe_hist, const double* sigma_bar_hist, const double* hss6, const double* hss_hist,
+                          const double* hxx_hist, double* hess, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Extended parameter sensitivities.  The hand-derived kernels differentiate w.r.t. the 12 native parameters of
  * cm_param_index; the reference differentiates w.r.t. EVERY leaf of the params pytree (jacrev in cmad/models/model.py:125-153,
  * flattened by cmad/parameters/parameters.py:368-377).  The remaining leaves -- rotation matrix, Hosford exponent, Barlat

@@ -37,6 +37,12 @@ class HostHistoryEngine:
     def hessian(self, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss, hxx=None):
         return hh.hessian_history(self._desc, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, sbar_hist, hss, hxx)
 
+    def direct_ep(self, ep_index, gradu_hist, xi_hist):
+        return hh.direct_history_ep(self._desc, ep_index, gradu_hist, xi_hist)
+
+    def hessian_ep(self, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxi_dpe_hist, sbar_hist, hss, hxx=None):
+        return hh.hessian_history_ep(self._desc, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxi_dpe_hist, sbar_hist, hss, hxx)
+
     def extended(self, ep_index, gradu_hist, xi_hist, lam_hist, sbar_hist):
         K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
         g = np.zeros(len(ep_index))

@@ -180,6 +180,45 @@ def hessian_history(desc, gradu_hist, xi_hist, lam_hist, dx_dp_hist, sbar_hist, 
     return H
 
 
+def direct_history_ep(desc, ep_index, gradu_hist, xi_hist):
+    """cm_direct_history_ep on the host build: dxi_dpe_hist (K+1, nx, n_ep, B)."""
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu_hist, xi_hist = c(gradu_hist), c(xi_hist)
+    ep = np.ascontiguousarray(ep_index, dtype=np.int32)
+    K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
+    dxe = np.zeros((K + 1, nx, len(ep), B))
+    rc = L.hh_direct_history_ep(C.byref(desc), C.c_int64(B), C.c_int(K), C.c_int(len(ep)), ep.ctypes.data_as(C.c_void_p),
+                                _p(gradu_hist), _p(xi_hist), _p(dxe))
+    assert rc == 0
+    return dxe
+
+
+def hessian_history_ep(desc, ep_index, gradu_hist, xi_hist, lam_hist, dx_dp_hist, dxe_hist, sbar_hist, hss, hxx=None):
+    """cm_hessian_history_ep on the host build: stage 1 (W per point and step, NQ = 2 nx + 12 + n_ep) by cm::hessian_weight,
+    the quadratic form sum D^T W D in numpy.  Returns hess (12 + n_ep, 12 + n_ep), native parameters first."""
+    L = lib()
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    gradu_hist, xi_hist, lam_hist, dx_dp_hist, dxe_hist, sbar_hist, hss = map(c, (gradu_hist, xi_hist, lam_hist, dx_dp_hist, dxe_hist, sbar_hist, hss))
+    hxx = None if hxx is None else c(hxx)
+    ep = np.ascontiguousarray(ep_index, dtype=np.int32)
+    K, nx, B = xi_hist.shape[0] - 1, xi_hist.shape[1], xi_hist.shape[2]
+    npt = 12 + len(ep)
+    nq = 2 * nx + npt
+    W = np.zeros((K, B, nq, nq))
+    hss6, hss_hist = (hss, None) if hss.ndim == 1 else (None, hss)
+    rc = L.hh_hessian_weights_ep(C.byref(desc), C.c_int64(B), C.c_int(K), C.c_int(len(ep)), ep.ctypes.data_as(C.c_void_p), _p(gradu_hist),
+                                 _p(xi_hist), _p(lam_hist), _p(sbar_hist), _p(hss6), _p(hss_hist), _p(hxx), _p(W))
+    assert rc == 0
+    H = np.zeros((npt, npt))
+    for k in range(1, K + 1):
+        for b in range(B):
+            D = np.vstack([np.hstack([dx_dp_hist[k, :, :, b], dxe_hist[k, :, :, b]]),
+                           np.hstack([dx_dp_hist[k - 1, :, :, b], dxe_hist[k - 1, :, :, b]]), np.eye(npt)])
+            H += D.T @ W[k - 1, b] @ D
+    return H
+
+
 def param_blocks(desc, ep_index, gradu, xi_prev, xi, nx, gradu_prev=None, info=None):
     """cm_param_blocks on the host build: dC_dp (n_ep, nx, B), dsigma_dp (n_ep, 6, B) for the extended parameter indices."""
     L = lib()

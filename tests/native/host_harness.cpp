@@ -563,6 +563,62 @@ int hh_hessian_weights(const cm_model_desc* m, int64_t B, int K, const double* g
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 #endif
+#if HH_HAS(4)
+// cm_direct_history_ep (cm::direct_column_ep over the steps): dxe_hist[(K+1)][NX*n_ep][B]
+int hh_direct_history_ep(const cm_model_desc* m, int64_t B, int K, int n_ep, const int32_t* ep_index, const double* gradu_hist,
+                         const double* xi_hist, double* dxe_hist) {
+    auto body = [&]<int D, int Y, bool R, int MK>() {
+        if constexpr (!(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS)) {
+            constexpr int NX = Dims<D>::NX, NU = Dims<D>::NU;
+            for (int64_t b = 0; b < B; ++b) for (int j = 0; j < n_ep; ++j) {
+                double d[NX], dn[NX];
+                for (int k = 0; k < NX; ++k) { d[k] = 0.0; dxe_hist[(int64_t)(k * n_ep + j) * B + b] = 0.0; }
+                for (int step = 1; step <= K; ++step) {
+                    double G[NU], Gp[NU], xp[NX], x[NX];
+                    for (int k = 0; k < NU; ++k) { G[k] = gradu_hist[((int64_t)step * NU + k) * B + b]; Gp[k] = gradu_hist[((int64_t)(step - 1) * NU + k) * B + b]; }
+                    for (int k = 0; k < NX; ++k) { x[k] = xi_hist[((int64_t)step * NX + k) * B + b]; xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + b]; }
+                    direct_column_ep<MK, D, Y, true>(*m, G, Gp, x, xp, ep_index[j], step > 1 ? d : nullptr, dn);
+                    for (int k = 0; k < NX; ++k) { dxe_hist[((int64_t)step * NX * n_ep + k * n_ep + j) * B + b] = dn[k]; d[k] = dn[k]; }
+                }
+            }
+        }
+    };
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+}
+// stage 1 of cm_hessian_history_ep: W[(step-1)*B + pt][NQ][NQ], NQ = 2 NX + 12 + n_ep
+int hh_hessian_weights_ep(const cm_model_desc* m, int64_t B, int K, int n_ep, const int32_t* ep_index, const double* gradu_hist,
+                          const double* xi_hist, const double* lam_hist, const double* sbar_hist, const double* hss6,
+                          const double* hss_hist, const double* hxx_hist, double* W) {
+    auto body = [&]<int D, int Y, bool R, int MK>() {
+        constexpr int NX = nx_of<D, MK>(), NU = Dims<D>::NU;
+        const int NQ = 2 * NX + CM_NUM_PARAMS + n_ep;
+        for (int step = 1; step <= K; ++step) for (int64_t pt = 0; pt < B; ++pt) {
+            double G[NU], xp[NX], x[NX], lam[NX], sbar[6], hs[6];
+            for (int k = 0; k < NU; ++k) {
+                G[k] = gradu_hist[((int64_t)step * NU + k) * B + pt];
+                if constexpr (MK == CM_SMALL_RATE_ELASTIC_PLASTIC) G[k] -= gradu_hist[((int64_t)(step - 1) * NU + k) * B + pt];
+            }
+            for (int k = 0; k < NX; ++k) {
+                xp[k] = xi_hist[((int64_t)(step - 1) * NX + k) * B + pt];
+                x[k] = xi_hist[((int64_t)step * NX + k) * B + pt];
+                lam[k] = lam_hist[((int64_t)step * NX + k) * B + pt];
+            }
+            for (int r = 0; r < 6; ++r) { sbar[r] = sbar_hist[((int64_t)step * 6 + r) * B + pt]; hs[r] = hss_hist ? hss_hist[step * 6 + r] : hss6[r]; }
+            const int64_t ps = (int64_t)(step - 1) * B + pt;
+            for (int a = 0; a < NQ; ++a) for (int b = a; b < NQ; ++b) {
+                double w = hessian_weight<D, CM_YIELD_ANY, true, MK>(*m, G, x, xp, lam, sbar, hs, a, b, ep_index);
+                if (hxx_hist && a == b && a < NX) w += hxx_hist[step * NX + a];
+                W[(ps * NQ + a) * NQ + b] = w; W[(ps * NQ + b) * NQ + a] = w;
+            }
+        }
+    };
+    if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
+        return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_RATE_ELASTIC_PLASTIC>(); });
+    return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, R, CM_SMALL_ELASTIC_PLASTIC>(); });
+}
+#endif
 #if HH_HAS(5)
 // cm_param_blocks (cm::param_direction per point and requested extended parameter)
 int hh_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu, const double* gradu_prev,

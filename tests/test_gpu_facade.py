@@ -914,3 +914,28 @@ def test_network_hardening_law_through_the_model_api():
     rrd = MPDirectObjective(rq, F).evaluate(x)
     np.testing.assert_allclose(rrd.grad, rra.grad, rtol=1e-8, atol=1e-10 * np.abs(rra.grad).max())
     np.testing.assert_allclose(rra.J, ra.J, rtol=1e-6)                                    # same material, two formulations
+
+
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True)])
+def test_direct_adjoint_hessian_with_extended_leaves(yield_kind, active_rotation):
+    """Second-order sensitivities w.r.t. leaves outside the 12 native kernel parameters -- the Hosford exponent, the nine
+    entries of the rotation matrix -- together with a native one (Y): the reference takes Hessians over the whole params pytree
+    (cmad/models/model.py:133-147 under cmad/objectives/mp_objective.py:218-345).  MPDirectAdjointObjective's gradient equals the
+    adjoint one; its Hessian is symmetric and matches central differences of the adjoint gradient."""
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectAdjointObjective
+    from problems import extended_leaf_problem
+    model, qoi, F = extended_leaf_problem(_models()[1], yield_kind, active_rotation)
+    x = model.parameters.flat_active_values(True)
+    J, grad, H = MPDirectAdjointObjective(qoi, F).evaluate(x)
+    ra = MPAdjointObjective(qoi, F).evaluate(x)
+    assert abs(J - ra.J) <= 1e-12 * abs(J)
+    np.testing.assert_allclose(grad, ra.grad, rtol=1e-9, atol=1e-11 * np.abs(ra.grad).max())
+    np.testing.assert_allclose(H, H.T, rtol=1e-8, atol=1e-9 * np.abs(H).max())
+    n = x.size
+    H_fd = np.zeros((n, n))
+    for k in range(n):
+        h = 1e-5 * max(1.0, abs(x[k]))
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        H_fd[:, k] = (MPAdjointObjective(qoi, F).evaluate(xp_).grad - MPAdjointObjective(qoi, F).evaluate(xm_).grad) / (2 * h)
+    np.testing.assert_allclose(H, H_fd, rtol=2e-4, atol=2e-5 * np.abs(H).max())
