@@ -33,14 +33,15 @@ def build(force=False, verbose=False, jobs=None):
         return LIB
     hipcc = hipcc_path()
     src = os.path.join(CSRC, SOURCES[0])
-    # two builds of every part (see the top of cmad_hip.hip): BASE (no network hardening law) and HNN (with it, without the dense
-    # yield surfaces); the heavy base parts first so that the short HNN parts fill the tail of the schedule
+    # two builds of every part (see the top of cmad_hip.hip): BASE (no network hardening law, one-hidden-layer networks) and EXT
+    # (network hardening law on J2 / Hill / Hosford; the plain hybrid surface with multi-layer networks; no rate form x dense
+    # surface); the heavy base parts first so that the shorter EXT parts fill the tail of the schedule
     objs = [os.path.join(CSRC, f"cmad_hip_part{k}.o") for k in range(NPARTS)] + \
            [os.path.join(CSRC, f"cmad_hip_hnn_part{k}.o") for k in range(NPARTS)]
     cmds = [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-c", src, "-o", objs[k]]
             for k in range(NPARTS)] + \
-           [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-DCM_HNN_VARIANT=1", "-c", src, "-o",
-             objs[NPARTS + k]] for k in range(NPARTS)]
+           [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-DCM_HNN_VARIANT=1", "-DCM_RATE_DENSE=0",
+             "-DCM_RATE_UNIAXIAL_DENSE=0", "-c", src, "-o", objs[NPARTS + k]] for k in range(NPARTS)]
     jobs = jobs or min(NPARTS, os.cpu_count() or 1)
     procs, failed = [], []
     pending = list(cmds)

@@ -24,6 +24,13 @@ using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::e
 #define CM_D __device__ __forceinline__
 #endif
 
+// CM_HNN = 1: this build carries the rarely used network features -- the network hardening law and input-convex networks with
+// more than one hidden layer (scratch-resident general evaluation).  The library's BASE build sets 0 (cmad_hip.hip: neither may
+// cost the common configurations an instruction or a register); its EXT build and the host build of the tests set 1.
+#ifndef CM_HNN
+#define CM_HNN 1
+#endif
+
 namespace cm {
 
 // Read-only, wave-uniform device data (the network weights): through the CONSTANT address space the loads are s_load_* into
@@ -382,6 +389,105 @@ CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6]
     }
 }
 
+// ---- input-convex network with any number of hidden layers [6, H1, ..., Hn, 1] -----------------------------------------------
+// cmad/neural_networks/input_convex_neural_network.py:58-69:  z_1 = softplus(x W0 + b_1),
+// z_{k+1} = softplus(z_k Wz_k + x Wx_{k+1} + b_{k+1}),  f = z_n wz_n + x wx_last + b_last.  Same contract as icnn_symmetric
+// (F = f(x) + f(-x) and its first two derivatives w.r.t. the scaled input), by one forward pass that keeps every unit's
+// softplus / sigmoid and the gradient of its pre-activation, one backward pass for nu_u = df/dz_u, and
+//     grad f = wx_last + sum_{u in layer n} wz_n[u] sigmoid(a_u) grad a_u ,
+//     hess f = sum_{all units u} nu_u sigmoid'(a_u) (grad a_u)(grad a_u)^T .
+// The per-unit arrays are indexed at run time (private memory): this is the general path, compiled only where CM_HNN = 1;
+// one hidden layer always takes icnn_symmetric.  Packed layout (the oracle's): x-layer k = 1 .. n+1: W[6][H_k], b[H_k]
+// (H_{n+1} = 1); z-layer k = 1 .. n: W[H_k][H_{k+1}]; scalers; f(0).
+constexpr int kIcnnMaxUnits = 64;        // hidden units of a multi-layer network, all layers together
+constexpr int kIcnnMaxLayers = 6;        // entries of nn_widths in use: 6, H1 .. Hn, 1 with n <= 4
+CM_D int icnn_deep_scalers_offset(const cm_model_desc& m) {
+    int off = 0;
+    for (int k = 1; k < m.nn_nlayers; ++k) off += 6 * m.nn_widths[k] + m.nn_widths[k];
+    for (int k = 1; k + 1 < m.nn_nlayers; ++k) off += m.nn_widths[k] * m.nn_widths[k + 1];
+    return off;
+}
+template <bool HESS>
+CM_D void icnn_symmetric_deep(const cm_model_desc& m, const double xs[6], double& F, double G[6], double Hx[21]) {
+    const cm_uniform_ptr w = uniform_ptr(m.nn_weights);
+    const int nl = m.nn_nlayers, nh = nl - 2;                  // hidden layers 1 .. nh
+    int xoff[kIcnnMaxLayers], zoff[kIcnnMaxLayers], uoff[kIcnnMaxLayers];   // x-layer k, z-layer k, first unit of layer k
+    {
+        int off = 0, u = 0;
+        for (int k = 1; k <= nh + 1; ++k) { xoff[k] = off; off += 7 * m.nn_widths[k]; }
+        for (int k = 1; k <= nh; ++k) { zoff[k] = off; off += m.nn_widths[k] * m.nn_widths[k + 1]; }
+        for (int k = 1; k <= nh; ++k) { uoff[k] = u; u += m.nn_widths[k]; }
+    }
+    F = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) G[i] = 0.0;
+    if constexpr (HESS) {
+#pragma unroll
+        for (int i = 0; i < 21; ++i) Hx[i] = 0.0;
+    }
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        const double sx = sgn ? -1.0 : 1.0;
+        double x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = sx * xs[i];
+        double spv[kIcnnMaxUnits], sgv[kIcnnMaxUnits], nu[kIcnnMaxUnits], Ja[kIcnnMaxUnits][6];
+        for (int k = 1; k <= nh; ++k) {                          // forward
+            const int Hk = m.nn_widths[k], Hp = (k > 1) ? m.nn_widths[k - 1] : 0;
+            for (int v = 0; v < Hk; ++v) {
+                double a = w[xoff[k] + 6 * Hk + v], J[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { J[i] = w[xoff[k] + i * Hk + v]; a += x[i] * J[i]; }
+                for (int u = 0; u < Hp; ++u) {
+                    const double wz = w[zoff[k - 1] + u * Hk + v], c = wz * sgv[uoff[k - 1] + u];
+                    a += wz * spv[uoff[k - 1] + u];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) J[i] += c * Ja[uoff[k - 1] + u][i];
+                }
+                const SoftUnit su = soft_unit(a);
+                spv[uoff[k] + v] = su.sp; sgv[uoff[k] + v] = su.sg;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Ja[uoff[k] + v][i] = J[i];
+            }
+        }
+        // output layer: value and gradient (the x . wx_last pass-through cancels between the two signs; kept for clarity)
+        const int Hn = m.nn_widths[nh];
+        double f = w[xoff[nh + 1] + 6], g[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { g[i] = w[xoff[nh + 1] + i]; f += x[i] * g[i]; }
+        for (int u = 0; u < Hn; ++u) {
+            const double wz = w[zoff[nh] + u];
+            f += wz * spv[uoff[nh] + u];
+            const double c = wz * sgv[uoff[nh] + u];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) g[i] += c * Ja[uoff[nh] + u][i];
+            nu[uoff[nh] + u] = wz;
+        }
+        F += f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) G[i] += sx * g[i];
+        if constexpr (HESS) {
+            for (int k = nh - 1; k >= 1; --k) {                  // backward: nu_u = df/dz_u
+                const int Hk = m.nn_widths[k], Hq = m.nn_widths[k + 1];
+                for (int u = 0; u < Hk; ++u) {
+                    double t = 0.0;
+                    for (int v = 0; v < Hq; ++v) t += w[zoff[k] + u * Hq + v] * nu[uoff[k + 1] + v] * sgv[uoff[k + 1] + v];
+                    nu[uoff[k] + u] = t;
+                }
+            }
+            const int ntot = uoff[nh] + Hn;
+            for (int u = 0; u < ntot; ++u) {
+                const double c2 = nu[u] * sgv[u] * (1.0 - sgv[u]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double ci = c2 * Ja[u][i];
+#pragma unroll
+                    for (int j = i; j < 6; ++j) Hx[sym6(i, j)] += ci * Ja[u][j];
+                }
+            }
+        }
+    }
+}
+
 // NN(flat dev s) of hybrid_hill_effective_stress (cmad/models/effective_stress.py:149-163) in the 6-vector
 // basis: value, d/ds6, d2/ds6 ds6.  NN input order is [xx,yy,zz,xy,xz,yz] of the deviator.
 // value, d/ds6 and (HESS) the second derivative written to the packed Hessian Hp
@@ -389,7 +495,8 @@ template <bool HESS>
 CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val, double g6[6], double Hp[21]) {
     const double* __restrict__ w = m.nn_weights;
     const int H = m.nn_widths[1];
-    const cm_uniform_ptr sc = uniform_ptr(w) + icnn_off_scalers(H);   // in_scale[6], in_min[6], out_scale, out_min, f0
+    const bool deep = (CM_HNN != 0) && m.nn_nlayers > 3;        // uniform; more than one hidden layer: the general evaluation
+    const cm_uniform_ptr sc = uniform_ptr(w) + (deep ? icnn_deep_scalers_offset(m) : icnn_off_scalers(H));   // in_scale[6], in_min[6], out_scale, out_min, f0
     const double h = (s[0] + s[3] + s[5]) * (1.0 / 3.0);
     const double x[6] = {s[0] - h, s[3] - h, s[5] - h, s[1], s[2], s[4]};
     // scaled input; the reference evaluates g(xs) and g(-xs) (input_convex_neural_network.py:59-69)
@@ -397,7 +504,10 @@ CM_D void icnn_yield_term(const cm_model_desc& m, const double s[6], double& val
 #pragma unroll
     for (int i = 0; i < 6; ++i) xs[i] = sc[i] * x[i] + sc[6 + i];
     double F, G[6], Hx[HESS ? 21 : 1];
-    icnn_symmetric<HESS>(w, H, xs, F, G, Hx);
+    if constexpr (CM_HNN != 0) {
+        if (deep) icnn_symmetric_deep<HESS>(m, xs, F, G, Hx);
+        else icnn_symmetric<HESS>(w, H, xs, F, G, Hx);
+    } else icnn_symmetric<HESS>(w, H, xs, F, G, Hx);
     const double ios = 1.0 / sc[12];
     val = (0.5 * F - sc[14] - sc[13]) * ios;                   // (1/2 (f(x)+f(-x)) - f(0) - out_min) / out_scale
     double gx[6];
@@ -898,9 +1008,6 @@ struct Hard { double H, dH, expo; };
 // Compiled only into the HNN build of the library (CM_HNN = 1, cmad_hip.hip): every kernel evaluates the hardening laws inside
 // its Newton loop, and this loop there costs the Voce / linear configurations scalar registers and spill traffic whether it
 // is inlined or called (profiles/r03_hnn_ab.txt).  The host build (tests) always has it.
-#ifndef CM_HNN
-#define CM_HNN 1
-#endif
 struct HnnTerm { double H, dH; };
 CM_D HnnTerm hardening_network(const double* wv, int Hn, double alpha) {
     const cm_uniform_ptr w = uniform_ptr(wv);

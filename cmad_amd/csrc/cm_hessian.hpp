@@ -170,8 +170,71 @@ CM_D T hardening_T(const cm_model_desc& m, const MatT<T>& p, const T& alpha) {
     return H;
 }
 
+// A network with any number of hidden layers in arithmetic T (cm::icnn_symmetric_deep): f(x) and grad f(x), the gradient by the
+// backward pass mu_n = wz_n o sigmoid(a_n), mu_k = (Wz_k mu_{k+1}) o sigmoid(a_k), grad f = wx_last + sum_k Wx_k mu_k.
+template <class T>
+CM_D void icnn_deep_value_grad_T(const cm_model_desc& m, const MatT<T>& p, const T x[6], T& f, T g[6]) {
+    const int nl = m.nn_nlayers, nh = nl - 2;
+    int xoff[kIcnnMaxLayers], zoff[kIcnnMaxLayers], uoff[kIcnnMaxLayers];
+    {
+        int off = 0, u = 0;
+        for (int k = 1; k <= nh + 1; ++k) { xoff[k] = off; off += 7 * m.nn_widths[k]; }
+        for (int k = 1; k <= nh; ++k) { zoff[k] = off; off += m.nn_widths[k] * m.nn_widths[k + 1]; }
+        for (int k = 1; k <= nh; ++k) { uoff[k] = u; u += m.nn_widths[k]; }
+    }
+    T spv[kIcnnMaxUnits], sgv[kIcnnMaxUnits], mu[kIcnnMaxUnits];
+    for (int k = 1; k <= nh; ++k) {
+        const int Hk = m.nn_widths[k], Hp = (k > 1) ? m.nn_widths[k - 1] : 0;
+        for (int v = 0; v < Hk; ++v) {
+            T a = p.nn_at(xoff[k] + 6 * Hk + v);
+            for (int i = 0; i < 6; ++i) a = a + x[i] * p.nn_at(xoff[k] + i * Hk + v);
+            for (int u = 0; u < Hp; ++u) a = a + p.nn_at(zoff[k - 1] + u * Hk + v) * spv[uoff[k - 1] + u];
+            softplus_T(a, spv[uoff[k] + v], sgv[uoff[k] + v]);
+        }
+    }
+    const int Hn = m.nn_widths[nh];
+    f = p.nn_at(xoff[nh + 1] + 6);
+    for (int i = 0; i < 6; ++i) { g[i] = p.nn_at(xoff[nh + 1] + i); f = f + x[i] * g[i]; }
+    for (int u = 0; u < Hn; ++u) {
+        const T wz = p.nn_at(zoff[nh] + u);
+        f = f + wz * spv[uoff[nh] + u];
+        mu[uoff[nh] + u] = wz * sgv[uoff[nh] + u];
+    }
+    for (int k = nh - 1; k >= 1; --k) {
+        const int Hk = m.nn_widths[k], Hq = m.nn_widths[k + 1];
+        for (int u = 0; u < Hk; ++u) {
+            T t = t_const<T>(0.0);
+            for (int v = 0; v < Hq; ++v) t = t + p.nn_at(zoff[k] + u * Hq + v) * mu[uoff[k + 1] + v];
+            mu[uoff[k] + u] = t * sgv[uoff[k] + u];
+        }
+    }
+    for (int k = 1; k <= nh; ++k) {
+        const int Hk = m.nn_widths[k];
+        for (int v = 0; v < Hk; ++v)
+            for (int i = 0; i < 6; ++i) g[i] = g[i] + p.nn_at(xoff[k] + i * Hk + v) * mu[uoff[k] + v];
+    }
+}
+
 template <class T>
 CM_D void icnn_yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& val, T g6[6]) {
+    if (CM_HNN != 0 && m.nn_nlayers > 3) {                      // more than one hidden layer (general evaluation; EXT / host builds)
+        const double* sc = p.nn + icnn_deep_scalers_offset(m);
+        const T h = (s[0] + s[3] + s[5]) * (1.0 / 3.0);
+        const T x[6] = {s[0] - h, s[3] - h, s[5] - h, s[1], s[2], s[4]};
+        T xs[6], xn[6], x0[6], fp, fn, f0, gp[6], gn[6], g0[6];
+        for (int i = 0; i < 6; ++i) { xs[i] = sc[i] * x[i] + sc[6 + i]; xn[i] = -xs[i]; x0[i] = t_const<T>(0.0); }
+        icnn_deep_value_grad_T<T>(m, p, xs, fp, gp);
+        icnn_deep_value_grad_T<T>(m, p, xn, fn, gn);
+        icnn_deep_value_grad_T<T>(m, p, x0, f0, g0);
+        const double ios = 1.0 / sc[12];
+        val = (0.5 * (fp + fn) - f0 - sc[13]) * ios;
+        T gx[6];
+        for (int i = 0; i < 6; ++i) gx[i] = (0.5 * sc[i] * ios) * (gp[i] - gn[i]);
+        constexpr int XI[6] = {0, 3, 4, 1, 5, 2};
+        const T gm = (gx[0] + gx[1] + gx[2]) * (1.0 / 3.0);
+        for (int k = 0; k < 6; ++k) { g6[k] = gx[XI[k]]; if (kDiag[k]) g6[k] = g6[k] - gm; }
+        return;
+    }
     const int H = m.nn_widths[1];
     const int oW0 = 0, ob0 = 6 * H, ob1 = 7 * H + 6, oWz = 7 * H + 7;
     const double* sc = p.nn + 8 * H + 7;                         // in_scale[6], in_min[6], out_scale, out_min (constants)
@@ -304,7 +367,8 @@ CM_D void yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& phi
         switch (m.yield_kind) {
             case CM_YIELD_J2: yield_T<CM_YIELD_J2, T>(m, p, s, phi, gt); break;
             case CM_YIELD_HILL: yield_T<CM_YIELD_HILL, T>(m, p, s, phi, gt); break;
-#if defined(CM_HNN_VARIANT) && CM_HNN_VARIANT             // the HNN build of the library has no dense surfaces (cmad_hip.hip)
+#if defined(CM_HNN_VARIANT) && CM_HNN_VARIANT             // the EXT build of the library: the plain hybrid surface is its only dense one
+            case CM_YIELD_HYBRID_HILL_NN: yield_T<CM_YIELD_HYBRID_HILL_NN, T>(m, p, s, phi, gt); break;
             default: yield_T<CM_YIELD_HOSFORD, T>(m, p, s, phi, gt); break;
 #else
             case CM_YIELD_HOSFORD: yield_T<CM_YIELD_HOSFORD, T>(m, p, s, phi, gt); break;

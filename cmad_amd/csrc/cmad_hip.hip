@@ -237,8 +237,11 @@ constexpr int min_waves_pool() { return is_dense_yield(YK) ? CM_POOL_WAVES_NN : 
 // Where the pool pays (measured, profiles/r02_pool_ab.txt): a pass must cost much more than the retire / refill bookkeeping and
 // the per-lane addressing -- the network surfaces (1.3x on top of the structured 6x6 solve) and Hosford under the line search
 // (a = 100 with the notch deck's settings: 2.2x).  J2 / Hill lose 5-30 %, Barlat (spills in the pool kernel) 10 %: lockstep.
+#ifndef CM_POOL_HILL
+#define CM_POOL_HILL 0              // experiment knob: Hill (plain Newton and line search) on the work pool as well
+#endif
 template <int YK, bool LS>
-constexpr bool pool_pays() { return is_nn_yield(YK) || (YK == CM_YIELD_HOSFORD && LS); }
+constexpr bool pool_pays() { return is_nn_yield(YK) || (YK == CM_YIELD_HOSFORD && LS) || (CM_POOL_HILL && YK == CM_YIELD_HILL); }
 
 typedef __attribute__((address_space(3))) double cm_lds_double;
 typedef __attribute__((address_space(3))) void* cm_lds_vptr;
@@ -1344,11 +1347,19 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS && m->def_type != CM_UNIAXIAL_STRESS) return false;
     if (m->def_type == CM_UNIAXIAL_STRESS && (m->uniaxial_idx < 0 || m->uniaxial_idx > 2)) return false;
     if (m->hnn_width < 0 || (m->hnn_width > 0 && (!m->nn_weights || m->hnn_offset < 0))) return false;   // network hardening law
-    if (CM_HNN_VARIANT && is_dense_yield(m->yield_kind)) return false;       // the HNN build: J2 / Hill / Hosford (see the top of the file)
+    // the EXT build: J2 / Hill / Hosford (+ the network hardening law) and the plain hybrid surface (+ multi-layer networks)
+    if (CM_HNN_VARIANT && is_dense_yield(m->yield_kind) && m->yield_kind != CM_YIELD_HYBRID_HILL_NN) return false;
     if (m->yield_kind == CM_YIELD_SCALED_HYBRID_HILL_NN && !(m->beta_equivalent_stress > 0.0 && m->beta_max_iters >= 0)) return false;
-    if (is_nn_yield(m->yield_kind))                    // one hidden layer [6, H, 1], weights resident on the device
-        return m->nn_weights && m->nn_nlayers == 3 && m->nn_widths[0] == 6 && m->nn_widths[2] == 1 &&
-               m->nn_widths[1] >= 1 && m->nn_widths[1] <= 256;
+    if (is_nn_yield(m->yield_kind)) {                  // weights resident on the device
+        if (!m->nn_weights || m->nn_widths[0] != 6) return false;
+        if (m->nn_nlayers == 3)                        // one hidden layer [6, H, 1]: the fast evaluation (either build)
+            return m->nn_widths[2] == 1 && m->nn_widths[1] >= 1 && m->nn_widths[1] <= 256;
+        // more hidden layers: the general evaluation of the EXT build, plain hybrid surface only
+        if (!CM_HNN_VARIANT || m->yield_kind != CM_YIELD_HYBRID_HILL_NN || m->nn_nlayers < 3 || m->nn_nlayers > kIcnnMaxLayers) return false;
+        int units = 0;
+        for (int k = 1; k + 1 < m->nn_nlayers; ++k) { if (m->nn_widths[k] < 1) return false; units += m->nn_widths[k]; }
+        return m->nn_widths[m->nn_nlayers - 1] == 1 && units <= kIcnnMaxUnits;
+    }
     if (m->yield_kind == CM_YIELD_BARLAT) return m->yc[18] >= 1.0;
     if (m->yield_kind != CM_YIELD_J2 && m->yield_kind != CM_YIELD_HILL && m->yield_kind != CM_YIELD_HOSFORD) return false;
     return true;
@@ -1403,9 +1414,9 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_J2)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HILL)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
-#if !CM_HNN_VARIANT                    // the HNN build leaves the dense surfaces out (supported() refuses them there)
     CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
+#if !CM_HNN_VARIANT                    // the EXT build leaves the other dense surfaces out (supported() refuses them there)
     CM_CASE(CM_FULL_3D, CM_YIELD_SCALED_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
     CM_CASE(CM_FULL_3D, CM_YIELD_BARLAT)
@@ -1415,9 +1426,9 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_J2)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HYBRID_HILL_NN)
 #if !CM_HNN_VARIANT
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_BARLAT)
-        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HYBRID_HILL_NN)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
 #endif
     }
@@ -1458,7 +1469,8 @@ static inline bool use_subspace_newton(const cm_model_desc* m) {
 // (CM_SOLVER_LOCKSTEP keeps the single fused kernel).  Same per-point arithmetic and the same reduction order either way.
 static inline bool pool_route(const cm_model_desc* m, int64_t B) {
     if (!m || m->model_kind != CM_SMALL_ELASTIC_PLASTIC || (m->solver_flags & CM_SOLVER_LOCKSTEP) || B < 256) return false;
-    return is_nn_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && m->ls_max_evals > 0);
+    return is_nn_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && m->ls_max_evals > 0) ||
+           (CM_POOL_HILL && m->yield_kind == CM_YIELD_HILL);
 }
 // ---- consistent tangent at given converged states (second kernel of cm_update_tangent's work-pool route) -------------------
 template <int DEF, int YK, bool ROT>

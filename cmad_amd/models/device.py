@@ -76,13 +76,18 @@ class HybridHillEffectiveStress:
     `SmallElasticPlastic(..., effective_stress_fun=HybridHillEffectiveStress(icnn))` where the reference passes
     `partial(hybrid_hill_effective_stress, nn_fun=icnn.evaluate)`; the network weights are read from
     params["plastic"]["effective stress"]["neural network"] like the reference does.
-    The HIP kernel supports one hidden layer ([6, H, 1]); `ScaledHybridHillEffectiveStress` is the beta-rescaled
-    variant (`scaled_effective_stress`, :130-146)."""
+    One hidden layer ([6, H, 1]) runs on the kernels' fast evaluation; more hidden layers ([6, H1, ..., Hn, 1], n <= 4,
+    at most 64 hidden units) on the general one.  `ScaledHybridHillEffectiveStress` is the beta-rescaled variant
+    (`scaled_effective_stress`, :130-146; one hidden layer)."""
     yield_kind = 3
 
     def __init__(self, icnn):
-        if len(icnn.layer_widths) != 3 or icnn.layer_widths[0] != 6 or icnn.layer_widths[-1] != 1:
-            raise NotImplementedError("the HIP kernel supports ICNN layer widths [6, H, 1]")
+        w = list(icnn.layer_widths)
+        if len(w) < 3 or w[0] != 6 or w[-1] != 1:
+            raise NotImplementedError("the HIP kernels evaluate ICNNs with layer widths [6, H1, ..., Hn, 1]")
+        if len(w) > 3 and (self.yield_kind != 3 or len(w) > 6 or sum(w[1:-1]) > 64):
+            raise NotImplementedError("networks with several hidden layers: plain hybrid surface, at most 4 hidden layers and "
+                                      "64 hidden units in all (general evaluation of the library's EXT build)")
         self.icnn = icnn
 
     def packed(self, values):
@@ -94,7 +99,8 @@ class HybridHillEffectiveStress:
         nn_params = values["plastic"]["effective stress"].get("neural network", self.icnn.params)
         widths, w = self.icnn.pack_for_device(nn_params)
         f0 = float(np.asarray(forward(np.zeros(widths[0]), nn_params)).ravel()[0])
-        return widths, np.concatenate([w, [f0], unit_records(nn_params)])
+        rec = unit_records(nn_params) if len(widths) == 3 else np.zeros(0)       # the fast evaluation's per-unit records
+        return widths, np.concatenate([w, [f0], rec])
 
 
 class ScaledHybridHillEffectiveStress(HybridHillEffectiveStress):
@@ -263,18 +269,18 @@ def leaf_ep_index(path, info):
         return EP_NN0 + off + (2 * Hn + elem if what == "weights" else 3 * Hn)
     if "neural network" in names:
         widths = info.get("nn_widths")
-        if widths is None or len(widths) != 3:
-            raise NotImplementedError("network-weight sensitivities need the hybrid surface with layer widths [6, H, 1]")
-        H = widths[1]
+        if widths is None:
+            raise NotImplementedError("network-weight sensitivities need the hybrid surface")
+        # packed layout (pack_for_device): x-layer k: W[6][H_k], b[H_k] for k = 1 .. n+1, then z-layer k: W[H_k][H_{k+1}]
         ints = [k for k in path if isinstance(k, (int, np.integer))]
-        layer, elem = int(ints[0]), (int(ints[1]) if len(ints) > 1 else 0)
-        kind, what = ("x params" in names), names[-1]
-        if kind and layer == 0:
-            return EP_NN0 + (elem if what == "weights" else 6 * H + elem)
-        if kind and layer == 1:
-            return EP_NN0 + (7 * H + elem if what == "weights" else 7 * H + 6)
-        if "z params" in names and layer == 0:
-            return EP_NN0 + 7 * H + 7 + elem
+        layer, elem = int(ints[0]), (int(ints[-1]) if len(ints) > 1 else 0)
+        outs = list(widths[1:])
+        if "x params" in names:
+            off = sum(7 * h for h in outs[:layer])
+            return EP_NN0 + off + (elem if names[-1] == "weights" else 6 * outs[layer] + elem)
+        if "z params" in names:
+            off = sum(7 * h for h in outs) + sum(a * b for a, b in zip(outs[:layer], outs[1:layer + 1]))
+            return EP_NN0 + off + elem
         raise KeyError(path)
     parent = names[-2] if len(names) >= 2 else None
     if parent == "hosford":

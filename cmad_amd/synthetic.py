@@ -28,7 +28,7 @@ def hosford_values(a=100., E=1000., nu=0.25, Y=2., S=10., D=2.):
 AL7079_HILL = (0.1477, 0.6805, 0.5345, 1.7977, 1.7148, 2.1675)    # F, G, H, L, M, N (calibrations/al7079/support.py:76-78)
 
 
-def al7079_hybrid_setup():
+def al7079_hybrid_setup(layer_widths=(6, 16, 1)):
     """BASELINE.json configs[3]: hybrid Hill + symmetric ICNN [6, 16, 1] yield surface with the Al7079 elastic
     constants and Hill coefficients (cmad/calibrations/al7079/support.py:76-78,
     nn_hill_uniaxial_stress_forward.py:84), weights from the seeded initialiser (seed 22), input scaler on
@@ -41,7 +41,7 @@ def al7079_hybrid_setup():
     in_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.vstack([feats, np.zeros((1, 6))]))
     in_sc.min_ = in_sc.min_ * 0.0
     out_sc = AffineScaler(feature_range=(0.0, 1.0)).fit(np.r_[-sig_c, sig_c].reshape(-1, 1))
-    icnn = InputConvexNeuralNetwork([6, 16, 1], in_sc, out_sc, seed=22)
+    icnn = InputConvexNeuralNetwork(list(layer_widths), in_sc, out_sc, seed=22)
     values = j2_voce_values(E=70.22857142857143e3, nu=0.33396551724137924, Y=525.0, S=200., D=20.)
     values["plastic"]["effective stress"] = {"hill": dict(zip("FGHLMN", AL7079_HILL)),
                                              "neural network": icnn.params}

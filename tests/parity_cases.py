@@ -286,7 +286,7 @@ def check_barlat_calibrated(backend, def_type=ol.FULL_3D, B=512, rot=True):
     check_vjp(backend, sc)
 
 
-def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False, scaled=False):
+def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False, scaled=False, widths=(6, 16, 1)):
     """scaled: the beta-rescaled surface `scaled_effective_stress` (effective_stress.py:130-146) with the al7079
     script's equivalent stress (nn_hill_uniaxial_stress_forward.py:74-78)."""
     from cmad_amd.models.device import (HybridHillEffectiveStress, NewtonSettings, ScaledHybridHillEffectiveStress,
@@ -296,7 +296,7 @@ def check_hybrid_nn(backend, def_type=ol.FULL_3D, B=512, rot=False, scaled=False
     class S:
         pass
     sc = S()
-    icnn, values = al7079_hybrid_setup()
+    icnn, values = al7079_hybrid_setup(widths)
     if rot:
         values["rotation matrix"] = rand_rot(np.random.default_rng(4))
     widths, packed = icnn.pack_for_device()
@@ -1031,24 +1031,24 @@ def check_param_blocks(param_blocks, def_type, yield_kind, kw, rate=False, uniax
         np.testing.assert_allclose(dS[:, :, 0].T, Sp, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(Sp).max()))
 
 
-def check_param_blocks_network(param_blocks, def_type=ol.FULL_3D, scaled=False, seed=3):
+def check_param_blocks_network(param_blocks, def_type=ol.FULL_3D, scaled=False, seed=3, layer_widths=(6, 16, 1)):
     """Hybrid Hill + network surface: sensitivities w.r.t. the Hill coefficients (oracle AD) and w.r.t. every packed network
     weight (central differences of the oracle's residual and stress -- the oracle holds the weights outside its
     differentiable parameter vector) at plastic states."""
     from cmad_amd.models.device import HybridHillEffectiveStress, ScaledHybridHillEffectiveStress, build_desc
-    icnn, values = al7079_hybrid_setup()
+    icnn, values = al7079_hybrid_setup(layer_widths)
     hyb = ScaledHybridHillEffectiveStress(icnn, 525.0) if scaled else HybridHillEffectiveStress(icnn)
     E, nu_ = values["elastic"]["E"], values["elastic"]["nu"]
     values["elastic"] = {"lambda": E * nu_ / ((1 + nu_) * (1 - 2 * nu_)), "mu": E / (2 * (1 + nu_))}
     desc, info = build_desc(values, def_type=def_type, hybrid=hyb)
     packed = np.array(info["nn_packed"])
     widths = [desc.nn_widths[i] for i in range(desc.nn_nlayers)]
-    H = widths[1]
-    nw = 8 * H + 7                                                                # differentiable weights (scalers follow)
+    outs = widths[1:]
+    nw = sum(7 * h for h in outs) + sum(a * b for a, b in zip(outs[:-1], outs[1:]))   # differentiable weights (scalers follow)
 
     def material(w):
-        # the device layout appends f(0) to the oracle's packing; the oracle evaluates the network at the origin itself
-        return ol.Material(values, def_type=def_type, nn=(widths, np.ascontiguousarray(w[:-1])),
+        # the device layout appends f(0) (and the fast evaluation's records) to the oracle's packing, which the oracle ignores
+        return ol.Material(values, def_type=def_type, nn=(widths, np.ascontiguousarray(w)),
                            scaled=(525.0, 10, 1e-14, 1e-14) if scaled else None)
     mat = material(packed)
     rng = np.random.default_rng(seed)
@@ -1082,11 +1082,11 @@ def check_param_blocks_network(param_blocks, def_type=ol.FULL_3D, scaled=False, 
         np.testing.assert_allclose(dC[6 + i, :, 0], fd, rtol=2e-5, atol=1e-9 * max(1.0, np.abs(fd).max()))
 
 
-def check_second_derivs_network(hessians, def_type=ol.FULL_3D, scaled=False, seed=3):
+def check_second_derivs_network(hessians, def_type=ol.FULL_3D, scaled=False, seed=3, layer_widths=(6, 16, 1)):
     """cm_hessians for the hybrid Hill + network surfaces (hyper-dual evaluation of the arithmetic-T model) against the
     oracle's nested duals: every block of d2C and d2 sigma w.r.t. (xi, xi_prev, native parameters incl. the Hill coefficients)."""
     from cmad_amd.models.device import HybridHillEffectiveStress, ScaledHybridHillEffectiveStress, build_desc
-    icnn, values = al7079_hybrid_setup()
+    icnn, values = al7079_hybrid_setup(layer_widths)
     hyb = ScaledHybridHillEffectiveStress(icnn, 525.0) if scaled else HybridHillEffectiveStress(icnn)
     E, nu_ = values["elastic"]["E"], values["elastic"]["nu"]
     values["elastic"] = {"lambda": E * nu_ / ((1 + nu_) * (1 - 2 * nu_)), "mu": E / (2 * (1 + nu_))}

@@ -50,8 +50,20 @@ def extended_leaf_problem(model_cls, yield_kind, active_rotation):
     and/or the rotation matrix (differentiated by forward-mode evaluation of the whole model, cm_param_blocks)."""
     from cmad_amd.models import DefType
     from cmad_amd.qois import Calibration
-    base = params_J2_voce(yield_kind=yield_kind, scale_params=False)
-    values = copy.deepcopy(base.values)
+    network = yield_kind.startswith("network")
+    kw = {}
+    if network:
+        # hybrid Hill + ICNN surface, one ("network") or two ("network deep") hidden layers; active: Y, one Hill coefficient,
+        # the input weights of the last layer and (deep) the weights between the hidden layers
+        from cmad_amd.models import HybridHillEffectiveStress
+        from cmad_amd.synthetic import al7079_hybrid_setup
+        icnn, values = al7079_hybrid_setup((6, 4, 3, 1) if yield_kind.endswith("deep") else (6, 5, 1))
+        values = copy.deepcopy(values)
+        values["plastic"]["flow stress"]["initial yield"]["Y"] = 200.0
+        kw = {"effective_stress_fun": HybridHillEffectiveStress(icnn)}
+    else:
+        base = params_J2_voce(yield_kind=yield_kind, scale_params=False)
+        values = copy.deepcopy(base.values)
     th = 0.35
     values["rotation matrix"] = np.array([[np.cos(th), -np.sin(th), 0.], [np.sin(th), np.cos(th), 0.], [0., 0., 1.]])
     if yield_kind == "hill":
@@ -62,9 +74,16 @@ def extended_leaf_problem(model_cls, yield_kind, active_rotation):
         flags["plastic"]["effective stress"]["hosford"]["a"] = True
     if active_rotation:
         flags["rotation matrix"] = True                        # an array leaf is active as a whole: nine entries
+    if network:
+        nn = flags["plastic"]["effective stress"]["neural network"]
+        flags["plastic"]["effective stress"]["hill"]["G"] = True
+        nn["x params"][-1]["weights"] = True
+        nn["x params"][0]["biases"] = True
+        if nn["z params"][:-1]:
+            nn["z params"][0]["weights"] = True
     params = Parameters(values, flags, tree_map(lambda a: None, copy.deepcopy(values)))
     F = plane_stress_F(0.02, 3)
-    model = model_cls(params, DefType.PLANE_STRESS)
+    model = model_cls(params, DefType.PLANE_STRESS, **kw)
     n = F.shape[2]
     t = np.linspace(0.0, 1.0, n)
     data = np.zeros((3, 3, n))

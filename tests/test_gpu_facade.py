@@ -802,7 +802,8 @@ def test_sharded_objective_through_rccl_process_group(tmp_path):
     np.testing.assert_allclose(out["1"]["grad"], out["0"]["grad"], rtol=1e-13, atol=0.0)
 
 
-@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("hosford", True)])
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("hosford", True),
+                                                        ("network", False), ("network deep", False)])
 def test_gradient_of_extended_leaves(yield_kind, active_rotation):
     """Objective gradients w.r.t. the Hosford exponent and the entries of the rotation matrix -- leaves the reference reaches
     by jacrev over the params pytree (cmad/models/model.py:125-153) and the kernels by forward-mode evaluation of the whole
@@ -916,7 +917,7 @@ def test_network_hardening_law_through_the_model_api():
     np.testing.assert_allclose(rra.J, ra.J, rtol=1e-6)                                    # same material, two formulations
 
 
-@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True)])
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("network deep", False)])
 def test_direct_adjoint_hessian_with_extended_leaves(yield_kind, active_rotation):
     """Second-order sensitivities w.r.t. leaves outside the 12 native kernel parameters -- the Hosford exponent, the nine
     entries of the rotation matrix -- together with a native one (Y): the reference takes Hessians over the whole params pytree

@@ -450,6 +450,15 @@ def test_second_derivatives_network_surfaces(def_type, scaled):
     pc.check_second_derivs_network(gpu_api.hessians, def_type, scaled=scaled)
 
 
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_multi_layer_network_sensitivities(def_type):
+    """Two hidden layers: weight sensitivities (cm_param_blocks; extended-parameter index = position in the weight blob)
+    against central differences of the oracle, second derivatives against its nested duals."""
+    import gpu_api
+    pc.check_param_blocks_network(gpu_api.param_blocks, def_type, layer_widths=(6, 7, 5, 1))
+    pc.check_second_derivs_network(gpu_api.hessians, def_type, layer_widths=(6, 7, 5, 1))
+
+
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
 def test_barlat_second_derivatives_and_coefficient_sensitivities(def_type):
     """Barlat Yld2004-18p through the arithmetic-T model on the GPU: `cm_hessians` against the oracle's nested duals,

@@ -86,6 +86,14 @@ def test_hybrid_hill_icnn(backend, def_type):
     pc.check_hybrid_nn(backend, def_type, B=2048, rot=(def_type == ol.FULL_3D))
 
 
+@pytest.mark.parametrize("widths", [(6, 7, 5, 1), (6, 12, 8, 6, 1)])
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_hybrid_hill_multi_layer_icnn(backend, def_type, widths):
+    """Networks with two and three hidden layers (reference input_convex_neural_network.py:58-69 loops over any depth):
+    the general evaluation of the library's second build, update + reverse sweep against the oracle."""
+    pc.check_hybrid_nn(backend, def_type, B=1024, rot=(def_type == ol.FULL_3D), widths=widths)
+
+
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])

@@ -83,7 +83,8 @@ def test_named_derivatives_parallel_their_inputs():
     check_named_derivatives(HostSmallElasticPlastic)
 
 
-@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("hosford", True)])
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("hosford", True),
+                                                        ("network", False), ("network deep", False)])
 def test_gradient_of_extended_leaves(yield_kind, active_rotation):
     """Objective gradients w.r.t. the Hosford exponent and entries of the rotation matrix (reference: jacrev over the params
     pytree, cmad/models/model.py:125-153): adjoint == direct, both == central differences of the objective; and the DPARAMS
@@ -92,7 +93,8 @@ def test_gradient_of_extended_leaves(yield_kind, active_rotation):
     from problems import extended_leaf_problem
     model, qoi, F = extended_leaf_problem(HostSmallElasticPlastic, yield_kind, active_rotation)
     x = model.parameters.flat_active_values(True)
-    assert len(model.extended_active()) == (1 if yield_kind == "hosford" else 0) + (9 if active_rotation else 0)
+    n_ext = {"hosford": 1, "hill": 0, "network": 1 + 6 + 5, "network deep": 1 + 6 + 4 + 12}[yield_kind] + (9 if active_rotation else 0)
+    assert len(model.extended_active()) == n_ext
     Ja, ga = MPAdjointObjective(qoi, F).evaluate(x)
     Jd, gd = MPDirectObjective(qoi, F).evaluate(x)
     assert abs(Ja - Jd) <= 1e-12 * abs(Ja)
@@ -236,7 +238,7 @@ def test_network_hardening_law_through_the_model_api():
     assert np.count_nonzero(np.abs(ra.grad) > 1e-9 * np.abs(ra.grad).max()) >= n - 1      # all but the output bias matter
 
 
-@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True)])
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("network deep", False)])
 def test_direct_adjoint_hessian_with_extended_leaves(yield_kind, active_rotation):
     """Second-order sensitivities w.r.t. leaves outside the 12 native kernel parameters -- the Hosford exponent, the nine
     entries of the rotation matrix -- together with a native one (Y): the reference takes Hessians over the whole params pytree

@@ -589,3 +589,19 @@ def test_network_hardening_law(def_type, with_voce, solver_variant):
     if def_type == ol.UNIAXIAL_STRESS:
         pytest.skip("covered through the facade")
     pc.check_nn_hardening(BACKEND, hh.param_blocks, def_type, with_voce=with_voce, B=192)
+
+
+DEEP = (6, 7, 5, 1)            # two hidden layers (the reference's forward loops over any number, input_convex_neural_network.py:58-69)
+
+
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_hybrid_surface_with_a_multi_layer_network(def_type, solver_variant):
+    """Hybrid Hill + ICNN with TWO hidden layers: the general network evaluation (cm::icnn_symmetric_deep: forward pass with
+    per-unit pre-activation gradients, backward pass for the Hessian weights) in the update and the reverse sweep against
+    the oracle, the weight sensitivities (arithmetic-T model, backward-pass gradient) against central differences, and the
+    second derivatives against the oracle's nested duals."""
+    import host_harness_lib as hh
+    pc.check_hybrid_nn(BACKEND, def_type, B=96, rot=(def_type == ol.PLANE_STRESS), widths=DEEP)
+    if solver_variant == "structured":
+        pc.check_param_blocks_network(hh.param_blocks, def_type, layer_widths=DEEP)
+        pc.check_second_derivs_network(hh.hessians, def_type, layer_widths=DEEP)
