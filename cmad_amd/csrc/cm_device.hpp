@@ -1637,11 +1637,14 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
                 for (int k = 0; k < NX; ++k) delta[k] = C[k];
                 lu_subst<NX>(A, delta);
             }
-            if constexpr (!LS) {
+            // LS kernels serve plain Newton too (ls_max_evals == 0, uniform): the cold configurations are built once
+            bool plain = !LS;
+            if constexpr (LS) plain = (m.ls_max_evals <= 0);
+            if (plain) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k) x[k] -= delta[k];
                 residual_mk<MK, DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
-            } else {
+            } else if constexpr (LS) {
                 const double cc = dot<NX>(C, C);
                 const double phi0 = 0.5 * cc, dphi0 = -cc, armijo = m.ls_c1 * dphi0;
                 int n = 0;

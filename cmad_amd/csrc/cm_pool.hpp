@@ -119,7 +119,9 @@ CM_D void newton_pass(const cm_model_desc& m, const double eg[6], const double* 
                         lu_subst<NX>(A, delta);
                     }
                 }
-                if constexpr (LS) {
+                bool search = LS;                                       // LS kernels serve plain Newton too (uniform)
+                if constexpr (LS) search = (m.ls_max_evals > 0);
+                if (search) {
 #pragma unroll
                     for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
                     s.cc = nsq; s.alpha = 1.0; s.best_alpha = 1.0; s.best_phi = INFINITY; s.n = 0;

@@ -101,10 +101,12 @@ CM_D uint32_t ru_newton(const cm_model_desc& m, double dU, const double* xp, dou
             ru_block<YK>(m, dU, x, xp, CM_W_XI, A, nullptr);
             for (int k = 0; k < NX; ++k) delta[k] = C[k];
             if (!ru_solve(NX, A, delta, 1)) flags |= CM_STATUS_SINGULAR;
-            if constexpr (!LS) {
+            bool plain = !LS;                                          // LS kernels serve plain Newton too (uniform)
+            if constexpr (LS) plain = (m.ls_max_evals <= 0);
+            if (plain) {
                 for (int k = 0; k < NX; ++k) x[k] -= delta[k];
                 ru_eval<YK>(m, dU, x, xp, C, sg);
-            } else {
+            } else if constexpr (LS) {
                 const double cc = dot<NX>(C, C);
                 const double phi0 = 0.5 * cc, dphi0 = -cc, armijo = m.ls_c1 * dphi0;
                 int n = 0;

@@ -487,9 +487,15 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
                     op_build<YK>(m, ev, op);
                     if (!op.ok) flags |= CM_STATUS_SINGULAR;
                     if (!solve_s<DEF, false>(m, op, ev, z, C, delta)) flags |= CM_STATUS_SINGULAR;
+                    if (m.ls_max_evals <= 0) {      // uniform: plain Newton through this kernel (the full step is the next iterate)
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
-                    cc = nsq; alpha = 1.0; best_alpha = 1.0; best_phi = INFINITY; n = 0; phase = 1;
+                        for (int k = 0; k < NX; ++k) x[k] -= delta[k];
+                        ++it;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
+                        cc = nsq; alpha = 1.0; best_alpha = 1.0; best_phi = INFINITY; n = 0; phase = 1;
+                    }
                 }
             }
             if (!__any(running)) break;

@@ -34,6 +34,12 @@ extern int g_cm_last_hip_error;
 int g_cm_last_hip_error = 0;
 #endif
 
+// the deterministic reductions (k_reduce_stage1/2, k_sum_rows) exist once in the library (part 1 of the base build); every
+// part launches them through these two helpers
+__attribute__((visibility("hidden"))) void cm_detail_reduce(hipStream_t s, const double* partials, int64_t nrows, double* stage,
+                                                            double* out, int first, int accumulate);
+__attribute__((visibility("hidden"))) void cm_detail_sum_rows(hipStream_t s, const double* part, int64_t nrows, int ncols, double* out);
+
 namespace {
 
 // 128 lanes (two wavefronts) per workgroup: measured against 64 and 256 on the same box (tools/ab_multi.sh): -3 % on the
@@ -494,6 +500,7 @@ __device__ __forceinline__ void block_reduce_store(const double* v, double* __re
 // stage 2: one block sums the kRedBlocks rows -> out[k] (+)= ...
 constexpr int kRedBlocks = 128;
 
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT      // one copy in the library: every part launches them through cm_detail_reduce()
 template <int NV>
 __device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int64_t begin, int64_t end, double* res) {
     double acc[NV];
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(kRBlock) void k_reduce_stage2(const double* __restr
     }
 }
 
+#endif
 // ---- cm_update_vjp / cm_objective_grad / cm_adjoint_step ----------------------------------------------
 // MODE 0: vjp for a given sigma_bar (xi given, converged)
 // MODE 1: fused update + calibration QoI + gradient (xi computed here)
@@ -1277,6 +1285,7 @@ __global__ __launch_bounds__(192) void k_hessian_quadform(int64_t B, int K, cons
 }
 
 // out[j] = sum over rows of part[row][ncols] in a fixed order (one thread per column)
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
 __global__ __launch_bounds__(256) void k_sum_rows(const double* __restrict__ part, int64_t nrows, int ncols, double* __restrict__ out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ncols) return;
@@ -1284,6 +1293,7 @@ __global__ __launch_bounds__(256) void k_sum_rows(const double* __restrict__ par
     for (int64_t r = 0; r < nrows; ++r) acc += part[r * ncols + j];
     out[j] = acc;
 }
+#endif
 
 // ---- extended parameter sensitivities: forward-mode evaluation of the whole model (cm::param_direction) ----------------
 // surfaces the arithmetic-T model (cm_hessian.hpp) covers: all of them (Barlat through a Jacobi eigen-decomposition in arithmetic T)
@@ -1396,16 +1406,30 @@ inline bool rate_uniaxial_dense(const cm_model_desc* m) {
 template <int ROTP, int D, int Y>
 constexpr bool always_rotates() { return CM_HNN_VARIANT != 0 || ROTP == 2 || (ROTP == 1 && (is_dense_yield(Y) || D == CM_UNIAXIAL_STRESS)); }   // (the HNN build keeps one variant per configuration)
 
+// Which configurations get a plain-Newton (LS = false) specialisation at all: J2 / Hill / Hosford of the total-form model in the
+// base build, in the material frame (Q = I) or under UNIAXIAL_STRESS -- the memory- and issue-bound ones, whose plain kernels
+// the line-search bookkeeping would cost registers (Hosford a = 8 update + vjp: -10 % through the LS = true kernel).  Everywhere
+// else (the dense surfaces, rotated frames, the rate form, the HNN build) the LS = true kernel serves both: its Newton loops take
+// the full step without a merit test when ls_max_evals == 0 (uniform branch; same iterates as the LS = false code, bit for bit:
+// tests/test_host_math.py::test_plain_newton_through_the_line_search_kernels).
+template <int ROTP, int D, int Y, bool R>
+constexpr bool always_searches() {
+    return CM_HNN_VARIANT != 0 || ROTP == 2 || is_dense_yield(Y) || (R && D != CM_UNIAXIAL_STRESS);
+}
+
 template <bool UNI = false, int ROTP = 0, class F>
 inline bool dispatch(const cm_model_desc* m, F&& f) {
     const bool rot = !m->rotation_is_identity, ls = m->ls_max_evals > 0;
+#define CM_CASE_LS(D, Y, R) \
+    if constexpr (always_searches<ROTP, D, Y, R>()) f.template operator()<D, Y, R, true>(); \
+    else { if (ls) f.template operator()<D, Y, R, true>(); else f.template operator()<D, Y, R, false>(); }
 #define CM_CASE(D, Y) \
     if (m->def_type == D && m->yield_kind == Y) { \
         if constexpr (always_rotates<ROTP, D, Y>()) { \
-            if (ls) f.template operator()<D, Y, true, true>(); else f.template operator()<D, Y, true, false>(); \
+            CM_CASE_LS(D, Y, true) \
         } else { \
-            if (rot) { if (ls) f.template operator()<D, Y, true, true>(); else f.template operator()<D, Y, true, false>(); } \
-            else { if (ls) f.template operator()<D, Y, false, true>(); else f.template operator()<D, Y, false, false>(); } \
+            if (rot) { CM_CASE_LS(D, Y, true) } \
+            else { CM_CASE_LS(D, Y, false) } \
         } \
         return true; }
     CM_CASE(CM_FULL_3D, CM_YIELD_J2)
@@ -1433,6 +1457,7 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
 #endif
     }
 #undef CM_CASE
+#undef CM_CASE_LS
     return false;
 }
 
@@ -1545,7 +1570,7 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
         }
         if constexpr (!TANGENT && pool_pays<Y, LS>()) {
             // expensive, iteration-bound passes: the work-pool kernel (CM_SOLVER_LOCKSTEP: one point per lane as everywhere else)
-            if (!(m->solver_flags & CM_SOLVER_LOCKSTEP) && B >= 256) {
+            if (pool_route(m, B)) {
                 static const int resident = pool_resident_waves((const void*)k_update_pool<D, Y, R, LS>);
                 // chunks of 256 points when every resident wavefront gets at least eight of them, else of 64
                 const int chunk_shift = (B >= (int64_t)resident * 256 * 8) ? 8 : 6;
@@ -1599,8 +1624,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     double* stage = partials + nb * kRed;
-    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
-    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, accumulate);
+    cm_detail_reduce(s, partials, B > 0 ? nb : 0, stage, out, out_offset, accumulate);
     return check_launch();
 }
 
@@ -1632,8 +1656,7 @@ int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, 
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     double* stage = partials + nb * kRed;
-    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
-    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, accumulate);
+    cm_detail_reduce(s, partials, B > 0 ? nb : 0, stage, out, out_offset, accumulate);
     return check_launch();
 }
 
@@ -1668,8 +1691,7 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     double* stage = partials + nb * kRed;
-    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, B > 0 ? nb : 0, stage);
-    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, out_offset, 0);
+    cm_detail_reduce(s, partials, B > 0 ? nb : 0, stage, out, out_offset, 0);
     return check_launch();
 }
 
@@ -1755,8 +1777,7 @@ int launch_direct_history(const cm_model_desc* m, int64_t B, int K, const double
     }
     if (grad_p) {
         double* stage = rows + (B > 0 ? B : 1) * kRed;
-        hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, rows, B, stage);
-        hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, grad_p, 1, 0);
+        cm_detail_reduce(s, rows, B, stage, grad_p, 1, 0);
     }
     return check_launch();
 }
@@ -1818,7 +1839,7 @@ int launch_hessian_history(const cm_model_desc* m, int64_t B, int K, const doubl
         if (!found) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, s, part, nps, NPP, out);
+    cm_detail_sum_rows(s, part, nps, NPP, out);
     return check_launch();
 }
 #endif
@@ -1877,7 +1898,7 @@ int launch_hessian_history_ep(const cm_model_desc* m, int64_t B, int K, int n_ep
         if (!found) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)((npt * npt + 255) / 256)), dim3(256), 0, s, part, nps, npt * npt, out);
+    cm_detail_sum_rows(s, part, nps, npt * npt, out);
     return check_launch();
 }
 
@@ -1923,12 +1944,22 @@ int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n
         if (!found) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)((n_ep + 255) / 256)), dim3(256), 0, s, rows, B, n_ep, grad_ep);
+    cm_detail_sum_rows(s, rows, B, n_ep, grad_ep);
     return check_launch();
 }
 #endif
 
 }  // namespace
+
+#if CM_HAS_PART(1) && !CM_HNN_VARIANT
+void cm_detail_reduce(hipStream_t s, const double* partials, int64_t nrows, double* stage, double* out, int first, int accumulate) {
+    hipLaunchKernelGGL((k_reduce_stage1<kRed>), dim3(kRedBlocks), dim3(kRBlock), 0, s, partials, nrows, stage);
+    hipLaunchKernelGGL((k_reduce_stage2<kRed>), dim3(1), dim3(kRBlock), 0, s, stage, out, first, accumulate);
+}
+void cm_detail_sum_rows(hipStream_t s, const double* part, int64_t nrows, int ncols, double* out) {
+    hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, part, nrows, ncols, out);
+}
+#endif
 
 extern "C" {
 // objective + gradient at given converged states (the MODE 2 reverse kernel without a history vector); defined with cm_adjoint_step

@@ -77,6 +77,12 @@ def set_passes(flag):
     lib().hh_set_passes(int(bool(flag)))
 
 
+def set_force_ls(flag):
+    """Run the line-search (LS = true) instantiations of the Newton loops also when ls_max_evals == 0: what the library does
+    for the configurations it builds once (Hosford and the dense surfaces, the rate form, the HNN build; cmad_hip.hip dispatch)."""
+    lib().hh_set_force_ls(int(bool(flag)))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -17,13 +17,16 @@ using namespace cm;
 #endif
 #define HH_HAS(k) (HH_PART == -1 || HH_PART == (k))
 #define g_dense hh_g_dense
+#define HH_LS(m) ((m).ls_max_evals > 0 || hh_g_force_ls)
 #if HH_HAS(0)
 int hh_g_dense = 0;       // 1: force the dense 7x7 path also for FULL_3D
 int hh_g_passes = 0;      // 1: solve by cm::newton_pass (the resumable form the work-pool kernels run)
+int hh_g_force_ls = 0;    // 1: the LS = true instantiations also for ls_max_evals == 0 (what the library's cold configurations run)
 int hh_g_radial_vjp = 0;  // 1: J2 / FULL_3D parameter gradient by cm::reverse_j2_radial (what the fused J2 kernels use)
 #else
 extern int hh_g_dense;
 extern int hh_g_passes;
+extern int hh_g_force_ls;
 extern int hh_g_radial_vjp;
 #endif
 
@@ -37,7 +40,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         strain_from_gradu<DEF, ROT>(m, G, eg);
         strain_z<DEF, ROT>(m, z);
-        const bool ls = m.ls_max_evals > 0;
+        const bool ls = HH_LS(m);
         double parked[2 * 9];                      // the kernels keep this in the lane's LDS column
         const LaneStage stage{parked, 1};
         uint32_t st;
@@ -186,7 +189,7 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
         for (int k = 0; k < NU; ++k) G[k] = gradu[k * B + b] - gradu_prev[k * B + b];
         for (int k = 0; k < NX; ++k) xp[k] = xi_prev[k * B + b];
         if constexpr (DEF == CM_UNIAXIAL_STRESS) {
-            const uint32_t stu = (m.ls_max_evals > 0) ? ru_newton<YK, true>(m, G[0], xp, x, true) : ru_newton<YK, false>(m, G[0], xp, x, true);
+            const uint32_t stu = HH_LS(m) ? ru_newton<YK, true>(m, G[0], xp, x, true) : ru_newton<YK, false>(m, G[0], xp, x, true);
             to_global<ROT>(m, x, sg);
             for (int k = 0; k < NX; ++k) xi[k * B + b] = x[k];
             for (int k = 0; k < 6; ++k) sigma[k * B + b] = sg[k];
@@ -198,13 +201,13 @@ static void run_update_rate(const cm_model_desc& m, int64_t B, const double* gra
         double parked[2 * 9];
         const LaneStage stage{parked, 1};
         uint32_t st;
-        if (hh_g_passes) st = (m.ls_max_evals > 0) ? newton_by_passes<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, stage)
+        if (hh_g_passes) st = HH_LS(m) ? newton_by_passes<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, true>(m, deg, z, xp, x, stage)
                                                    : newton_by_passes<(DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF, YK, CM_SMALL_RATE_ELASTIC_PLASTIC, false>(m, deg, z, xp, x, stage);
         else {      // same choice as k_update_rate: the structured solver where there is one; the "dense" variant keeps cm::newton
             constexpr int D2 = (DEF == CM_UNIAXIAL_STRESS) ? CM_FULL_3D : DEF;
-            if (g_dense) st = (m.ls_max_evals > 0) ? newton_rate_any<D2, YK, true, false>(m, deg, z, xp, x, true, stage)
+            if (g_dense) st = HH_LS(m) ? newton_rate_any<D2, YK, true, false>(m, deg, z, xp, x, true, stage)
                                                    : newton_rate_any<D2, YK, false, false>(m, deg, z, xp, x, true, stage);
-            else st = (m.ls_max_evals > 0) ? newton_rate_any<D2, YK, true, true>(m, deg, z, xp, x, true, stage)
+            else st = HH_LS(m) ? newton_rate_any<D2, YK, true, true>(m, deg, z, xp, x, true, stage)
                                            : newton_rate_any<D2, YK, false, true>(m, deg, z, xp, x, true, stage);
         }
         to_global<ROT>(m, x, sg);
@@ -310,7 +313,7 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
                         const double* wsq6, const double* xi0, double* xi_hist, double* out,
                         HistoryCotangents hc = HistoryCotangents{nullptr, nullptr, nullptr}) {
     for (int k = 0; k < 1 + CM_NUM_PARAMS; ++k) out[k] = 0.0;
-    const bool ls = m.ls_max_evals > 0;
+    const bool ls = HH_LS(m);
     for (int64_t b = 0; b < B; ++b) {
         double red[1 + CM_NUM_PARAMS] = {0.0};
         double parked[2 * 9];
@@ -334,7 +337,7 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
 template <int DEF, int YK, bool ROT, int MK>
 static void run_primal_history(const cm_model_desc& m, int64_t B, int K, const double* gradu_hist, const double* xi0,
                                double* xi_hist, double* sigma_hist, uint32_t* status_hist) {
-    const bool ls = m.ls_max_evals > 0;
+    const bool ls = HH_LS(m);
     for (int64_t b = 0; b < B; ++b) {
         double parked[2 * 9];
         const LaneStage stage{parked, 1};
@@ -656,6 +659,7 @@ void hh_exp_s(int64_t n, const double* x, double* y) { for (int64_t i = 0; i < n
 #if HH_HAS(0)
 void hh_set_dense(int d) { g_dense = d; }
 void hh_set_passes(int d) { hh_g_passes = d; }
+void hh_set_force_ls(int d) { hh_g_force_ls = d; }
 void hh_set_radial_vjp(int d) { hh_g_radial_vjp = d; }
 // points that left the J2 subspace iterations for the general path since the last reset (cm::subspace_fallbacks)
 long long hh_subspace_fallbacks(int reset) { const long long n = cm::subspace_fallbacks(); if (reset) cm::subspace_fallbacks() = 0; return n; }

@@ -605,3 +605,36 @@ def test_hybrid_surface_with_a_multi_layer_network(def_type, solver_variant):
     if solver_variant == "structured":
         pc.check_param_blocks_network(hh.param_blocks, def_type, layer_widths=DEEP)
         pc.check_second_derivs_network(hh.hessians, def_type, layer_widths=DEEP)
+
+
+@pytest.mark.parametrize("yield_kind,kw", pc.YIELDS)
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_plain_newton_through_the_line_search_kernels(def_type, yield_kind, kw, solver_variant):
+    """The library builds Hosford, the dense surfaces, the rate form and the HNN build with the line-search Newton loops only;
+    with ls_max_evals == 0 those loops take the full step without a merit test (uniform branch).  Same states, stresses and
+    status words, bit for bit, as the LS = false instantiations -- structured, dense and by passes, total and rate form
+    (UNIAXIAL_STRESS rate form: cm::ru_newton)."""
+    import numpy as np
+    import host_harness_lib as hh
+    sc = pc.Scenario(def_type, yield_kind, kw, True, False, B=384)
+    runs = [lambda: BACKEND.update(sc, sc.gradu, sc.xi1)]
+    if yield_kind in ("J2", "hill", "hosford"):
+        for dt in ((def_type, ol.UNIAXIAL_STRESS) if def_type == ol.FULL_3D else (def_type,)):
+            def rate_run(dt=dt):
+                outs = []
+                def upd(desc, info, g, gp, xp):
+                    r = hh.update_rate(desc, g, gp, xp, {0: 7, 2: 8, 3: 12}[desc.def_type])
+                    outs.extend(r)
+                    return r
+                pc.check_rate_model(upd, dt, yield_kind, kw, False, False, B=128)       # three load steps, checked against the oracle
+                return outs
+            runs.append(rate_run)
+    ref = [r() for r in runs]
+    hh.set_force_ls(True)
+    try:
+        got = [r() for r in runs]
+    finally:
+        hh.set_force_ls(False)
+    for a, b in zip(ref, got):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
