@@ -67,7 +67,9 @@ CM_D void newton_pass(const cm_model_desc& m, const double eg[6], const double* 
                 const double phi = 0.5 * dot<NX>(C, C);                // merit; phi(0) = cc / 2, phi'(0) = -cc
                 const bool finite = isfinite(phi);
                 if (finite && phi < s.best_phi) { s.best_alpha = s.alpha; s.best_phi = phi; }
-                const bool accepted = finite && (phi <= 0.5 * s.cc + s.alpha * (m.ls_c1 * -s.cc));
+                // ls_max_evals == 0 (uniform): plain Newton through this kernel -- the full step is the next iterate whatever its
+                // merit, exactly the LS = false code (the cold configurations are built once, cmad_hip.hip always_searches<>)
+                const bool accepted = (m.ls_max_evals <= 0) || (finite && (phi <= 0.5 * s.cc + s.alpha * (m.ls_c1 * -s.cc)));
                 ++s.n;
                 if (accepted) { ++s.it; at_iterate = true; }
                 else if (s.n < m.ls_max_evals) {
@@ -119,9 +121,7 @@ CM_D void newton_pass(const cm_model_desc& m, const double eg[6], const double* 
                         lu_subst<NX>(A, delta);
                     }
                 }
-                bool search = LS;                                       // LS kernels serve plain Newton too (uniform)
-                if constexpr (LS) search = (m.ls_max_evals > 0);
-                if (search) {
+                if constexpr (LS) {
 #pragma unroll
                     for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
                     s.cc = nsq; s.alpha = 1.0; s.best_alpha = 1.0; s.best_phi = INFINITY; s.n = 0;

@@ -448,7 +448,10 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
                     const double phi = 0.5 * norm.template sq<NX>(C);            // merit; phi(0) = cc / 2, phi'(0) = -cc
                     const bool finite = isfinite(phi);
                     if (finite && phi < best_phi) { best_alpha = alpha; best_phi = phi; }
-                    const bool accepted = finite && (phi <= 0.5 * cc + alpha * (m.ls_c1 * -cc));
+                    // ls_max_evals == 0 (uniform): plain Newton through this kernel -- the full step is the next iterate whatever
+                    // its merit, exactly the LS = false loop above (cmad_hip.hip always_searches<>; measured against an explicit
+                    // plain branch on the pool kernels: profiles/r03_ls_plain_fallback_ab.txt)
+                    const bool accepted = (m.ls_max_evals <= 0) || (finite && (phi <= 0.5 * cc + alpha * (m.ls_c1 * -cc)));
                     ++n;
                     if (accepted) commit = true;
                     else if (n < m.ls_max_evals) {
@@ -487,15 +490,9 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
                     op_build<YK>(m, ev, op);
                     if (!op.ok) flags |= CM_STATUS_SINGULAR;
                     if (!solve_s<DEF, false>(m, op, ev, z, C, delta)) flags |= CM_STATUS_SINGULAR;
-                    if (m.ls_max_evals <= 0) {      // uniform: plain Newton through this kernel (the full step is the next iterate)
 #pragma unroll
-                        for (int k = 0; k < NX; ++k) x[k] -= delta[k];
-                        ++it;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
-                        cc = nsq; alpha = 1.0; best_alpha = 1.0; best_phi = INFINITY; n = 0; phase = 1;
-                    }
+                    for (int k = 0; k < NX; ++k) { stage.at(k) = x[k]; stage.at(NX + k) = delta[k]; x[k] -= delta[k]; }
+                    cc = nsq; alpha = 1.0; best_alpha = 1.0; best_phi = INFINITY; n = 0; phase = 1;
                 }
             }
             if (!__any(running)) break;
