@@ -162,6 +162,11 @@ def history_workload(args, dev, rank, world, distributed):
     obj = BatchedCalibrationObjective(model, gradu_hist, data_hist, weight, fused_history=fused)
     for _ in range(max(1, args.warmup)):
         r = obj.evaluate_native()
+    # a generation-2 collection of the interpreter (tens of ms with torch loaded) inside a window of a few 1-ms evaluations
+    # would be timed as if it were the evaluation: collect before the window and keep the collector off inside it (as timeit does)
+    import gc
+    gc.collect()
+    gc.disable()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -172,6 +177,7 @@ def history_workload(args, dev, rank, world, distributed):
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

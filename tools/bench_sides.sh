@@ -24,3 +24,10 @@ run --workload j2_update_vjp --yield-surface hill
 run --workload j2_update_vjp --yield-surface hill --def-type plane_stress
 run --workload j2_update_vjp --yield-surface hosford8
 run --workload j2_update_vjp --yield-surface barlat8 --points 2000000
+run --workload hosford_update_vjp --steps 5
+run --workload hosford_update_tangent --steps 5
+run --workload hybrid_update_vjp --points 5000000 --steps 5
+run --workload hybrid_update_tangent --points 5000000 --steps 5
+run --workload calibration_history --steps 5
+run --workload j2_update --def-type uniaxial_stress --points 2000000
+run --workload j2_objective_grad --def-type uniaxial_stress --points 2000000
