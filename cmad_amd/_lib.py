@@ -17,7 +17,7 @@ CM_OK, CM_ERR_BAD_ARG, CM_ERR_UNSUPPORTED, CM_ERR_LAUNCH, CM_ERR_WORKSPACE = 0, 
 EXPORTS = ["cm_hessians", "cm_hessians_rate", "cm_update_rate_tangent", "cm_update_rate_vjp", "cm_update_rate_and_vjp",
            "cm_objective_grad_rate", "cm_adjoint_step_rate", "cm_evaluate_rate", "cm_update_rate", "cm_evaluate", "cm_abi_version", "cm_last_hip_error", "cm_sizeof_model_desc", "cm_update_and_vjp", "cm_num_xi", "cm_num_gradu", "cm_workspace_bytes", "cm_update",
            "cm_update_tangent", "cm_update_vjp", "cm_objective_grad", "cm_adjoint_step", "cm_objective_grad_history", "cm_update_history", "cm_direct_step",
-           "cm_param_blocks", "cm_param_adjoint_history", "cm_adjoint_history", "cm_direct_history", "cm_direct_workspace_bytes", "cm_hessian_history", "cm_hessian_workspace_bytes",
+           "cm_param_blocks", "cm_param_adjoint_history", "cm_update_complex", "cm_adjoint_history", "cm_direct_history", "cm_direct_workspace_bytes", "cm_hessian_history", "cm_hessian_workspace_bytes",
            "cm_direct_history_ep", "cm_hessian_history_ep", "cm_hessian_ep_workspace_bytes"]
 
 
@@ -106,6 +106,7 @@ def lib():
     L.cm_hessian_history_ep.argtypes = [md, i64, C.c_int32, C.c_int32, vp, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_double), dp, dp, dp, vp, i64, vp]
     L.cm_hessian_history_ep.restype = C.c_int
     L.cm_param_blocks.argtypes = [md, i64, C.c_int32, vp, dp, dp, dp, dp, dp, dp, vp]; L.cm_param_blocks.restype = C.c_int
+    L.cm_update_complex.argtypes = [md, i64, C.POINTER(C.c_double), dp, dp, dp, dp, dp, dp, vp, vp]; L.cm_update_complex.restype = C.c_int
     L.cm_param_adjoint_history.argtypes = [md, i64, C.c_int32, C.c_int32, vp, dp, dp, dp, dp, dp, vp, i64, vp]
     L.cm_param_adjoint_history.restype = C.c_int
     L.cm_update_history.argtypes = [md, i64, C.c_int32, dp, dp, dp, dp, vp, vp]; L.cm_update_history.restype = C.c_int

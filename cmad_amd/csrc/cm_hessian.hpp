@@ -62,6 +62,56 @@ CM_D D1 operator/(const D1& x, const D1& y) { const double i = 1.0 / y.v; return
 CM_D D1 operator/(const D1& x, double c) { return (1.0 / c) * x; }
 CM_D D1 operator/(double c, const D1& y) { const double i = 1.0 / y.v; return D1{c * i, -c * i * i * y.d}; }
 
+// complex scalars: the arithmetic of the reference's complex-step model instances (is_complex = True, e.g.
+// cmad/models/small_elastic_plastic.py:118-127: the whole model traced with complex dtype so that Im J(p + i h d) / h checks the
+// gradients, tests/objectives/test_J2_fd_checks.py:163-235).  Holomorphic continuations of the real functions; |z| and every
+// comparison follow the complex-step convention (decided on the real part), so the model stays analytic along the real axis.
+struct CX {
+    double re, im;
+};
+CM_D CX operator+(const CX& x, const CX& y) { return CX{x.re + y.re, x.im + y.im}; }
+CM_D CX operator-(const CX& x, const CX& y) { return CX{x.re - y.re, x.im - y.im}; }
+CM_D CX operator-(const CX& x) { return CX{-x.re, -x.im}; }
+CM_D CX operator*(const CX& x, const CX& y) { return CX{x.re * y.re - x.im * y.im, x.re * y.im + x.im * y.re}; }
+CM_D CX operator*(double c, const CX& x) { return CX{c * x.re, c * x.im}; }
+CM_D CX operator*(const CX& x, double c) { return c * x; }
+CM_D CX operator+(const CX& x, double c) { return CX{x.re + c, x.im}; }
+CM_D CX operator+(double c, const CX& x) { return x + c; }
+CM_D CX operator-(const CX& x, double c) { return CX{x.re - c, x.im}; }
+CM_D CX operator-(double c, const CX& x) { return CX{c - x.re, -x.im}; }
+CM_D CX cx_inv(const CX& y) { const double n = 1.0 / (y.re * y.re + y.im * y.im); return CX{y.re * n, -y.im * n}; }
+CM_D CX operator/(const CX& x, const CX& y) { return x * cx_inv(y); }
+CM_D CX operator/(const CX& x, double c) { return (1.0 / c) * x; }
+CM_D CX operator/(double c, const CX& y) { return c * cx_inv(y); }
+CM_D CX cx_sqrt(const CX& z) {                                  // principal branch, stable for |im| << |re|
+    const double r = sqrt(z.re * z.re + z.im * z.im);
+    if (r == 0.0) return CX{0.0, 0.0};
+    if (z.re >= 0.0) { const double a = sqrt(0.5 * (r + z.re)); return CX{a, 0.5 * z.im / a}; }
+    const double b = sqrt(0.5 * (r - z.re));
+    return CX{0.5 * fabs(z.im) / b, (z.im >= 0.0) ? b : -b};
+}
+CM_D CX cx_exp(const CX& z) { const double e = exp(z.re); return CX{e * cos(z.im), e * sin(z.im)}; }
+CM_D CX cx_log(const CX& z) { return CX{0.5 * log(z.re * z.re + z.im * z.im), atan2(z.im, z.re)}; }
+CM_D CX cx_abs(const CX& z) { return (z.re > 0.0) ? z : ((z.re < 0.0) ? -z : CX{0.0, 0.0}); }
+
+// dual numbers over the complex scalars: the Jacobian d C / d x of the complex residual, one column per evaluation
+struct DC {
+    CX v, d;
+};
+CM_D DC operator+(const DC& x, const DC& y) { return DC{x.v + y.v, x.d + y.d}; }
+CM_D DC operator-(const DC& x, const DC& y) { return DC{x.v - y.v, x.d - y.d}; }
+CM_D DC operator-(const DC& x) { return DC{-x.v, -x.d}; }
+CM_D DC operator*(const DC& x, const DC& y) { return DC{x.v * y.v, x.d * y.v + x.v * y.d}; }
+CM_D DC operator*(double c, const DC& x) { return DC{c * x.v, c * x.d}; }
+CM_D DC operator*(const DC& x, double c) { return c * x; }
+CM_D DC operator+(const DC& x, double c) { return DC{x.v + c, x.d}; }
+CM_D DC operator+(double c, const DC& x) { return x + c; }
+CM_D DC operator-(const DC& x, double c) { return DC{x.v - c, x.d}; }
+CM_D DC operator-(double c, const DC& x) { return DC{c - x.v, -x.d}; }
+CM_D DC operator/(const DC& x, const DC& y) { const CX i = cx_inv(y.v); return DC{x.v * i, (x.d - x.v * i * y.d) * i}; }
+CM_D DC operator/(const DC& x, double c) { return (1.0 / c) * x; }
+CM_D DC operator/(double c, const DC& y) { const CX i = cx_inv(y.v); return DC{c * i, -(c * i * i) * y.d}; }
+
 // scalar-type dispatch so the same templates run on double (host tests), D1 and HD
 CM_D double t_sqrt(double x) { return sqrt(x); }
 CM_D double t_exp(double x) { return exp(x); }
@@ -78,11 +128,27 @@ CM_D D1 t_exp(const D1& x) { const double e = exp(x.v); return d1_chain(x, e, e)
 CM_D D1 t_log(const D1& x) { return d1_chain(x, log(x.v), 1.0 / x.v); }
 CM_D D1 t_abs(const D1& x) { const double sg = (x.v > 0.0) ? 1.0 : ((x.v < 0.0) ? -1.0 : 0.0); return D1{fabs(x.v), sg * x.d}; }
 CM_D double t_val(const D1& x) { return x.v; }
+CM_D CX t_sqrt(const CX& x) { return cx_sqrt(x); }
+CM_D CX t_exp(const CX& x) { return cx_exp(x); }
+CM_D CX t_log(const CX& x) { return cx_log(x); }
+CM_D CX t_abs(const CX& x) { return cx_abs(x); }
+CM_D double t_val(const CX& x) { return x.re; }
+CM_D DC t_sqrt(const DC& x) { const CX r = cx_sqrt(x.v); return DC{r, (0.5 * cx_inv(r)) * x.d}; }
+CM_D DC t_exp(const DC& x) { const CX e = cx_exp(x.v); return DC{e, e * x.d}; }
+CM_D DC t_log(const DC& x) { return DC{cx_log(x.v), cx_inv(x.v) * x.d}; }
+CM_D DC t_abs(const DC& x) { return (x.v.re > 0.0) ? x : ((x.v.re < 0.0) ? -x : DC{CX{0.0, 0.0}, CX{0.0, 0.0}}); }
+CM_D double t_val(const DC& x) { return x.v.re; }
 // constants of type T, and the seed of a differentiation variable (D1: its one direction)
 template <class T> CM_D T t_const(double c);
 template <> CM_D double t_const<double>(double c) { return c; }
 template <> CM_D D1 t_const<D1>(double c) { return D1{c, 0.0}; }
 template <> CM_D HD t_const<HD>(double c) { return HD{c, 0.0, 0.0, 0.0}; }
+template <> CM_D CX t_const<CX>(double c) { return CX{c, 0.0}; }
+template <> CM_D DC t_const<DC>(double c) { return DC{CX{c, 0.0}, CX{0.0, 0.0}}; }
+CM_D void t_seed(CX&) {}
+CM_D void t_seed(DC& x) { x.d = CX{1.0, 0.0}; }
+CM_D void t_seed2(CX&) {}
+CM_D void t_seed2(DC&) {}
 CM_D void t_seed(double&) {}
 CM_D void t_seed(D1& x) { x.d = 1.0; }
 CM_D void t_seed(HD& x) { x.a = 1.0; }         // first differentiation direction of a hyper-dual ...
@@ -821,6 +887,82 @@ CM_D bool direct_column_ep(const cm_model_desc& m, const double* G, const double
 #pragma unroll
     for (int i = 0; i < NX; ++i) d[i] = rhs[i];
     return ok;
+}
+
+// ---- complex-step model instances: the imperative Newton on the complex residual ------------------------------------------
+// The reference builds `Model(parameters, def_type, is_complex=True)` (small_elastic_plastic.py:118-127,
+// small_rate_elastic_plastic.py:125-134) so that its tests can take Im J(p + i h d) / h as an AD-free directional derivative
+// (tests/objectives/test_J2_fd_checks.py:163-235, 355-386): newton_solve (nonlinear_solver.py:14-85) then iterates on complex
+// states with the holomorphic Jacobian.  Here: the arithmetic-T model with T = CX for the residual and T = DC (duals over CX,
+// one column per evaluation) for d C / d x, an unpivoted complex LU, the reference's stopping rule on ||C||_2.
+// p_im[CM_NUM_PARAMS]: imaginary parts of the native parameters (KP order); the real parts are the model description's.
+template <class T> CM_D void mat_add_imag(MatT<T>&, const double*);
+template <> CM_D void mat_add_imag<CX>(MatT<CX>& p, const double* p_im) {
+    p.lambda.im = p_im[CM_P_LAMBDA]; p.mu.im = p_im[CM_P_MU]; p.Y.im = p_im[CM_P_Y];
+    p.S.im = p_im[CM_P_VOCE_S]; p.D.im = p_im[CM_P_VOCE_D]; p.K.im = p_im[CM_P_LIN_K];
+    for (int k = 0; k < CM_NUM_PARAMS - CM_P_YC0; ++k) p.yc[k].im = p_im[CM_P_YC0 + k];
+}
+template <> CM_D void mat_add_imag<DC>(MatT<DC>& p, const double* p_im) {
+    p.lambda.v.im = p_im[CM_P_LAMBDA]; p.mu.v.im = p_im[CM_P_MU]; p.Y.v.im = p_im[CM_P_Y];
+    p.S.v.im = p_im[CM_P_VOCE_S]; p.D.v.im = p_im[CM_P_VOCE_D]; p.K.v.im = p_im[CM_P_LIN_K];
+    for (int k = 0; k < CM_NUM_PARAMS - CM_P_YC0; ++k) p.yc[k].v.im = p_im[CM_P_YC0 + k];
+}
+
+// x: in = the starting iterate, out = the returned state; C, sg: residual and global Cauchy stress at the returned state.
+// G: grad u (rate form: grad u - grad u_prev).  max_iters = 0 evaluates C and sg at x.  Returns the status word.
+template <int DEF, int YK, int MK>
+CM_D uint32_t newton_cx(const cm_model_desc& m, const double* p_im, const double* G, const CX* xp, CX* x, CX* C, CX sg[6]) {
+    constexpr int NX = nx_of<DEF, MK>();
+    MatT<CX> p;
+    mat_from_desc<CX>(m, p);
+    mat_add_imag<CX>(p, p_im);
+    MatT<DC> pd;
+    mat_from_desc<DC>(m, pd);
+    mat_add_imag<DC>(pd, p_im);
+    auto norm2 = [&]() { double n = 0.0; for (int k = 0; k < NX; ++k) n += C[k].re * C[k].re + C[k].im * C[k].im; return n; };
+    model_eval_T<DEF, YK, MK, CX>(m, p, G, x, xp, C, sg);
+    const double n0 = norm2(), rel2 = m.rel_tol * m.rel_tol * n0, abs2 = m.abs_tol * m.abs_tol;
+    uint32_t flags = 0;
+    int it = 0;
+    for (;;) {
+        const double nsq = norm2();
+        if ((nsq < rel2) || (nsq < abs2)) { flags |= CM_STATUS_CONVERGED; break; }
+        if (it >= m.max_iters) break;
+        CX A[NX][NX], delta[NX];
+        {
+            DC xd[NX], xpd[NX], Cd[NX], sgd[6];
+            for (int k = 0; k < NX; ++k) { xd[k] = DC{x[k], CX{0.0, 0.0}}; xpd[k] = DC{xp[k], CX{0.0, 0.0}}; }
+            for (int j = 0; j < NX; ++j) {
+                xd[j].d = CX{1.0, 0.0};
+                model_eval_T<DEF, YK, MK, DC>(m, pd, G, xd, xpd, Cd, sgd);
+                xd[j].d = CX{0.0, 0.0};
+                for (int k = 0; k < NX; ++k) A[k][j] = Cd[k].d;
+            }
+        }
+        for (int k = 0; k < NX; ++k) {                              // LU without pivoting (cm::lu_factor), complex
+            const CX piv = A[k][k];
+            if (!(piv.re * piv.re + piv.im * piv.im > 1e-300)) flags |= CM_STATUS_SINGULAR;
+            const CX ip = cx_inv(piv);
+            A[k][k] = ip;
+            for (int r = k + 1; r < NX; ++r) {
+                const CX l = A[r][k] * ip;
+                A[r][k] = l;
+                for (int c = k + 1; c < NX; ++c) A[r][c] = A[r][c] - l * A[k][c];
+            }
+        }
+        for (int k = 0; k < NX; ++k) delta[k] = C[k];
+        for (int k = 0; k < NX; ++k)
+            for (int r = k + 1; r < NX; ++r) delta[r] = delta[r] - A[r][k] * delta[k];
+        for (int k = NX - 1; k >= 0; --k) {
+            CX t = delta[k];
+            for (int c = k + 1; c < NX; ++c) t = t - A[k][c] * delta[c];
+            delta[k] = t * A[k][k];
+        }
+        for (int k = 0; k < NX; ++k) x[k] = x[k] - delta[k];
+        ++it;
+        model_eval_T<DEF, YK, MK, CX>(m, p, G, x, xp, C, sg);
+    }
+    return flags | (uint32_t)it;
 }
 
 }  // namespace cm

@@ -118,6 +118,36 @@ class ScaledHybridHillEffectiveStress(HybridHillEffectiveStress):
         self.max_iters, self.abs_tol, self.rel_tol = int(max_iters), float(abs_tol), float(rel_tol)
 
 
+def real_tree(values):
+    """The real parts of a (possibly complex) parameter tree: what `build_desc` describes for a complex-step model instance."""
+    from ..parameters.parameters import tree_map
+    return tree_map(lambda v: np.real(v) if np.iscomplexobj(v) else v, values)
+
+
+def complex_native_parameters(values, yield_type):
+    """The 12 native kernel parameters (KP order, include/cmad_hip.h) of a complex parameter tree, as complex numbers: the Lame
+    pair through the same conversion table as the real path (analytic in its arguments), the flow-stress and yield coefficients
+    as they are.  `cm_update_complex` takes the imaginary parts; the real parts are the model description's."""
+    from .elastic_constants import ElasticConstants
+    ec = ElasticConstants.from_params({k: complex(v) for k, v in values["elastic"].items()})
+    kp = np.zeros(_lib.CM_NUM_PARAMS, dtype=complex)
+    kp[_lib.P_LAMBDA], kp[_lib.P_MU] = ec.lmbda, ec.mu
+    fs = values["plastic"]["flow stress"]
+    kp[_lib.P_Y] = complex(fs["initial yield"]["Y"])
+    hard = fs.get("hardening", {}) or {}
+    if "voce" in hard:
+        kp[_lib.P_VOCE_S], kp[_lib.P_VOCE_D] = complex(hard["voce"]["S"]), complex(hard["voce"]["D"])
+    if "linear" in hard:
+        kp[_lib.P_LIN_K] = complex(hard["linear"]["K"])
+    eff = values["plastic"]["effective stress"]
+    if yield_type == "hill":
+        for i, n in enumerate(HILL_NAMES):
+            kp[_lib.P_YC0 + i] = complex(eff["hill"][n])
+    elif yield_type == "hosford":
+        kp[_lib.P_YC0] = complex(eff["hosford"]["a"])
+    return kp
+
+
 def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, uniaxial_stress_idx=0,
                newton: NewtonSettings | None = None, effective_stress_type: str | None = None, hybrid=None,
                hardening_nn=None):
@@ -422,6 +452,30 @@ class DeviceEvaluator:
                                    _ptr(sigma), _ptr(status), self._stream())
         _lib.check(rc, "cm_update_rate")
         return xi, sigma, status
+
+    def update_complex(self, p_imag, gradu, xi_prev, xi_start, gradu_prev=None):
+        """`cm_update_complex`: the local Newton solve of a complex-step model instance (reference `Model(..., is_complex=True)`
+        under `newton_solve`).  p_imag: (12,) imaginary parts of the native parameters (host); gradu (n_gradu, B) real;
+        xi_prev, xi_start (2, n_xi, B): real rows then imaginary rows.  Returns (xi (2, n_xi, B), residual (2, n_xi, B),
+        sigma (2, 6, B), status); `max_iters = 0` in the description evaluates residual and stress at xi_start."""
+        torch = _torch()
+        B = gradu.shape[1]
+        _check_soa(gradu, self.nu, B, "gradu")
+        gp = self._rate_prev(gradu_prev, B)
+        for t, name in ((xi_prev, "xi_prev"), (xi_start, "xi_start")):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+                    and tuple(t.shape) == (2, self.nx, B)):
+                raise ValueError(f"{name}: expected a contiguous float64 CUDA tensor of shape (2, {self.nx}, {B})")
+        dev = gradu.device
+        xi = xi_start.clone()
+        res = torch.empty((2, self.nx, B), dtype=torch.float64, device=dev)
+        sigma = torch.empty((2, 6, B), dtype=torch.float64, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        pim = (C.c_double * _lib.CM_NUM_PARAMS)(*[float(v) for v in p_imag])
+        rc = self.L.cm_update_complex(C.byref(self.desc), B, pim, _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(xi), _ptr(res),
+                                      _ptr(sigma), _ptr(status), self._stream())
+        _lib.check(rc, "cm_update_complex")
+        return xi, res, sigma, status
 
     def _rate_prev(self, gradu_prev, B):
         """The rate-form model (desc.model_kind = 1) takes the previous grad u in every entry point."""

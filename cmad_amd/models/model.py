@@ -63,9 +63,8 @@ class Model(ABC):
         return {}
 
     def __init__(self) -> None:
-        if getattr(self, "_is_complex", False):
-            # the reference's complex-step models (is_complex=True) rely on holomorphic JAX tracing
-            raise NotImplementedError("complex-step models are not available in the HIP path")
+        if getattr(self, "_is_complex", False) and (self._hybrid is not None or self._hardening_nn is not None):
+            raise NotImplementedError("complex-step instances: J2 / Hill / Hosford with Voce / linear hardening (cm_update_complex)")
         self._deriv_mode = DerivType.DNONE
         self.newton_settings = NewtonSettings()
         self.parameters.compute_mixed_block_shapes(self._num_eqs)
@@ -74,6 +73,9 @@ class Model(ABC):
 
     # ------------------------------------------------------------------ device plumbing
     def _desc(self, params=None, newton: NewtonSettings | None = None):
+        if getattr(self, "_is_complex", False):             # complex-step instance: the description carries the real parts
+            from .device import real_tree
+            params = real_tree(self.parameters.values if params is None else params)
         return build_desc(self.parameters.values if params is None else params, def_type=self._def_type,
                           model_kind=self._model_kind, yield_tol=self._yield_tol,
                           uniaxial_stress_idx=self._uniaxial_stress_idx, newton=newton or self.newton_settings,
@@ -183,9 +185,42 @@ class Model(ABC):
                 for pos, path in enumerate(self.parameters.active_paths())]
         return np.stack(cols, axis=1) if cols else np.zeros((M_kp.shape[0], 0))
 
+    # ------------------------------------------------------------------ complex-step instances (reference: is_complex=True)
+    def _complex_arrays(self):
+        """(p_imag (12,), gradu (n, 1), gradu_prev or None, xi_prev (2, n_xi, 1), xi (2, n_xi, 1)) of the gathered state."""
+        from .device import complex_native_parameters
+        _, info = self._desc()
+        kp = complex_native_parameters(self.parameters.values, info["yield_type"])
+        split = lambda blocks: np.stack([f(np.concatenate([np.atleast_1d(np.asarray(b, dtype=complex)).ravel() for b in blocks]))
+                                         for f in (np.real, np.imag)])[:, :, None]
+        G = np.asarray(self._U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
+        Gp = np.asarray(self._U_prev.grad_fields["u"], dtype=np.float64).reshape(-1, 1) if self._model_kind == 1 else None
+        return kp.imag.copy(), G, Gp, np.ascontiguousarray(split(self._xi_prev)), np.ascontiguousarray(split(self._xi))
+
+    def _complex_solve(self, settings: NewtonSettings):
+        """One `cm_update_complex` launch at the gathered state, started at the current xi: (xi, C, sigma6, status word), complex."""
+        import torch
+        p_im, G, Gp, xp, x0 = self._complex_arrays()
+        ev = self.device_evaluator(settings)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+        xi, res, sig, status = ev.update_complex(p_im, t(G), t(xp), t(x0), gradu_prev=t(Gp))
+        c = lambda a: a.cpu().numpy()[0, :, 0] + 1j * a.cpu().numpy()[1, :, 0]
+        return c(xi), c(res), c(sig), int(status.cpu().numpy().astype(np.uint32)[0])
+
+    def _complex_values(self):
+        """Residual and stress of a complex-step instance at its current state (values only: such an instance exists to be
+        differentiated by the complex step itself)."""
+        if self._deriv_mode != DerivType.DNONE:
+            raise NotImplementedError("complex-step instances evaluate values (DerivType.DNONE); derivatives come from the real model")
+        _, Cv, s6, _ = self._complex_solve(NewtonSettings(0, self.newton_settings.abs_tol, self.newton_settings.rel_tol, {"max evals": 0}))
+        return Cv, s6
+
     # ------------------------------------------------------------------ reference :168-190
     def evaluate(self) -> None:
         """Evaluate the residual (C) or its jacobian (Jac)."""
+        if getattr(self, "_is_complex", False):
+            self._C, self._Jac = self._complex_values()[0], None
+            return
         xi, xi_prev, params, U, U_prev = self.variables()
         mode = self._deriv_mode
         if mode == DerivType.DNONE:
@@ -279,6 +314,9 @@ class Model(ABC):
     # ------------------------------------------------------------------ reference :273-293
     def evaluate_cauchy(self) -> None:
         """Evaluate the cauchy stress (Sigma) or its derivatives (dSigma)."""
+        if getattr(self, "_is_complex", False):
+            self._Sigma, self._dSigma = _sym3(self._complex_values()[1]), None
+            return
         xi, xi_prev, params, U, U_prev = self.variables()
         mode = self._deriv_mode
         if mode == DerivType.DNONE:
@@ -536,6 +574,8 @@ class Model(ABC):
         (iters, converged).  Same algorithm as newton_solve / make_newton_solve (nonlinear_solver.py)."""
         import torch
         st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0})
+        if getattr(self, "_is_complex", False):
+            return self._complex_newton(st)
         ev = self.device_evaluator(st)
         dev = torch.device("cuda")
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 1)).to(dev)
@@ -543,6 +583,13 @@ class Model(ABC):
         xi, _, status = ev.update(t(G), t(self._flat(self._xi_prev)), want_sigma=False)
         self._xi = [b.astype(self.dtype) for b in self._split(xi.cpu().numpy()[:, 0])]
         s = int(status.cpu().numpy().astype(np.uint32)[0])
+        return s & _lib.STATUS_ITERS_MASK, bool(s & _lib.STATUS_CONVERGED)
+
+    def _complex_newton(self, st: NewtonSettings):
+        if st.line_search.get("max evals", 0) > 0:
+            raise NotImplementedError("complex-step instances: plain Newton steps (the reference's tests use newton_solve defaults)")
+        xi, _, _, s = self._complex_solve(st)
+        self._xi = [np.asarray(b, dtype=complex) for b in self._split(xi)]
         return s & _lib.STATUS_ITERS_MASK, bool(s & _lib.STATUS_CONVERGED)
 
     # ------------------------------------------------------------------ batched API (new capability)

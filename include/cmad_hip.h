@@ -488,6 +488,22 @@ int cm_param_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, int32
                              const double* sigma_bar_hist, double* grad_ep,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
+/*
+ * Complex-step model instances.  The reference can build a model with complex dtype, Model(parameters, def_type,
+ * is_complex=True) (cmad/models/small_elastic_plastic.py:118-127, small_rate_elastic_plastic.py:125-134), so that
+ * Im J(p + i h d) / h gives a directional derivative of an objective that uses no derivative code at all
+ * (tests/objectives/test_J2_fd_checks.py:163-235, 355-386).  cm_update_complex is the local solve of such an instance: the
+ * imperative Newton (cmad/models/nonlinear_solver.py:14-85, plain steps) on the complex residual with the holomorphic Jacobian;
+ * |.| and the branch select are decided on real parts (complex-step convention).
+ *   in : p_im[CM_NUM_PARAMS] (HOST) imaginary parts of the native parameters, KP order -- the real parts are the description's;
+ *        gradu[n_gradu][B] (real), gradu_prev (rate form, else NULL), xi_prev[2][n_xi][B] (real rows, then imaginary rows)
+ *   i/o: xi[2][n_xi][B]: in = the starting iterate (the reference starts at the model's current state), out = the returned state
+ *   out: residual[2][n_xi][B], sigma[2][6][B] at the returned state (either may be NULL), status[B] (may be NULL)
+ * max_iters = 0 evaluates residual and stress at xi.  J2 / Hill / Hosford; both model kinds; every deformation type.
+ */
+int cm_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* gradu, const double* gradu_prev,
+                      const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

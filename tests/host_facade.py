@@ -54,6 +54,15 @@ class HostHistoryEngine:
         return g
 
 
+def _host_complex_solve(model, settings):
+    """Model._complex_solve on the host build of cm::newton_cx."""
+    p_im, G, Gp, xp, x0 = model._complex_arrays()
+    desc, _ = model._desc(newton=settings)
+    xi, res, sig, st = hh.update_complex(desc, p_im, G, xp, x0, gradu_prev=Gp)
+    c = lambda a: a[0, :, 0] + 1j * a[1, :, 0]
+    return c(xi), c(res), c(sig), int(st[0])
+
+
 class HostSmallElasticPlastic(SmallElasticPlastic):
     def history_engine(self, newton=None):
         return HostHistoryEngine(self, newton)
@@ -75,6 +84,8 @@ class HostSmallElasticPlastic(SmallElasticPlastic):
 
     def device_newton(self, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search=None):
         st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0})
+        if self._is_complex:
+            return self._complex_newton(st)
         desc, info = self._desc(newton=st)
         G = np.asarray(self._U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
         xi, sig, status = hh.update(desc, G, self._flat(self._xi_prev).reshape(-1, 1), self.num_dofs)
@@ -87,6 +98,9 @@ class HostSmallElasticPlastic(SmallElasticPlastic):
         G = np.asarray(U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
         dC, dS = hh.param_blocks(desc, ep_list, G, self._flat(xi_prev).reshape(-1, 1), self._flat(xi).reshape(-1, 1), self.num_dofs)
         return dC[:, :, 0], dS[:, :, 0]
+
+    def _complex_solve(self, settings):
+        return _host_complex_solve(self, settings)
 
     def _second_derivative_pass(self):
         xi, xi_prev, params, U, U_prev = self.variables()

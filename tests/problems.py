@@ -147,3 +147,81 @@ def check_named_derivatives(ModelClass):
         if elem is not None:
             leaf = leaf[(slice(None),) + elem]
         np.testing.assert_allclose(leaf, fd, rtol=1e-6, atol=1e-12)
+
+
+def check_complex_step(ModelCls, scale_params, num_pts_per_increment=50):
+    """The complex-step half of the reference's tests/objectives/test_J2_fd_checks.py:301-386 (plane_stress_fd_checks): a
+    second model instance built with is_complex=True evaluates the objective at p + i h d (gradient: :163-197) and at
+    p + h d e^{+-i pi/3} (Hessian: :200-235) by stepping through the history with newton_solve, and the AD-free directional
+    derivatives must approach those of MPDirectObjective / MPAdjointObjective / MPDirectAdjointObjective of the REAL model
+    with an error that drops by more than five decades over h = 1 ... 1e-9."""
+    from cmad_amd.models import DefType, mp_U_from_F, newton_solve
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectAdjointObjective, MPDirectObjective
+    from cmad_amd.qois import Calibration
+
+    def run_history(model, per_step):
+        model.set_xi_to_init_vals()
+        for step in range(1, F.shape[2]):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            model.seed_xi()
+            newton_solve(model)
+            model.seed_none()
+            per_step(step)
+            model.advance_xi()
+
+    F = plane_stress_F(0.02, num_pts_per_increment)
+    model = ModelCls(params_J2_voce(scale_params=scale_params), DefType.PLANE_STRESS, is_complex=False)
+    cauchy = np.zeros((3, 3, F.shape[2]))
+
+    def store(step):
+        model.evaluate_cauchy()
+        cauchy[:, :, step] = model.Sigma()
+    run_history(model, store)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.
+    qoi = Calibration(model, cauchy, weight)
+    model_c = ModelCls(params_J2_voce(scale_params=scale_params), DefType.PLANE_STRESS, is_complex=True)
+    qoi_c = Calibration(model_c, cauchy.astype(complex), weight)
+    assert model_c.dtype is complex
+
+    def J_complex(flat_complex):
+        model_c.parameters.set_active_values_from_flat(flat_complex, is_complex=True)
+        acc = [0.0 + 0.0j]
+
+        def add(step):
+            qoi_c.evaluate(step)
+            acc[0] = acc[0] + qoi_c.J()
+        run_history(model_c, add)
+        return complex(acc[0])
+
+    # evaluate away from the values the data came from, like the reference
+    offset = 1.1 * model.parameters.flat_active_values(False)
+    model.parameters.set_active_values_from_flat(offset, False)
+    model_c.parameters.set_active_values_from_flat(offset.astype(complex), False, is_complex=True)
+    x = model.parameters.flat_active_values(True)
+    x_c = model_c.parameters.flat_active_values(True).astype(complex)
+    np.testing.assert_allclose(x_c.real, x, rtol=1e-14)
+    _, g_direct = MPDirectObjective(qoi, F).evaluate(x)
+    _, g_adjoint = MPAdjointObjective(qoi, F).evaluate(x)
+    J_ref, _, H = MPDirectAdjointObjective(qoi, F).evaluate(x)
+    np.random.seed(22)
+    d = np.random.uniform(low=-1.0, size=x.size)
+    hs = np.logspace(0, -9, 10)
+    # with no perturbation the complex instance reproduces the real objective
+    J0 = J_complex(x_c)
+    assert abs(J0.imag) == 0.0 and abs(J0.real - J_ref) <= 1e-9 * max(1.0, abs(J_ref))
+    err_d, err_a, err_h = [], [], []
+    for h in hs:
+        dd = J_complex(x_c + 1j * h * d).imag / h
+        err_d.append(abs(dd - d @ g_direct)); err_a.append(abs(dd - d @ g_adjoint))
+        J1 = J_complex(x_c + complex(0.5, np.sqrt(3.) / 2.) * h * d)
+        J2 = J_complex(x_c + complex(-0.5, -np.sqrt(3.) / 2.) * h * d)
+        err_h.append(abs((J1 + J2).imag / (np.sqrt(3.) / 2. * h ** 2) - d @ H @ d))
+    err_d, err_a, err_h = np.array(err_d), np.array(err_a), np.array(err_h)
+    assert np.isfinite(err_d).all() and np.isfinite(err_h).all()
+    assert np.allclose(err_d, err_a)
+    tiny = 1e-300
+    assert np.log10(err_d.max() / max(err_d.min(), tiny)) > 5.0
+    assert np.log10(err_h.max() / max(err_h.min(), tiny)) > 5.0
+    # the complex step has no subtractive cancellation: at h = 1e-9 the directional derivative is exact to round-off
+    assert err_d[-1] <= 1e-9 * max(1.0, abs(d @ g_direct))
+    model_c.parameters.set_active_values_from_flat(x_c, is_complex=True)

@@ -940,3 +940,13 @@ def test_direct_adjoint_hessian_with_extended_leaves(yield_kind, active_rotation
         xp_[k] += h; xm_[k] -= h
         H_fd[:, k] = (MPAdjointObjective(qoi, F).evaluate(xp_).grad - MPAdjointObjective(qoi, F).evaluate(xm_).grad) / (2 * h)
     np.testing.assert_allclose(H, H_fd, rtol=2e-4, atol=2e-5 * np.abs(H).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,scale_params", [(False, False), (True, True)])
+def test_complex_step_model_instances(rate, scale_params):
+    """The reference's complex-step checks (tests/objectives/test_J2_fd_checks.py:301-386: SmallElasticPlastic unscaled,
+    SmallRateElasticPlastic with scaled parameters) through `Model(..., is_complex=True)` on cm_update_complex."""
+    from cmad_amd.models import SmallElasticPlastic, SmallRateElasticPlastic
+    from problems import check_complex_step
+    check_complex_step(SmallRateElasticPlastic if rate else SmallElasticPlastic, scale_params, num_pts_per_increment=25)

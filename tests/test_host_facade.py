@@ -261,3 +261,12 @@ def test_direct_adjoint_hessian_with_extended_leaves(yield_kind, active_rotation
         xp_[k] += h; xm_[k] -= h
         H_fd[:, k] = (MPAdjointObjective(qoi, F).evaluate(xp_).grad - MPAdjointObjective(qoi, F).evaluate(xm_).grad) / (2 * h)
     np.testing.assert_allclose(H, H_fd, rtol=2e-4, atol=2e-5 * np.abs(H).max())
+
+
+@pytest.mark.parametrize("scale_params", [False, True])
+def test_complex_step_model_instances(scale_params):
+    """`Model(..., is_complex=True)`: tests/objectives/test_J2_fd_checks.py:301-386 (complex-step gradient and Hessian checks of
+    the three material-point objectives) on the host build of cm::newton_cx; the GPU twin runs both model forms through
+    cm_update_complex."""
+    from problems import check_complex_step
+    check_complex_step(HostSmallElasticPlastic, scale_params, num_pts_per_increment=12)
