@@ -242,16 +242,22 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     return d, info
 
 
+class _ExtendedLeaf(NotImplementedError):
+    """The leaf is not among the 12 native kernel parameters: its sensitivities come from the forward-mode entry points
+    (`leaf_ep_index` -> cm_param_blocks / cm_param_adjoint_history / cm_*_history_ep).  Callers catch this and take that route."""
+
+
 def kp_to_leaf_grad(path, g_kp, info):
     """Sensitivity w.r.t. the parameter-tree leaf at `path` from the kernel's KP-order vector
-    (include/cmad_hip.h `cm_param_index`).  `g_kp` may have trailing batch/row dims on axis 0 = KP."""
+    (include/cmad_hip.h `cm_param_index`).  `g_kp` may have trailing batch/row dims on axis 0 = KP.
+    Raises `_ExtendedLeaf` (a NotImplementedError) for the leaves served by `leaf_ep_index` instead."""
     leaf = path[-1]
     if path[0] == "elastic":
         j = info["elastic_names"].index(leaf)
         J = info["lame_jac"]
         return g_kp[_lib.P_LAMBDA] * J[0, j] + g_kp[_lib.P_MU] * J[1, j]
     if path[0] == "rotation matrix":
-        raise NotImplementedError("sensitivities w.r.t. the rotation matrix are not available in the HIP path")
+        raise _ExtendedLeaf("rotation matrix: extended parameter (leaf_ep_index)")
     if leaf == "Y":
         return g_kp[_lib.P_Y]
     parent = path[-2] if len(path) >= 2 else None
@@ -261,16 +267,16 @@ def kp_to_leaf_grad(path, g_kp, info):
         return g_kp[_lib.P_LIN_K]
     if parent == "hill":
         if info.get("yield_type") == "hybrid":
-            raise NotImplementedError("Hill-coefficient sensitivities of the hybrid Hill+NN surface are not available")
+            raise _ExtendedLeaf("Hill coefficients of the hybrid surface: extended parameters (leaf_ep_index)")
         return g_kp[_lib.P_YC0 + HILL_NAMES.index(leaf)]
     if "neural network" in path:
-        raise NotImplementedError("sensitivities w.r.t. network weights are not available in the HIP path")
+        raise _ExtendedLeaf("network weights: extended parameters (leaf_ep_index)")
     if parent == "effective stress" and leaf == "J2":
         return g_kp[0] * 0.0
     if parent == "hosford":
-        raise NotImplementedError("sensitivity w.r.t. the Hosford exponent is not available in the HIP path")
+        raise _ExtendedLeaf("Hosford exponent: extended parameter (leaf_ep_index)")
     if parent == "barlat":
-        raise NotImplementedError("sensitivities w.r.t. the Barlat coefficients are not available in the HIP path")
+        raise _ExtendedLeaf("Barlat coefficients: extended parameters (leaf_ep_index)")
     raise KeyError(path)
 
 

@@ -18,7 +18,8 @@ class QoI(ABC):
         raise NotImplementedError
 
     def evaluate_hessians(self, step) -> None:
-        raise NotImplementedError("QoI Hessians are a SURVEY section 8(f) 'next' row")
+        raise NotImplementedError("abstract: Calibration.evaluate_hessians is the per-step form; the objectives take the "
+                                  "whole-history route (stress_curvature / state_curvature with cm_hessian_history)")
 
     def J(self):
         return self._J
