@@ -72,6 +72,27 @@ class UniaxialCalibration(QoI):
         h[0] = 0.0
         return h
 
+    def evaluate_hessians(self, step) -> None:
+        """d2J_dxi2 (n_xi, n_xi), d2J_dxi_dparams (n_xi, P), d2J_dparams2 (P, P) at the model's current state (reference
+        qoi.py:160-188 with `_qoi` of uniaxial_calibration.py:70-85): the axial-stress term through the model's first and second
+        stress derivatives (cm_hessians), the two stretch terms -- linear in the state -- as their constant diagonal."""
+        model = self._model
+        d2C, d2S, dC, dS, info, nx = model._second_derivative_pass()
+        T1, T2 = model._param_chain(info)
+        d, w = self.data_at_step(step), self.weight_at_step(step)
+        r_aa = (0, 3, 5)[self._idx]
+        model.seed_none(); model.evaluate_cauchy()
+        r = w[0] ** 2 * (model.Sigma()[self._idx, self._idx] - d[0])
+        Hq = w[0] ** 2 * np.outer(dS[r_aa], dS[r_aa]) + r * d2S[r_aa]
+        gq = r * dS[r_aa]
+        off = model.delta_xi_offset(self._svar, 0)
+        Hq[off, off] += w[1] ** 2
+        Hq[off + 1, off + 1] += w[2] ** 2
+        a, c = slice(0, nx), slice(2 * nx, None)
+        self.d2J_dxi2 = Hq[a, a]
+        self.d2J_dxi_dparams = Hq[a, c] @ T1
+        self.d2J_dparams2 = T1.T @ Hq[c, c] @ T1 + np.einsum("p,pij->ij", gq[c], T2)
+
     def evaluate(self, step) -> None:
         """reference qoi.py:80-110 with `_qoi` of uniaxial_calibration.py:70-85."""
         model = self._model

@@ -199,6 +199,38 @@ def test_direct_adjoint_hessian_of_the_uniaxial_calibration_qoi():
     H2 = MPDirectAdjointObjective(q2, F).evaluate(x).hessian
     assert np.abs(H2 - H).max() > 1e-4 * np.abs(H).max()
     assert not np.allclose(H2, H_fd, rtol=5e-5, atol=5e-6 * np.abs(H).max())
+    # the per-step form (reference QoI.evaluate_hessians, qoi.py:160-188) at the state of the last step, against central
+    # differences of the QoI's own first derivatives
+    model.parameters.set_active_values_from_flat(x)
+    model.set_xi_to_init_vals()
+    for step in range(1, K + 1):
+        model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+        newton_solve(model)
+        if step < K:
+            model.advance_xi()
+    qoi.evaluate_hessians(K)
+    xi0 = [b.copy() for b in model.xi()]
+
+    def dJ_dxi():
+        model.seed_xi(); qoi.evaluate(K); model.seed_none()
+        return np.asarray(qoi.dJ()).ravel().copy()
+    n_xi = model.num_dofs
+    fd = np.zeros((n_xi, n_xi))
+    col = 0
+    for blk in range(len(xi0)):
+        for e in range(xi0[blk].size):
+            hh_ = 1e-7 * max(1.0, abs(xi0[blk].ravel()[e]))
+            g = []
+            for sgn in (1.0, -1.0):
+                model._xi = [b.copy() for b in xi0]
+                model._xi[blk].ravel()[e] += sgn * hh_
+                g.append(dJ_dxi())
+            fd[:, col] = (g[0] - g[1]) / (2 * hh_)
+            col += 1
+    model._xi = [b.copy() for b in xi0]
+    np.testing.assert_allclose(qoi.d2J_dxi2, fd, rtol=1e-5, atol=1e-6 * np.abs(fd).max())
+    assert qoi.d2J_dxi_dparams.shape == (n_xi, x.size) and qoi.d2J_dparams2.shape == (x.size, x.size)
+    assert np.isfinite(qoi.d2J_dxi_dparams).all() and np.isfinite(qoi.d2J_dparams2).all()
 
 
 def test_network_hardening_law_through_the_model_api():
