@@ -258,6 +258,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")           # set by torch.distributed.run; only the 1-rank rehearsal lacks it
         # RCCL prints a version banner on stdout when its communicator comes up; stdout is reserved for the one JSON
         # line, so the communicator is created (init + one tiny all-reduce) with fd 1 pointed at stderr.
         sys.stdout.flush()
