@@ -347,6 +347,10 @@ CM_D void icnn_symmetric(const double* __restrict__ w, int H, const double xs[6]
     double rn[kIcnnRec];
 #pragma unroll
     for (int i = 0; i < kIcnnRec; ++i) rn[i] = rec[i];
+#ifndef CM_ICNN_UNROLL
+#define CM_ICNN_UNROLL 1            // experiment knob: units per loop iteration; 2 and 4 measured equal (profiles/r03_icnn_unroll_ab.txt)
+#endif
+#pragma unroll CM_ICNN_UNROLL
     for (int o = 0; o < H; ++o) {
         double r[kIcnnRec];
 #pragma unroll
