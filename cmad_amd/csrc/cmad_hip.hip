@@ -2,6 +2,7 @@
 // gfx950 only.  One Gauss point per lane; SoA arrays so that lane b of a wavefront reads
 // element [k*B + b] -> every global access is a 512-byte contiguous row per wave instruction.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
 // Two builds of this file make the library (cmad_amd/build.py): the BASE build (CM_HNN_VARIANT = 0) without the network hardening
 // law -- so that law costs the Voce / linear configurations nothing, not an instruction and not a register (inlined into every
@@ -238,6 +239,23 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>
 #endif
 constexpr int kPoolHalf = 32;            // points per staged half (one LDS-DMA instruction moves 4 rows of it in 16-byte pieces)
 
+// Counters of the dynamic half assignment: one per launch, taken round-robin from a small ring and zeroed on the launch's
+// stream right before the kernel (64 launches would have to be in flight at once for two of them to share a counter).
+#ifndef CM_POOL_DYNAMIC
+#define CM_POOL_DYNAMIC 1
+#endif
+constexpr int kPoolTicketSlots = 64;
+__device__ unsigned long long g_pool_ticket[kPoolTicketSlots];
+inline unsigned long long* pool_ticket_slot() {
+    static unsigned long long* const base = [] {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pool_ticket)) != hipSuccess) p = nullptr;
+        return (unsigned long long*)p;
+    }();
+    static std::atomic<unsigned> next{0};
+    return base ? base + (next.fetch_add(1) % kPoolTicketSlots) : nullptr;
+}
+
 template <int DEF, int YK>
 constexpr int min_waves_pool() { return is_dense_yield(YK) ? CM_POOL_WAVES_NN : CM_POOL_WAVES_HOSFORD; }
 // Where the pool pays (measured, profiles/r02_pool_ab.txt): a pass must cost much more than the retire / refill bookkeeping and
@@ -254,7 +272,7 @@ typedef __attribute__((address_space(3))) void* cm_lds_vptr;
 typedef const __attribute__((address_space(1))) void* cm_gvptr;
 
 template <int DEF, int YK, bool ROT, bool LS>
-__global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int chunk_shift, int wide,
+__global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int chunk_shift, int wide, unsigned long long* __restrict__ ticket,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NIN = NU + NX;
@@ -265,17 +283,35 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
     volatile cm_lds_double* const ringl = (volatile cm_lds_double*)ring;
     const unsigned lane = threadIdx.x;
     const int64_t nwaves = gridDim.x;
-    // The wavefront's stream in halves of 32 points: half h lies in chunk (blockIdx.x + (h >> hshift) * nwaves) at offset
-    // (h & hmask) * 32; its first point is half_base(h).  Chunks hold 2^chunk_shift points (a multiple of 32).
+    // The wavefront's stream in halves of 32 points.  Static assignment (ticket == nullptr; small batches): half h lies in chunk
+    // (blockIdx.x + (h >> hshift) * nwaves) at offset (h & hmask) * 32; chunks hold 2^chunk_shift points (a multiple of 32).
+    // Dynamic assignment (large batches): every half is the next 32 points of the batch, taken from a device counter when its
+    // copy is issued -- wavefronts that run faster (or drew cheaper points) simply take more halves, so the grid drains together
+    // instead of waiting for its slowest static share (round-3 counters: the mean wavefront lived 77-82 % of the kernel).  A
+    // point's result does not depend on which lane computes it, so the output is the same either way.
     const int hshift = chunk_shift - 5, hmask = (1 << hshift) - 1;
-#define CM_HALF_BASE(h) ((((int64_t)blockIdx.x + (int64_t)((h) >> hshift) * nwaves) << chunk_shift) + (int64_t)(((h) & hmask) * kPoolHalf))
+    volatile __shared__ long long hbase[4];                      // first point of the halves in flight (index: half & 3)
+#define CM_HALF_BASE_STATIC(h) ((((int64_t)blockIdx.x + (int64_t)((h) >> hshift) * nwaves) << chunk_shift) + (int64_t)(((h) & hmask) * kPoolHalf))
     int next_issue = 0, ready = 0, cons_half = 0, cons_off = 0;  // wave-uniform cursors: issued / arrived / handed out
     bool stream_end = false;
     // issue the LDS-DMA copies of every half whose ring slot is free (at most two halves ahead of the consumer)
 #define CM_TRY_ISSUE() \
     while (!stream_end && next_issue < cons_half + 2) { \
-        const int64_t g0_ = CM_HALF_BASE(next_issue); \
+        int64_t g0_; \
+        if (ticket) { \
+            /* the next chunk of 2^chunk_shift points of the batch, drawn when its first half is issued.  A SCALAR atomic: one */ \
+            /* request per wavefront, the result in SGPRs, and its wait (lgkmcnt) does not drain the vector memory queue.  One */ \
+            /* ticket per CHUNK, not per half: all wavefronts hit one address, and the device serves ~80 M same-address atomics */ \
+            /* per second -- 312 500 tickets of 32 points took 3.9 ms by themselves (profiles/r03_pool_dynamic_ab.txt) */ \
+            if ((next_issue & hmask) == 0) { \
+                unsigned long long r_, inc_ = 1ull << chunk_shift; \
+                asm volatile("s_atomic_add_x2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) : "s"(ticket), "0"(inc_) : "memory"); \
+                dyn_base = (int64_t)r_; \
+            } \
+            g0_ = dyn_base + (int64_t)((next_issue & hmask) * kPoolHalf); \
+        } else g0_ = CM_HALF_BASE_STATIC(next_issue); \
         if (g0_ >= B) { stream_end = true; break; } \
+        if (lane == 0) hbase[next_issue & 3] = g0_; \
         const unsigned dst_ = (unsigned)__builtin_amdgcn_readfirstlane((next_issue & 1) * NIN * kPoolHalf); \
         if (wide) { \
             int64_t pt_ = g0_ + 2 * (lane & 15); \
@@ -308,6 +344,7 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
     bool running = false;
     PassState st;
     pass_reset(st);
+    int64_t dyn_base = 0;                                        // wave-uniform: first point of the chunk being issued (dynamic assignment)
     CM_TRY_ISSUE()
     for (;;) {
         const uint64_t idle_mask = __ballot(!running);
@@ -348,7 +385,9 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
                 int need = nidle, first = 0, slot = -1;
                 while (need > 0 && cons_half < ready) {          // uniform; confirmed halves only (at most two per refill)
-                    const int64_t g0 = CM_HALF_BASE(cons_half);
+                    const long long hb = hbase[cons_half & 3];     // written when the half was issued (same wavefront: in order)
+                    const int64_t g0 = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)hb >> 32)) << 32) |
+                                                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)hb & 0xffffffffull)));
                     const int vc = (B - g0 < kPoolHalf) ? (int)(B - g0) : kPoolHalf;     // >= 1: only halves that start below B are issued
                     const int avail = vc - cons_off;
                     const int take = need < avail ? need : avail;
@@ -378,7 +417,7 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
         newton_pass<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS>(m, eg, z, xp, x, st, running, stage);
     }
 #undef CM_TRY_ISSUE
-#undef CM_HALF_BASE
+#undef CM_HALF_BASE_STATIC
 }
 
 // ---- cm_update_rate: rate-form model (small_rate_elastic_plastic) ------------------------------------------
@@ -1599,13 +1638,23 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
             // expensive, iteration-bound passes: the work-pool kernel (CM_SOLVER_LOCKSTEP: one point per lane as everywhere else)
             if (pool_route(m, B)) {
                 static const int resident = pool_resident_waves((const void*)k_update_pool<D, Y, R, LS>);
-                // chunks of 256 points when every resident wavefront gets at least eight of them, else of 64
-                const int chunk_shift = (B >= (int64_t)resident * 256 * 8) ? 8 : 6;
+                // Chunk = what a wavefront owns at a time (static round-robin).  32 points (one staged half) when every resident
+                // wavefront gets at least 64 of them: with 256-point chunks 10^7 points are 39 062 chunks over 2048 wavefronts =
+                // 19.07 each, so most of the grid idles while 7 % of the wavefronts run their 20th chunk (measured, round 3:
+                // network surface +4.5 %, Hosford a = 100 +0.5-1 %, profiles/r03_pool_chunk_ab.txt).  Small batches: 64 points,
+                // so that a wavefront with a single chunk still fills its lanes.
+                const bool dynamic = (CM_POOL_DYNAMIC != 0) && B >= (int64_t)resident * 2048;
+                unsigned long long* ticket = nullptr;
+                if (dynamic) {                                   // a zeroed counter for this launch, stream-ordered (a memset node under capture)
+                    ticket = pool_ticket_slot();
+                    if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned long long), s) != hipSuccess) { (void)hipGetLastError(); ticket = nullptr; }
+                }
+                const int chunk_shift = dynamic && ticket ? 8 : ((B >= (int64_t)resident * 2048) ? 5 : 6);
                 const int64_t nchunks = (B + ((int64_t)1 << chunk_shift) - 1) >> chunk_shift;
                 const unsigned nw = (unsigned)(nchunks < resident ? nchunks : resident);
                 // 16-byte LDS-DMA pieces need every row start 16-byte aligned: both arrays, and an even row length
                 const int wide = ((B & 1) == 0 && (((uintptr_t)gradu | (uintptr_t)xi_prev) & 15) == 0) ? 1 : 0;
-                hipLaunchKernelGGL((k_update_pool<D, Y, R, LS>), dim3(nw), dim3(64), 0, s, md, B, chunk_shift, wide, gradu, xi_prev, xi, sigma, status);
+                hipLaunchKernelGGL((k_update_pool<D, Y, R, LS>), dim3(nw), dim3(64), 0, s, md, B, chunk_shift, wide, ticket, gradu, xi_prev, xi, sigma, status);
                 return;
             }
         }
