@@ -244,6 +244,9 @@ constexpr int kPoolHalf = 32;            // points per staged half (one LDS-DMA 
 #ifndef CM_POOL_DYNAMIC
 #define CM_POOL_DYNAMIC 1
 #endif
+#ifndef CM_POOL_DYNAMIC_MIN
+#define CM_POOL_DYNAMIC_MIN 2048       // points per resident wavefront from which the chunks are drawn dynamically
+#endif
 constexpr int kPoolTicketSlots = 64;
 __device__ unsigned long long g_pool_ticket[kPoolTicketSlots];
 inline unsigned long long* pool_ticket_slot() {
@@ -1643,13 +1646,17 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
                 // 19.07 each, so most of the grid idles while 7 % of the wavefronts run their 20th chunk (measured, round 3:
                 // network surface +4.5 %, Hosford a = 100 +0.5-1 %, profiles/r03_pool_chunk_ab.txt).  Small batches: 64 points,
                 // so that a wavefront with a single chunk still fills its lanes.
-                const bool dynamic = (CM_POOL_DYNAMIC != 0) && B >= (int64_t)resident * 2048;
+                const bool dynamic = (CM_POOL_DYNAMIC != 0) && B >= (int64_t)resident * CM_POOL_DYNAMIC_MIN;
                 unsigned long long* ticket = nullptr;
                 if (dynamic) {                                   // a zeroed counter for this launch, stream-ordered (a memset node under capture)
                     ticket = pool_ticket_slot();
                     if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned long long), s) != hipSuccess) { (void)hipGetLastError(); ticket = nullptr; }
                 }
-                const int chunk_shift = dynamic && ticket ? 8 : ((B >= (int64_t)resident * 2048) ? 5 : 6);
+                int chunk_shift = (B >= (int64_t)resident * 2048) ? 5 : 6;
+                if (dynamic && ticket) {                         // the smallest chunk that keeps the launch under ~40 000 tickets (see k_update_pool)
+                    chunk_shift = 7;
+                    while ((B >> chunk_shift) > 40000 && chunk_shift < 16) ++chunk_shift;
+                }
                 const int64_t nchunks = (B + ((int64_t)1 << chunk_shift) - 1) >> chunk_shift;
                 const unsigned nw = (unsigned)(nchunks < resident ? nchunks : resident);
                 // 16-byte LDS-DMA pieces need every row start 16-byte aligned: both arrays, and an even row length
