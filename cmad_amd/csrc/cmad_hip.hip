@@ -358,7 +358,11 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
             // have landed, and so have the stores of the previous retire -- the wait is free), (2) retire, (3) hand out points of
             // confirmed halves only, (4) issue the copies for the ring slots this step freed.  Nothing waits for a memory
             // operation issued in this same step (round 3's first version waited vmcnt(0) behind the retire's stores).
-            if (ready < next_issue) {
+#ifndef CM_POOL_LAZY_CONFIRM
+#define CM_POOL_LAZY_CONFIRM 0          // experiment knob: confirm only when the confirmed halves cannot serve every idle lane
+#endif
+            const int conf_avail = (ready - cons_half) * kPoolHalf - cons_off;      // points of confirmed halves not handed out yet
+            if (ready < next_issue && (!CM_POOL_LAZY_CONFIRM || conf_avail < nidle)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 ready = next_issue;
             }
