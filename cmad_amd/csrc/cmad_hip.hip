@@ -239,8 +239,10 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>
 #endif
 constexpr int kPoolHalf = 32;            // points per staged half (one LDS-DMA instruction moves 4 rows of it in 16-byte pieces)
 
-// Counters of the dynamic half assignment: one per launch, taken round-robin from a small ring and zeroed on the launch's
-// stream right before the kernel (64 launches would have to be in flight at once for two of them to share a counter).
+// Counters of the dynamic chunk assignment: one per launch, taken round-robin from a small ring of device words and zeroed by a
+// one-thread kernel on the launch's stream right before the pool kernel (a kernel node under graph capture; no host-side address,
+// no runtime call that a capturing stream could object to).  64 launches would have to be in flight at once for two of them to
+// share a counter.
 #ifndef CM_POOL_DYNAMIC
 #define CM_POOL_DYNAMIC 1
 #endif
@@ -249,14 +251,13 @@ constexpr int kPoolHalf = 32;            // points per staged half (one LDS-DMA 
 #endif
 constexpr int kPoolTicketSlots = 64;
 __device__ unsigned long long g_pool_ticket[kPoolTicketSlots];
-inline unsigned long long* pool_ticket_slot() {
-    static unsigned long long* const base = [] {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pool_ticket)) != hipSuccess) p = nullptr;
-        return (unsigned long long*)p;
-    }();
+__global__ void k_pool_ticket_zero(int slot);
+#if CM_HAS_PART(0)                       // launched by cm_update only: one copy per build
+__global__ void k_pool_ticket_zero(int slot) { g_pool_ticket[slot] = 0ull; }
+#endif
+inline int pool_ticket_slot() {
     static std::atomic<unsigned> next{0};
-    return base ? base + (next.fetch_add(1) % kPoolTicketSlots) : nullptr;
+    return (int)(next.fetch_add(1) % kPoolTicketSlots);
 }
 
 template <int DEF, int YK>
@@ -275,7 +276,7 @@ typedef __attribute__((address_space(3))) void* cm_lds_vptr;
 typedef const __attribute__((address_space(1))) void* cm_gvptr;
 
 template <int DEF, int YK, bool ROT, bool LS>
-__global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int chunk_shift, int wide, unsigned long long* __restrict__ ticket,
+__global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool(cm_model_desc m, int64_t B, int chunk_shift, int wide, int ticket_slot,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status) {
     constexpr int NX = Dims<DEF>::NX, NU = Dims<DEF>::NU, NIN = NU + NX;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
     // instead of waiting for its slowest static share (round-3 counters: the mean wavefront lived 77-82 % of the kernel).  A
     // point's result does not depend on which lane computes it, so the output is the same either way.
     const int hshift = chunk_shift - 5, hmask = (1 << hshift) - 1;
+    unsigned long long* const ticket = (ticket_slot >= 0) ? &g_pool_ticket[ticket_slot] : nullptr;     // wave-uniform
     volatile __shared__ long long hbase[4];                      // first point of the halves in flight (index: half & 3)
 #define CM_HALF_BASE_STATIC(h) ((((int64_t)blockIdx.x + (int64_t)((h) >> hshift) * nwaves) << chunk_shift) + (int64_t)(((h) & hmask) * kPoolHalf))
     int next_issue = 0, ready = 0, cons_half = 0, cons_off = 0;  // wave-uniform cursors: issued / arrived / handed out
@@ -1651,13 +1653,13 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
                 // network surface +4.5 %, Hosford a = 100 +0.5-1 %, profiles/r03_pool_chunk_ab.txt).  Small batches: 64 points,
                 // so that a wavefront with a single chunk still fills its lanes.
                 const bool dynamic = (CM_POOL_DYNAMIC != 0) && B >= (int64_t)resident * CM_POOL_DYNAMIC_MIN;
-                unsigned long long* ticket = nullptr;
-                if (dynamic) {                                   // a zeroed counter for this launch, stream-ordered (a memset node under capture)
+                int ticket = -1;
+                if (dynamic) {                                   // a zeroed counter for this launch, stream-ordered
                     ticket = pool_ticket_slot();
-                    if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned long long), s) != hipSuccess) { (void)hipGetLastError(); ticket = nullptr; }
+                    hipLaunchKernelGGL(k_pool_ticket_zero, dim3(1), dim3(1), 0, s, ticket);
                 }
                 int chunk_shift = (B >= (int64_t)resident * 2048) ? 5 : 6;
-                if (dynamic && ticket) {                         // the smallest chunk that keeps the launch under ~40 000 tickets (see k_update_pool)
+                if (dynamic) {                                   // the smallest chunk that keeps the launch under ~40 000 tickets (see k_update_pool)
                     chunk_shift = 7;
                     while ((B >> chunk_shift) > 40000 && chunk_shift < 16) ++chunk_shift;
                 }
