@@ -302,3 +302,40 @@ def test_complex_step_model_instances(scale_params):
     cm_update_complex."""
     from problems import check_complex_step
     check_complex_step(HostSmallElasticPlastic, scale_params, num_pts_per_increment=12)
+
+
+@pytest.mark.parametrize("def_type_name,yield_kind", [("UNIAXIAL_STRESS", "hill"), ("FULL_3D", "hosford"), ("PLANE_STRESS", "hill")])
+def test_complex_step_instances_on_other_configurations(def_type_name, yield_kind):
+    """Complex-step instances beyond the reference's J2 / PLANE_STRESS check: the stress at the end of a short history from a
+    model built with is_complex=True equals the real model's, and Im sigma(p + i h d) / h (h = 1e-20) equals the central
+    difference of the real model's stress along d."""
+    from cmad_amd.models import DefType, mp_U_from_F, newton_solve
+    dt = getattr(DefType, def_type_name)
+    kw = {"uniaxial_stress_idx": 1} if dt == DefType.UNIAXIAL_STRESS else {}
+    nd = {DefType.UNIAXIAL_STRESS: 1, DefType.FULL_3D: 3, DefType.PLANE_STRESS: 2}[dt]
+    a = 1 if dt == DefType.UNIAXIAL_STRESS else 0
+    K = 6
+    F = np.repeat(np.eye(nd)[:, :, None], K + 1, axis=2)
+    F[0, 0, :] += np.linspace(0., 0.006, K + 1)
+
+    def final_stress(model):
+        model.set_xi_to_init_vals()
+        for step in range(1, K + 1):
+            model.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            newton_solve(model)
+            model.evaluate_cauchy()
+            model.advance_xi()
+        return model.Sigma()[a, a]
+
+    real = HostSmallElasticPlastic(params_J2_voce(yield_kind=yield_kind), dt, **kw)
+    cplx = HostSmallElasticPlastic(params_J2_voce(yield_kind=yield_kind), dt, is_complex=True, **kw)
+    x = real.parameters.flat_active_values(True)
+    d, h, eps = np.array([0.3, -0.7, 0.5])[:x.size], 1e-20, 1e-6
+    cplx.parameters.set_active_values_from_flat(x.astype(complex) + 1j * h * d, is_complex=True)
+    s_real, s_cplx = final_stress(real), final_stress(cplx)
+    assert abs(s_cplx.real - s_real) <= 1e-12 * abs(s_real)
+    fd = []
+    for sgn in (1.0, -1.0):
+        real.parameters.set_active_values_from_flat(x + sgn * eps * d)
+        fd.append(final_stress(real))
+    np.testing.assert_allclose(s_cplx.imag / h, (fd[0] - fd[1]) / (2 * eps), rtol=1e-6)
