@@ -7,9 +7,18 @@ A "step" is one pass of the hot path over the resident batch: the fused kernel b
 plus, for N > 1, one RCCL all-reduce of the 12 gradient doubles.  Points shard across ranks with no
 data-path collective (weak scaling).  Inputs are resident in HBM before the timed region.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no launcher in the environment (no WORLD_SIZE) the command starts its own ranks: the parent -- which never
+imports torch or touches the GPU -- runs
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+as a child (`--dry-launch` prints that command), relays rank 0's JSON line and returns the child's exit code; started under a
+launcher it is simply one of the ranks.  The line's `rccl` block states the process group's world size, backend and the number
+of data-path collectives inside the timed region; `objective` is BASELINE.json configs[4] on the same shards (fused calibration
+objective + gradient, one all-reduce of 13 doubles per evaluation), timed by the same rule right after the headline.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -204,9 +213,52 @@ def history_workload(args, dev, rank, world, distributed):
         dist.destroy_process_group()
 
 
+def launcher_command(n_ranks, port, argv):
+    """The command `bench.py --gpus N` runs itself under when it was not started by a launcher: one rank per GPU."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as FRESH child processes (this
+    parent never imports torch and never touches the GPU -- a process that has initialised the GPU must not be replaced or
+    forked), relay rank 0's JSON line(s) on stdout, everything else on stderr, and return the children's exit code."""
+    import subprocess
+    argv = [a for a in argv if a != "--dry-launch"]
+    cmd = launcher_command(args.gpus, free_port(), argv)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this pool (task statement)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        is_json = False
+        if line.startswith("{"):
+            try:
+                is_json = "metric" in json.loads(line)
+            except ValueError:
+                pass
+        (sys.stdout if is_json else sys.stderr).write(line)
+        (sys.stdout if is_json else sys.stderr).flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="print the child command `--gpus N` would start (one rank per GPU under torch.distributed.run) and exit")
+    ap.add_argument("--sustain", action="store_true",
+                    help="sustained-clock measurement: 250 back-to-back steps after an idle gap, no warm-up; reports the mean of "
+                         "launches 50-250 beside the first 14 and the per-launch trace (`sustained` in the JSON line)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000, help="Gauss points per GPU")
@@ -238,6 +290,12 @@ def main():
                              "ps_calibration_history", "calibration_history"],
                     help="default = BASELINE.json configs[1]; the others are side measurements (DESIGN.md section 6)")
     args = ap.parse_args()
+    # Not started by a launcher (no WORLD_SIZE): N > 1 -- or the 1-rank rehearsal of the process-group path -- runs under
+    # torch.distributed.run as child processes, started before anything here imports torch or touches the GPU.
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch or os.environ.get("CMAD_BENCH_FORCE_DIST") == "1"):
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.sustain:
+        args.steps, args.warmup = max(args.steps, 250), 0
 
     import numpy as np
     import torch
@@ -303,16 +361,20 @@ def main():
         icnn, values = al7079_hybrid_setup()
         hybrid, eps_y = HybridHillEffectiveStress(icnn), 525.0 / 70.2e3
         newton = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})
-    # algorithmic bytes per point: rows of 8 bytes read (grad u, xi_prev, sigma_bar / data) and written (xi, sigma,
-    # tangent); FULL_3D n_gradu = 9, n_xi = 7 -> 232 / 280 / 176 / 664; PLANE_STRESS n_gradu = 4, n_xi = 8 -> 208 / 256 / 144 / 400
     ps = args.def_type == "plane_stress"
     ux = args.def_type == "uniaxial_stress"
     if ps or ux:
         assert wl.startswith("j2_"), "--def-type applies to the J2 workloads"
     n_gradu, n_xi = (4, 8) if ps else ((1, 9) if ux else (9, 7))
-    reads = n_gradu + n_xi + (6 if (wl.endswith("_vjp") or wl == "j2_objective_grad") else 0)
-    writes = 0 if wl == "j2_objective_grad" else n_xi + 6 + (6 * n_gradu if wl.endswith("_update_tangent") else 0)
-    bytes_per_update = 8 * (reads + writes)
+
+    def algorithmic_bytes(w):
+        # algorithmic bytes per point: rows of 8 bytes read (grad u, xi_prev, sigma_bar / data) and written (xi,
+        # sigma, tangent); FULL_3D n_gradu = 9, n_xi = 7 -> 232 / 280 / 176 / 664; PLANE_STRESS n_gradu = 4, n_xi = 8 -> 208 / 256 / 144 / 400
+        reads = n_gradu + n_xi + (6 if (w.endswith("_vjp") or w == "j2_objective_grad") else 0)
+        writes = 0 if w == "j2_objective_grad" else n_xi + 6 + (6 * n_gradu if w.endswith("_update_tangent") else 0)
+        return 8 * (reads + writes)
+
+    bytes_per_update = algorithmic_bytes(wl)
     from cmad_amd.models.deformation_types import DefType
     newton.lockstep = bool(args.lockstep)
     desc, info = build_desc(values, def_type=DefType.PLANE_STRESS if ps else (DefType.UNIAXIAL_STRESS if ux else DefType.FULL_3D),
@@ -338,115 +400,133 @@ def main():
            "grad": torch.empty(12, dtype=torch.float64, device=dev)}
     if wl.endswith("_update_tangent"):
         out["dsigma"] = torch.empty((6 * n_gradu, B), dtype=torch.float64, device=dev)
-
-    # two result buffers: the all-reduce of step k (RCCL's own stream) overlaps the kernel of step k+1
-    grads = [torch.empty(12, dtype=torch.float64, device=dev) for _ in range(2)]
-    res13 = [torch.empty(13, dtype=torch.float64, device=dev) for _ in range(2)]
     wsq6 = [1., 1., 1., 1., 1., 1.]
-    pending = [None, None]
-
-    def launch(k):
-        i = k & 1
-        if pending[i] is not None:                 # the buffer's previous all-reduce must have finished
-            pending[i].wait()
-            pending[i] = None
-        if wl.endswith("_update_vjp"):
-            out["grad"] = grads[i]
-            ev.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
-            return grads[i]
-        if wl == "j2_objective_grad":              # sigma_bar doubles as the "measured stress" array
-            ev.objective_grad(gradu, xi_prev, sigma_bar, wsq6, out=res13[i])
-            return res13[i]
-        ev.update(gradu, xi_prev, want_status=False, out=out, tangent=wl.endswith("_update_tangent"))
-        return None
-
-    def reduce_async(k, r):
-        if distributed and r is not None:
-            pending[k & 1] = dist.all_reduce(r, async_op=True)
-
-    # The step is replayed from a captured HIP graph (one per result buffer): the entry points allocate and synchronise
-    # nothing (include/cmad_hip.h), so a replay is the main kernel + the two reduction kernels with one host call and
-    # no Python between the launches.  --no-graph launches through the C-ABI each step instead (A/B).
     use_graph = not args.no_graph
-    graphs = [None, None]
-    if use_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+
+    def timed_region(w, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` steps of workload `w` on the resident batch, bracketed by barrier +
+        synchronize on both sides; returns the max-over-ranks wall time and the device-side timeline of this rank."""
+        # two result buffers: the all-reduce of step k (RCCL's own stream) overlaps the kernel of step k+1
+        grads = [torch.empty(12, dtype=torch.float64, device=dev) for _ in range(2)]
+        res13 = [torch.empty(13, dtype=torch.float64, device=dev) for _ in range(2)]
+        pending = [None, None]
+        calls = [0]
+
+        def launch(k):
+            i = k & 1
+            if pending[i] is not None:                 # the buffer's previous all-reduce must have finished
+                pending[i].wait()
+                pending[i] = None
+            if w.endswith("_update_vjp"):
+                out["grad"] = grads[i]
+                ev.update_and_vjp(gradu, xi_prev, sigma_bar, out=out)
+                return grads[i]
+            if w == "j2_objective_grad":               # sigma_bar doubles as the "measured stress" array
+                ev.objective_grad(gradu, xi_prev, sigma_bar, wsq6, out=res13[i])
+                return res13[i]
+            ev.update(gradu, xi_prev, want_status=False, out=out, tangent=w.endswith("_update_tangent"))
+            return None
+
+        def reduce_async(k, r):
+            if distributed and r is not None:
+                pending[k & 1] = dist.all_reduce(r, async_op=True)
+                calls[0] += 1
+
+        # The step is replayed from a captured HIP graph (one per result buffer): the entry points allocate and synchronise
+        # nothing (include/cmad_hip.h), so a replay is the main kernel + the two reduction kernels with one host call and
+        # no Python between the launches.  --no-graph launches through the C-ABI each step instead (A/B).
+        graphs = [None, None]
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(2):
+                    launch(i)                              # warm-up on the capture stream (workspace allocated here)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
             for i in range(2):
-                launch(i)                              # warm-up on the capture stream (workspace allocated here)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+                graphs[i] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graphs[i], stream=side):
+                    launch(i)
+        result_of = res13 if w == "j2_objective_grad" else (grads if w.endswith("_update_vjp") else [None, None])   # what each graph writes
+
+        def step(k):
+            i = k & 1
+            if not use_graph:
+                return launch(k)
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
+            graphs[i].replay()
+            return result_of[i]
+
+        # every timing event is created AND recorded once before the timed region: hipEventCreate / the first record of an
+        # event must not land between two timed launches
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        for e in starts + ends:
+            e.record()
+        for k in range(warmup):
+            reduce_async(k, step(k))
         for i in range(2):
-            graphs[i] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graphs[i], stream=side):
-                launch(i)
-    result_of = res13 if wl == "j2_objective_grad" else (grads if wl.endswith("_update_vjp") else [None, None])   # what each graph writes
+            if pending[i] is not None:
+                pending[i].wait(); pending[i] = None
+        if args.sustain:
+            torch.cuda.synchronize()
+            time.sleep(1.0)                            # start from an idle card: the first launches run at the boost clock
+        calls[0] = 0
+        host_t = [0.0] * (steps + 1)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            host_t[k] = time.perf_counter()
+            starts[k].record()                         # events on the stream the kernels are launched on
+            r = step(k)
+            ends[k].record()
+            reduce_async(k, r)
+        host_t[steps] = time.perf_counter()
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        per_step_ms = [s_.elapsed_time(e_) for s_, e_ in zip(starts, ends)]
+        kernel_ms = float(np.mean(per_step_ms))
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        per_rank_kernel_ms = [kernel_ms]
+        if distributed:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            gathered = [torch.zeros_like(kms) for _ in range(world)]
+            dist.all_gather(gathered, kms)
+            per_rank_kernel_ms = [float(t.item()) for t in gathered]
+        finite = all(bool(torch.isfinite(r_).all()) for r_ in result_of if r_ is not None)
+        return {"elapsed": float(tmax.item()), "local_elapsed": elapsed, "per_step_ms": per_step_ms, "kernel_ms": kernel_ms,
+                "device_span_ms": float(starts[0].elapsed_time(ends[-1])),           # first launch start -> last launch end, device clock
+                "start_gaps_ms": [starts[k].elapsed_time(starts[k + 1]) for k in range(steps - 1)],
+                "host_issue_ms": [(host_t[k + 1] - host_t[k]) * 1e3 for k in range(steps)],
+                "per_rank_kernel_ms": per_rank_kernel_ms, "collective_calls": calls[0], "finite": finite,
+                "payload_doubles": 13 if w == "j2_objective_grad" else (12 if w.endswith("_update_vjp") else 0)}
 
-    def step(k):
-        i = k & 1
-        if not use_graph:
-            return launch(k)
-        if pending[i] is not None:
-            pending[i].wait()
-            pending[i] = None
-        graphs[i].replay()
-        return result_of[i]
-
-    # every timing event is created AND recorded once before the timed region: hipEventCreate / the first record of an
-    # event must not land between two timed launches
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    for e in starts + ends:
-        e.record()
-    for k in range(args.warmup):
-        reduce_async(k, step(k))
-    for i in range(2):
-        if pending[i] is not None:
-            pending[i].wait(); pending[i] = None
-    host_t = [0.0] * (args.steps + 1)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        host_t[k] = time.perf_counter()
-        starts[k].record()                         # events on the stream the kernels are launched on
-        r = step(k)
-        ends[k].record()
-        reduce_async(k, r)
-    host_t[args.steps] = time.perf_counter()
-    for i in range(2):
-        if pending[i] is not None:
-            pending[i].wait()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    per_step_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
-    kernel_ms = float(np.mean(per_step_ms))
-    device_span_ms = float(starts[0].elapsed_time(ends[-1]))           # first launch start -> last launch end, device clock
-    start_gaps_ms = [starts[k].elapsed_time(starts[k + 1]) for k in range(args.steps - 1)]
-    host_issue_ms = [(host_t[k + 1] - host_t[k]) * 1e3 for k in range(args.steps)]
-    local_elapsed = elapsed
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-    per_rank_kernel_ms = [kernel_ms]
-    if distributed:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(kms) for _ in range(world)]
-        dist.all_gather(gathered, kms)
-        per_rank_kernel_ms = [float(t.item()) for t in gathered]
-    elapsed = float(tmax.item())
+    tr = timed_region(wl, args.steps, args.warmup)
+    elapsed, local_elapsed, per_step_ms, kernel_ms = tr["elapsed"], tr["local_elapsed"], tr["per_step_ms"], tr["kernel_ms"]
+    device_span_ms, start_gaps_ms, host_issue_ms = tr["device_span_ms"], tr["start_gaps_ms"], tr["host_issue_ms"]
+    per_rank_kernel_ms = tr["per_rank_kernel_ms"]
+    headline_cfg = wl == "j2_update_vjp" and not (ps or ux) and args.yield_surface == "j2" and args.ls_evals == 0 and not args.general_newton
+    # BASELINE.json configs[4] on the same resident shards: the fused calibration objective + gradient, one all-reduce of
+    # (J, grad) = 13 doubles per evaluation over RCCL -- timed by the same rule (every rank takes part: it holds collectives)
+    tobj = timed_region("j2_objective_grad", args.steps, args.warmup) if (headline_cfg and not args.sustain) else None
 
     # a cheap self-check so a broken run cannot report a number: all points converged, finite gradient
     stride = max(1, B // 65536)                   # a strided sample: representative for any point order
     xi, sig, status = ev.update(gradu[:, ::stride][:, :65536].contiguous(), xi_prev[:, ::stride][:, :65536].contiguous())
     status = status.cpu().numpy().astype(np.uint32)
     assert ((status >> 16) & 1).mean() > 0.999, "points failed to converge"
-    if wl == "j2_update_vjp":
-        assert torch.isfinite(grads[0]).all() and torch.isfinite(grads[1]).all()
+    assert tr["finite"] and (tobj is None or tobj["finite"]), "non-finite objective / gradient"
     plastic_frac = float(((status & 0xFFFF) > 0).mean())
 
     if rank == 0:
@@ -522,8 +602,35 @@ def main():
                                            "mean": float(np.mean(host_issue_ms))},
                          "per_rank_kernel_ms": per_rank_kernel_ms},
         }
-        if (n == 1 and wl == "j2_update_vjp" and not (ps or ux) and args.ls_evals == 0 and not args.general_newton
-                and args.yield_surface == "j2"):
+        # proof of what ran: the process group's own world size and backend, and the number of data-path collectives inside
+        # the timed region (one per step: the 12 gradient doubles of update + vjp, or (J, grad) = 13 of the objective)
+        res["rccl"] = {"world_size": dist.get_world_size() if distributed else 1,
+                       "backend": dist.get_backend() if distributed else None,
+                       "collective_calls": tr["collective_calls"], "payload_doubles": tr["payload_doubles"],
+                       "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else None}
+        if tobj is not None:
+            ob, oms = algorithmic_bytes("j2_objective_grad"), tobj["elapsed"] / args.steps * 1e3
+            res["objective"] = {
+                "workload": "fused J2 calibration objective + gradient, single step, FULL_3D, points sharded over the ranks, one "
+                            "RCCL all-reduce of (J, grad) = 13 fp64 per evaluation (BASELINE.json configs[4]: 8 x 1e7 = 8e7 points at N = 8)",
+                "value": n * B * args.steps / tobj["elapsed"], "unit": "point objective+gradient evaluations/s",
+                "total_points": n * B, "ms_per_step": oms, "steps": args.steps, "warmup": args.warmup,
+                "roofline": {"bound": "hbm", "achieved": ob * B / (oms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ob * B / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_update": ob,
+                             "kernel": "k_reverse<FULL_3D,J2,noROT,fused objective+grad>", "kernel_ms": tobj["kernel_ms"],
+                             "kernel_only_frac": ob * B / (tobj["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "rccl": {"collective_calls": tobj["collective_calls"], "payload_doubles": tobj["payload_doubles"]},
+                "per_rank_kernel_ms": tobj["per_rank_kernel_ms"]}
+        if args.sustain:
+            # a calibration runs thousands of evaluations back to back: after an idle gap the engine starts at its boost clock
+            # and sustained fp64 issue pulls it down within milliseconds, so the sustained figure is the late one
+            first, late = per_step_ms[:14], per_step_ms[50:250]
+            to_frac = lambda ms: bytes_per_update * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            res["sustained"] = {"first_14_ms": float(np.mean(first)), "launches_50_250_ms": float(np.mean(late)),
+                                "first_14_frac": to_frac(float(np.mean(first))), "sustained_frac": to_frac(float(np.mean(late))),
+                                "sustained_value": B / (float(np.mean(late)) * 1e-3),
+                                "per_launch_ms": [round(x, 4) for x in per_step_ms]}
+        if n == 1 and headline_cfg and not args.sustain:
             # the same workload (i) on the general 7-dof Newton path (no J2 specialisation) and (ii) with
             # make_newton_solve's default line search (4 evaluations; for J2 every full step passes the Armijo test,
             # so the iterates are the same and the acceptance bookkeeping is the only extra work).
@@ -546,7 +653,7 @@ def main():
                         "roofline_frac": bytes_per_update * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             res["general_newton"] = side(NewtonSettings(j2_radial_line=False))
             res["with_line_search"] = dict(side(NewtonSettings.traced()), max_evals=4)
-        if n == 1 and not args.no_cpu_baseline and wl == "j2_update_vjp":
+        if n == 1 and not args.no_cpu_baseline and wl == "j2_update_vjp" and not args.sustain:
             res["cpu_baseline"] = cpu_baseline(values)
         print(json.dumps(res))
     if distributed:
