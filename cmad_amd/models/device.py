@@ -129,6 +129,12 @@ def complex_native_parameters(values, yield_type):
     pair through the same conversion table as the real path (analytic in its arguments), the flow-stress and yield coefficients
     as they are.  `cm_update_complex` takes the imaginary parts; the real parts are the model description's."""
     from .elastic_constants import ElasticConstants
+    # a perturbation of any other leaf (rotation matrix, ...) would be dropped silently and Im J / h would read 0 for it: the
+    # reference's complex instance carries the perturbation through the whole pytree (small_elastic_plastic.py:118-127)
+    rot = values.get("rotation matrix")
+    if rot is not None and np.iscomplexobj(rot) and np.any(np.imag(np.asarray(rot)) != 0.0):
+        raise NotImplementedError("complex-step perturbation of 'rotation matrix': cm_update_complex carries imaginary parts of "
+                                  "the 12 native kernel parameters only (elastic constants, flow stress, Hill / Hosford coefficients)")
     ec = ElasticConstants.from_params({k: complex(v) for k, v in values["elastic"].items()})
     kp = np.zeros(_lib.CM_NUM_PARAMS, dtype=complex)
     kp[_lib.P_LAMBDA], kp[_lib.P_MU] = ec.lmbda, ec.mu

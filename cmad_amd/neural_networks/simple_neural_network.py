@@ -54,10 +54,21 @@ class SimpleNeuralNetwork:
 
 def hardening_network_scales(hardening_funs):
     """(input_scale, output_scale) of the network behind hardening_funs["neural network"] -- a `SimpleNeuralNetwork.evaluate`
-    (functools.partial of `forward_with_offset`).  Anything else has no kernel."""
-    if set(hardening_funs) != {"neural network"}:
-        raise NotImplementedError("hardening_funs: only {'neural network': SimpleNeuralNetwork(...).evaluate} selects a kernel "
-                                  "(Voce and linear hardening are built in and need no entry)")
+    (functools.partial of `forward_with_offset`) -- or None when the table has no such entry.  The table is the reference's
+    lookup `combined_hardening_fun` indexes by the keys of params[...]["hardening"] (cmad/models/hardening.py:22-34): its
+    "voce" / "linear" entries must be the built-in laws (`cmad_amd.models.hardening.get_hardening_funs()`), which the kernels
+    evaluate themselves; any other callable has no kernel."""
+    from ..models.hardening import linear_hardening, voce_hardening
+    builtin = {"voce": voce_hardening, "linear": linear_hardening}
+    for name, fun in hardening_funs.items():
+        if name == "neural network":
+            continue
+        if name not in builtin or fun is not builtin[name]:
+            raise NotImplementedError(f"hardening_funs[{name!r}]: only the built-in Voce / linear laws (cmad_amd.models.hardening."
+                                      "get_hardening_funs()) and {'neural network': SimpleNeuralNetwork(...).evaluate} select a "
+                                      "kernel; arbitrary callables cannot be traced into a HIP kernel")
+    if "neural network" not in hardening_funs:
+        return None
     fun = hardening_funs["neural network"]
     kw = getattr(fun, "keywords", None)
     if getattr(fun, "func", None) is not forward_with_offset or not kw or set(kw) != {"input_scale", "output_scale"}:

@@ -339,3 +339,44 @@ def test_complex_step_instances_on_other_configurations(def_type_name, yield_kin
         real.parameters.set_active_values_from_flat(x + sgn * eps * d)
         fd.append(final_stress(real))
     np.testing.assert_allclose(s_cplx.imag / h, (fd[0] - fd[1]) / (2 * eps), rtol=1e-6)
+
+
+def test_hardening_funs_is_the_reference_lookup_table():
+    """`hardening_funs` is the table `combined_hardening_fun` indexes (cmad/models/hardening.py:22-34): passing
+    `get_hardening_funs()` (the Voce / linear laws the kernels have built in), with or without a "neural network" entry, is
+    valid; only a custom callable has no kernel."""
+    import copy
+    from cmad_amd.models import DefType
+    from cmad_amd.models.hardening import combined_hardening_fun, get_hardening_funs
+    from cmad_amd.neural_networks.simple_neural_network import SimpleNeuralNetwork, hardening_network_scales
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.parameters.parameters import tree_map
+    from cmad_amd.synthetic import j2_voce_values
+    table = get_hardening_funs()
+    assert set(table) == {"voce", "linear"}
+    assert abs(combined_hardening_fun(0.01, {"voce": {"S": 200., "D": 20.}, "linear": {"K": 50.}}, table)
+               - (200. * (1. - np.exp(-0.2)) + 0.5)) < 1e-13
+    assert hardening_network_scales(table) is None
+    net = SimpleNeuralNetwork([1, 4, 1], input_scale=3., output_scale=7.)
+    assert hardening_network_scales(dict(table, **{"neural network": net.evaluate})) == (3., 7.)
+    with pytest.raises(NotImplementedError):
+        hardening_network_scales({"voce": lambda alpha, p: 0. * alpha})
+    values = j2_voce_values()
+    params = Parameters(values, tree_map(lambda a: False, copy.deepcopy(values)), tree_map(lambda a: None, copy.deepcopy(values)))
+    model = HostSmallElasticPlastic(params, DefType.FULL_3D, hardening_funs=table)          # the built-in laws: no network entry needed
+    assert model._hardening_nn is None
+
+
+def test_complex_perturbation_outside_the_native_parameters_is_refused():
+    """`cm_update_complex` carries the imaginary parts of the 12 native kernel parameters; a complex perturbation of the
+    rotation matrix must raise instead of reading as a zero directional derivative."""
+    import copy
+    from cmad_amd.models.device import complex_native_parameters
+    from cmad_amd.synthetic import j2_voce_values
+    values = copy.deepcopy(j2_voce_values())
+    values["plastic"]["flow stress"]["initial yield"]["Y"] = 200. + 1e-20j
+    kp = complex_native_parameters(values, "J2")
+    assert kp[2].imag == 1e-20 and kp[0].imag == 0.0
+    values["rotation matrix"] = np.eye(3) + 1e-20j * np.ones((3, 3))
+    with pytest.raises(NotImplementedError):
+        complex_native_parameters(values, "J2")
