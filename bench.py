@@ -355,6 +355,7 @@ def main():
         from cmad_amd.synthetic import hosford_values
         values, eps_y = hosford_values(), 2e-3
         newton = NewtonSettings.traced(max_iters=500, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 100})
+        newton.j2_radial_line = not args.general_newton       # --general-newton: the reference's iteration from x_prev (work pool)
     elif wl.startswith("hybrid_update"):           # configs[3]: hybrid Hill + ICNN [6,16,1]
         from cmad_amd.models.device import HybridHillEffectiveStress
         from cmad_amd.synthetic import al7079_hybrid_setup
@@ -564,7 +565,12 @@ def main():
                 "point_order": "sorted by deviatoric strain (coherent wavefronts)" if args.coherent else "uncorrelated",
                 "newton": {"max_iters": newton.max_iters, "abs_tol": newton.abs_tol, "rel_tol": newton.rel_tol,
                            "line_search_max_evals": newton.line_search["max evals"],
-                           "solver": ("8-dof Newton in the coordinates of the J2 plane it never leaves (identical iterates and "
+                           "solver": ("make_newton_solve's Newton + Armijo search started at the analytic warm start (cm::hosford_warm_start); "
+                                      "the returned state passes the reference's convergence test on the reference's residual"
+                                      if (wl.startswith("hosford_") and not args.general_newton) else
+                                      "make_newton_solve's iteration from x_prev (work-pool kernel)"
+                                      if wl.startswith("hosford_") else
+                                      "8-dof Newton in the coordinates of the J2 plane it never leaves (identical iterates and "
                                       "iteration counts; CM_SOLVER_GENERAL_NEWTON turns it off)"
                                       if (ps and args.yield_surface == "j2" and wl.startswith("j2_") and not (args.general_newton or args.ls_evals > 0)) else
                                       "general 7-dof Newton, structured block solve"

@@ -392,13 +392,15 @@ struct PlainNorm {
 template <int YK, bool LS, int DEF = CM_FULL_3D, class NORM = PlainNorm>
 CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
                        EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}, const double* z = nullptr,
-                       const NORM norm = NORM{}, const double* x0 = nullptr) {
+                       const NORM norm = NORM{}, const double* x0 = nullptr, const double* n0sq_known = nullptr) {
     constexpr int NX = Dims<DEF>::NX;
     double C[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) x[k] = x0 ? x0[k] : xp[k];
     residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);
-    const double n0sq = norm.template sq<NX>(C);   // squared-norm form of nonlinear_solver.py:140-150, see cm::newton
+    // squared-norm form of nonlinear_solver.py:140-150, see cm::newton.  n0sq_known: ||C(x_prev)||^2 when the iteration starts
+    // somewhere else (hosford_warm_start) -- the relative tolerance stays the reference's, measured against the residual at x_prev
+    const double n0sq = n0sq_known ? *n0sq_known : norm.template sq<NX>(C);
     const double rel2 = m.rel_tol * m.rel_tol * n0sq, abs2 = m.abs_tol * m.abs_tol;
     int it = 0;
     bool running = lane_valid;
@@ -500,6 +502,128 @@ CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double*
         }
         return flags | (uint32_t)it;
     }
+}
+
+// ---- Hosford, FULL_3D: analytic warm start of the local Newton ---------------------------------------------------------------
+// With a large exponent (the notch deck's a = 100) the surface is a Tresca hexagon with rounded corners, and the reference's
+// iteration -- Newton on the 7-dof residual started at x_prev, Armijo search on ||C||^2 / 2 -- spends 10-18 residual evaluations
+// on every point whose return ends in a corner zone (a quarter of the points of BASELINE configs[2]; 4.1 evaluations per point
+// on average).  The same equations are benign in other variables.  Only the normal entries matter (effective_stress.py:167:
+// the yield function sees the diagonal), the flow direction is n = D^T p with p_i = d phi / d d_i = 1/2 sgn(d_i) q_i,
+// q_i = (|d_i| / phi)^(a-1), d = (s00 - s11, s11 - s22, s22 - s00), and with m / j the largest / second largest |d_i| of the
+// trial state (opposite signs, since sum d = 0; the third obeys |d_3| <= |d_m| / 2, so q_3 <= 2^-(a-1) is dropped) the
+// backward-Euler equations read, in w_i = log q_i and dgam,
+//     R_m = phi r_m - |d_m|_trial + mu dgam (2 q_m + q_j) = 0        r_i = exp(w_i / (a-1)) = |d_i| / phi ,  q_i = exp(w_i)
+//     R_j = phi r_j - |d_j|_trial + mu dgam (2 q_j + q_m) = 0        phi = Y + H(alpha_prev + dgam)   (f = 0 by construction)
+//     R_n = q_m r_m + q_j r_j - 2 = 0                                 (the definition of phi: 1/2 sum (|d_i| / phi)^a = 1)
+// -- the stiff map d -> q = (d / phi)^(a-1) is only ever evaluated in its benign direction q -> d.  Newton on these three,
+// started at the return onto the Tresca hexagon (face or corner, each one scalar equation in dgam), converges in 2-6 steps of
+// ~five exponentials.  The result is NOT taken on trust: it is handed to newton_s as its starting point, so what is returned
+// passed the reference's own convergence test on the reference's residual (relative tolerance against ||C(x_prev)||, as in
+// nonlinear_solver.py:140-150) -- a converged warm start costs one residual evaluation, anything else is finished by the
+// reference's Newton steps / line search from there.  Same root, to the Newton tolerance; iteration counts are counted from
+// the warm start.  CM_SOLVER_GENERAL_NEWTON runs the reference's iteration from x_prev instead.
+constexpr double kHosfordWarmMinA = 20.0;          // below: q_3 is not negligible and the reference iteration is cheap anyway
+constexpr int kHosfordWarmMaxIt = 14;
+CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const double* xp, double* x0, double& n0sq, bool lane_valid) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x0[k] = xp[k];
+    n0sq = 0.0;
+    const double a = m.yc[0];
+    if (!(a >= kHosfordWarmMinA)) return false;                                // uniform
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m);
+    const double e0 = eg[0] - xp[0], e3 = eg[3] - xp[3], e5 = eg[5] - xp[5], lt = m.lambda * (e0 + e3 + e5);
+    const double s[6] = {twomu * e0 + lt, 0.0, 0.0, twomu * e3 + lt, 0.0, twomu * e5 + lt};
+    double phi_tr, gtr[6], Hdummy[1];
+    yield_eval_p<CM_YIELD_HOSFORD, false>(m, s, phi_tr, gtr, Hdummy);          // the value residual_s sees at x_prev
+    const double alpha_p = xp[6];
+    const Hard hp = hardening(m, alpha_p);
+    const double f0 = (phi_tr - (m.Y + hp.H)) * i2mu;
+    const bool plastic0 = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
+    n0sq = plastic0 ? f0 * f0 : 0.0;                                           // C(x_prev) = [0, f0] resp. 0 (elastic branch)
+    bool active = lane_valid && plastic0 && (f0 > 0.0);
+    if (!__any(active)) return false;
+    const double d0 = s[0] - s[3], d1 = s[3] - s[5], d2 = s[5] - s[0];
+    const double t0 = fabs(d0), t1 = fabs(d1), t2 = fabs(d2);
+    const bool m0 = (t0 >= t1) && (t0 >= t2), m1 = !m0 && (t1 >= t2), m2 = !m0 && !m1;
+    const bool j0 = (m1 && t0 >= t2) || (m2 && t0 >= t1), j1 = (m0 && t1 >= t2) || (m2 && !(t0 >= t1)), j2 = !(m2 || j0 || j1);
+    const double dm = m0 ? t0 : (m1 ? t1 : t2), dj = j0 ? t0 : (j1 ? t1 : t2);
+    const double ia = rcp(a), ia1 = rcp(a - 1.0), ap = a * ia1, mu = m.mu;
+    const double kf = exp_s<false>(-0.6931471805599453 * ia), c = 2.0 * kf;    // 2^(-1/a): phi = kf |d_m| on a face; q_m = c there
+    // return onto the hexagon: face (one scalar equation), then -- when the second difference overtakes the first on the way --
+    // the corner (both faces active: dgam from the sum of the two equations, the split from their difference)
+    double g = 0.0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const Hard h = hardening(m, alpha_p + g);
+        g -= (kf * (dm - twomu * c * g) - (m.Y + h.H)) * rcp(-twomu * c * kf - h.dH);
+    }
+    g = fmax(g, 0.0);
+    const bool corner = mu * c * g > dm - dj;
+    double gc = g;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const Hard h = hardening(m, alpha_p + gc);
+        gc -= (dm + dj - 6.0 * mu * gc - 2.0 * (m.Y + h.H)) * rcp(-6.0 * mu - 2.0 * h.dH);
+    }
+    gc = fmax(gc, 1e-300);
+    const double half_split = 0.5 * (dm - dj) * rcp(mu * gc);                  // (q_m - q_j) / 2 at the corner, q_m + q_j = 2
+    double gam = corner ? gc : g;
+    // q_j: the corner's split, or (face) what the second difference reaches at the face solution, r_j^(a-1).  Between the two
+    // regimes -- the second difference ends within a few per cent of phi -- the face value overshoots (it ignores the flow q_j
+    // itself causes) and the corner's split is about zero or below: start at 0.05 there (true values 0.01 .. 0.3)
+    const double qj_c = fmin(fmax(1.0 - half_split, 0.05), 1.0);
+    const Hard hg = hardening(m, alpha_p + g);
+    const double rj_f = fmin(fmax((dj - mu * c * g) * rcp(m.Y + hg.H), 1e-300), 1.0);
+    const double wj_face = log_pos(rj_f) * (a - 1.0), wj_cap = log_pos(qj_c);
+    const bool capped = !corner && (wj_face > wj_cap);
+    double wj = (corner || capped) ? wj_cap : wj_face;
+    double wm = log_pos(corner ? 2.0 - qj_c : (capped ? c - 0.9 * qj_c : c));
+    active = active && (gam > 0.0);
+    bool done = !active, ok = false;
+    for (int it = 0; it < kHosfordWarmMaxIt; ++it) {
+        const double qm = exp_s(wm), qj = exp_s(wj), rm = exp_s(wm * ia1), rj = exp_s(wj * ia1);
+        const Hard h = hardening(m, alpha_p + gam);
+        const double phi = m.Y + h.H, mg = mu * gam;
+        const double Rm = phi * rm - dm + mg * (2.0 * qm + qj), Rj = phi * rj - dj + mg * (2.0 * qj + qm);
+        const double Rn = qm * rm + qj * rj - 2.0;
+        const double res = fmax(fmax(fabs(Rm), fabs(Rj)) * rcp(dm), fabs(Rn));
+        if (!done && !(res < 1e300)) done = true;                              // not finite: give up, the reference iteration takes over
+        if (!done && res < 1e-13) { done = true; ok = true; }                  // converged as evaluated
+        // quadratic convergence: from 1e-7 the next iterate is converged to round-off, and newton_s checks it anyway
+        const bool last = res < 1e-7;
+        if (!done) {
+            const double J00 = phi * rm * ia1 + 2.0 * mg * qm, J01 = mg * qj, J02 = h.dH * rm + mu * (2.0 * qm + qj);
+            const double J10 = mg * qm, J11 = phi * rj * ia1 + 2.0 * mg * qj, J12 = h.dH * rj + mu * (2.0 * qj + qm);
+            const double J20 = ap * qm * rm, J21 = ap * qj * rj;               // J22 = 0
+            // Cramer on the 3 x 3 system J delta = R
+            const double c00 = -J12 * J21, c01 = J12 * J20, c02 = J10 * J21 - J11 * J20;
+            const double det = J00 * c00 + J01 * c01 + J02 * c02;
+            const double idet = rcp(det);
+            const double dwm = (Rm * c00 + J01 * (J12 * Rn) + J02 * (Rj * J21 - J11 * Rn)) * idet;
+            const double dwj = (J00 * (-J12 * Rn) + Rm * c01 + J02 * (J10 * Rn - Rj * J20)) * idet;
+            const double dgm = (J00 * (J11 * Rn - Rj * J21) + J01 * (Rj * J20 - J10 * Rn) + Rm * c02) * idet;
+            // A step that lowers q = e^w is taken in the variable q (q <- q (1 - dw): the equations are nearly linear in q, and the
+            // exponential would creep down by one unit of w per iteration), a step that raises it in w (at most e^2 per step)
+            wm += (dwm > 0.0) ? log_pos(fmax(1.0 - dwm, 0.05)) : fmin(-dwm, 2.0);
+            wj += (dwj > 0.0) ? log_pos(fmax(1.0 - dwj, 0.05)) : fmin(-dwj, 2.0);
+            gam = fmax(gam - dgm, 1e-3 * gam);
+            if (last) { done = true; ok = true; }
+        }
+        if (!__any(!done)) break;
+    }
+    ok = ok && (gam > 0.0) && (wm < 1.0) && (wj < 1.0);
+    if (ok) {
+        const double qm = exp_s(wm), qj = exp_s(wj);
+        const double p0 = 0.5 * ((d0 >= 0.0) ? 1.0 : -1.0) * (m0 ? qm : (j0 ? qj : 0.0));
+        const double p1 = 0.5 * ((d1 >= 0.0) ? 1.0 : -1.0) * (m1 ? qm : (j1 ? qj : 0.0));
+        const double p2 = 0.5 * ((d2 >= 0.0) ? 1.0 : -1.0) * (m2 ? qm : (j2 ? qj : 0.0));
+        x0[0] = xp[0] + gam * (p0 - p2);
+        x0[3] = xp[3] + gam * (p1 - p0);
+        x0[5] = xp[5] + gam * (p2 - p1);
+        x0[6] = alpha_p + gam;
+    }
+    return true;
 }
 
 #if defined(CM_HOST_BUILD)
@@ -802,14 +926,29 @@ constexpr bool has_j2_subspace() {
 }
 // what the launchers test to pick the RL = true kernel variants (UNIAXIAL_STRESS needs no variant: its kernels always take the
 // 9 x 9 Newton step through the 4 x 4 form, uniaxial_solve in cm_device.hpp, which is the same step)
+// Hosford / FULL_3D: the reference's Newton started at the analytic warm start (hosford_warm_start) instead of x_prev
 template <int DEF, int YK, bool LS>
-constexpr bool has_fast_newton() { return has_j2_subspace<DEF, YK, LS>(); }
+constexpr bool has_hosford_warm_start() { return CM_HNN_BUILD_HAS_SUBSPACE && YK == CM_YIELD_HOSFORD && DEF == CM_FULL_3D; }
+template <int DEF, int YK, bool LS>
+constexpr bool has_fast_newton() { return has_j2_subspace<DEF, YK, LS>() || has_hosford_warm_start<DEF, YK, LS>(); }
 template <int DEF, bool LS>
 CM_D uint32_t newton_j2_sub(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
                             bool lane_valid, EvalS<CM_YIELD_J2>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
     static_assert(has_j2_subspace<DEF, CM_YIELD_J2, LS>(), "J2 subspace Newton: FULL_3D and PLANE_STRESS");
     if constexpr (DEF == CM_FULL_3D) return newton_j2_line<LS>(m, eg, xp, x, lane_valid, ev, stage);
     else return newton_j2_plane<LS>(m, eg, z, xp, x, lane_valid, ev, stage);
+}
+// the RL = true kernel variants' solver: what has_fast_newton<> promises for (DEF, YK); `ev` holds the evaluation at the returned x
+template <int DEF, int YK, bool LS>
+CM_D uint32_t newton_fast(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
+                          bool lane_valid, EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
+    static_assert(has_fast_newton<DEF, YK, LS>(), "no subspace iteration / warm start for this configuration");
+    if constexpr (YK == CM_YIELD_J2) return newton_j2_sub<DEF, LS>(m, eg, z, xp, x, lane_valid, ev, stage);
+    else {
+        double x0[7], n0sq;
+        const bool warm = hosford_warm_start(m, eg, xp, x0, n0sq, lane_valid);
+        return newton_s<YK, LS, DEF>(m, eg, xp, x, lane_valid, ev, stage, z, PlainNorm{}, x0, warm ? &n0sq : nullptr);
+    }
 }
 
 // ---- reverse sweep, structured (same contract as cm::reverse_point; FULL_3D and PLANE_STRESS) ---------------
@@ -971,7 +1110,7 @@ CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const doubl
                          LaneStage stage = LaneStage{nullptr, 0}) {
     if constexpr (STRUCT && has_structured<DEF, YK>()) {
         EvalS<YK> ev;
-        if constexpr (RL) return newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, ev, stage);
+        if constexpr (RL) return newton_fast<DEF, YK, LS>(m, eg, z, xp, x, valid, ev, stage);
         else return newton_s<YK, LS, DEF>(m, eg, xp, x, valid, ev, stage, z);
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS, STRUCT>(m, eg, z, xp, x, valid);   // STRUCT = false: the dense reference path

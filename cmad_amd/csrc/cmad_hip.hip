@@ -2,8 +2,9 @@
 // gfx950 only.  One Gauss point per lane; SoA arrays so that lane b of a wavefront reads
 // element [k*B + b] -> every global access is a 512-byte contiguous row per wave instruction.
 #include <hip/hip_runtime.h>
-#include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 // Two builds of this file make the library (cmad_amd/build.py): the BASE build (CM_HNN_VARIANT = 0) without the network hardening
 // law -- so that law costs the Voce / linear configurations nothing, not an instruction and not a register (inlined into every
 // Newton loop it cost the fused J2 objective and PLANE_STRESS kernels 4 %, as a call 15-20 % more VALU instructions per
@@ -239,25 +240,51 @@ __global__ __launch_bounds__(kBlock, (min_waves_update<DEF, YK, LS, TANGENT, RL>
 #endif
 constexpr int kPoolHalf = 32;            // points per staged half (one LDS-DMA instruction moves 4 rows of it in 16-byte pieces)
 
-// Counters of the dynamic chunk assignment: one per launch, taken round-robin from a small ring of device words and zeroed by a
-// one-thread kernel on the launch's stream right before the pool kernel (a kernel node under graph capture; no host-side address,
-// no runtime call that a capturing stream could object to).  64 launches would have to be in flight at once for two of them to
-// share a counter.
+// Counters of the dynamic chunk assignment.  Every launch that can be in flight at the same time as another one must draw from
+// its own counter, and a launch captured into a HIP graph keeps the counter it was captured with for every replay:
+//   * eager launches: one counter per STREAM (launches on one stream are ordered, so they can share; a host-side table maps the
+//     stream handle to its slot -- kPoolStreamSlots streams, after which a new stream's launches use the static assignment);
+//   * captured launches (hipStreamIsCapturing): a private counter per captured launch, never handed out again
+//     (kPoolCaptureSlots of them per build of this file, after which captures use the static assignment) -- a replayed graph can
+//     therefore overlap eager launches on any stream and other graphs.  (One graph executable cannot run concurrently with
+//     itself; instantiating the same captured graph twice and running both at once is the one combination left out.)
+// The counter is zeroed by a one-thread kernel on the launch's stream right before the pool kernel (a kernel node under graph
+// capture; no host-side address, no runtime call that a capturing stream could object to).
 #ifndef CM_POOL_DYNAMIC
 #define CM_POOL_DYNAMIC 1
 #endif
 #ifndef CM_POOL_DYNAMIC_MIN
 #define CM_POOL_DYNAMIC_MIN 2048       // points per resident wavefront from which the chunks are drawn dynamically
 #endif
-constexpr int kPoolTicketSlots = 64;
+constexpr int kPoolStreamSlots = 64, kPoolCaptureSlots = 4032;
+constexpr int kPoolTicketSlots = kPoolStreamSlots + kPoolCaptureSlots;
 __device__ unsigned long long g_pool_ticket[kPoolTicketSlots];
 __global__ void k_pool_ticket_zero(int slot);
 #if CM_HAS_PART(0)                       // launched by cm_update only: one copy per build
 __global__ void k_pool_ticket_zero(int slot) { g_pool_ticket[slot] = 0ull; }
 #endif
-inline int pool_ticket_slot() {
-    static std::atomic<unsigned> next{0};
-    return (int)(next.fetch_add(1) % kPoolTicketSlots);
+// the launch's counter, or -1: static assignment (always correct, a few per cent slower on the largest batches)
+inline int pool_ticket_slot(hipStream_t s) {
+    static std::mutex mu;
+    static std::unordered_map<uintptr_t, int> by_stream;        // (device, stream handle) -> slot
+    static int next_capture = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    // CM_DEBUG_POOL_SLOTS=<n>: shrink both tables (tests force the out-of-slots fallback with it)
+    static const int limit = [] { const char* e = getenv("CM_DEBUG_POOL_SLOTS"); return e ? atoi(e) : -1; }();
+    const int stream_slots = (limit >= 0 && limit < kPoolStreamSlots) ? limit : kPoolStreamSlots;
+    const int capture_slots = (limit >= 0 && limit < kPoolCaptureSlots) ? limit : kPoolCaptureSlots;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cs != hipStreamCaptureStatusNone) return (next_capture < capture_slots) ? kPoolStreamSlots + next_capture++ : -1;
+    const uintptr_t key = (uintptr_t)s ^ ((uintptr_t)(unsigned)dev << 56);
+    const auto it = by_stream.find(key);
+    if (it != by_stream.end()) return it->second;
+    if ((int)by_stream.size() >= stream_slots) return -1;
+    const int slot = (int)by_stream.size();
+    by_stream.emplace(key, slot);
+    return slot;
 }
 
 template <int DEF, int YK>
@@ -666,7 +693,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     uint32_t st = CM_STATUS_CONVERGED;
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
-            if constexpr (RL) st = newton_j2_sub<DEF, LS>(m, eg, z, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock));
+            if constexpr (RL) st = newton_fast<DEF, YK, LS>(m, eg, z, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock));
             else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock), z);
         }
         else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid);
@@ -725,7 +752,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     // arrays are always passed (never a run-time null): a nullable local array would be forced into scratch
     // (MODE 1 / 3 have no per-point cotangent outputs at all: compile-time nulls let the compiler drop that work)
     constexpr bool BARS = (MODE == 0 || MODE == 2);
-    if constexpr (SFAST && RL) {
+    if constexpr (SFAST && RL && YK == CM_YIELD_J2) {
         // converged J2 states: the parameter gradient is the derivative of the return map in its own coordinates (the radial
         // line, the plane: no 7 / 8-dof transposed solve); a wavefront holding an unconverged point (iteration cap)
         // differentiates through A(x) at the returned state as the reference does
@@ -1567,9 +1594,15 @@ static inline bool use_subspace_newton(const cm_model_desc* m) {
 // pool.  The fused entry points below take the same route for them -- work-pool update, then the reverse sweep as a second
 // kernel over the stored states -- instead of the lockstep fused kernel, whose wavefronts wait for their slowest point
 // (CM_SOLVER_LOCKSTEP keeps the single fused kernel).  Same per-point arithmetic and the same reduction order either way.
+// Hosford / FULL_3D with a large exponent starts the reference's Newton at an analytic warm start (cm::hosford_warm_start): one
+// or two residual evaluations per point instead of 4-18, so nothing is left for the pool to balance -- lockstep kernels.
+static inline bool hosford_warm_route(const cm_model_desc* m) {
+    return CM_HNN_BUILD_HAS_SUBSPACE && m->model_kind == CM_SMALL_ELASTIC_PLASTIC && m->yield_kind == CM_YIELD_HOSFORD &&
+           m->def_type == CM_FULL_3D && m->yc[0] >= kHosfordWarmMinA && use_subspace_newton(m);
+}
 static inline bool pool_route(const cm_model_desc* m, int64_t B) {
     if (!m || m->model_kind != CM_SMALL_ELASTIC_PLASTIC || (m->solver_flags & CM_SOLVER_LOCKSTEP) || B < 256) return false;
-    return is_nn_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && m->ls_max_evals > 0) ||
+    return is_nn_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && m->ls_max_evals > 0 && !hosford_warm_route(m)) ||
            (CM_POOL_HILL && m->yield_kind == CM_YIELD_HILL);
 }
 // ---- consistent tangent at given converged states (second kernel of cm_update_tangent's work-pool route) -------------------
@@ -1652,11 +1685,14 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
                 // 19.07 each, so most of the grid idles while 7 % of the wavefronts run their 20th chunk (measured, round 3:
                 // network surface +4.5 %, Hosford a = 100 +0.5-1 %, profiles/r03_pool_chunk_ab.txt).  Small batches: 64 points,
                 // so that a wavefront with a single chunk still fills its lanes.
-                const bool dynamic = (CM_POOL_DYNAMIC != 0) && B >= (int64_t)resident * CM_POOL_DYNAMIC_MIN;
+                // CM_DEBUG_POOL_DYNAMIC_MIN=<points per resident wavefront>: tests bring the dynamic assignment down to small batches
+                static const int64_t dyn_min = [] { const char* e = getenv("CM_DEBUG_POOL_DYNAMIC_MIN"); return e ? (int64_t)atoll(e) : (int64_t)CM_POOL_DYNAMIC_MIN; }();
+                bool dynamic = (CM_POOL_DYNAMIC != 0) && B >= (int64_t)resident * dyn_min;
                 int ticket = -1;
-                if (dynamic) {                                   // a zeroed counter for this launch, stream-ordered
-                    ticket = pool_ticket_slot();
-                    hipLaunchKernelGGL(k_pool_ticket_zero, dim3(1), dim3(1), 0, s, ticket);
+                if (dynamic) {                                   // a zeroed counter of its own for this launch, stream-ordered
+                    ticket = pool_ticket_slot(s);
+                    if (ticket >= 0) hipLaunchKernelGGL(k_pool_ticket_zero, dim3(1), dim3(1), 0, s, ticket);
+                    else dynamic = false;                        // out of counters: static assignment
                 }
                 int chunk_shift = (B >= (int64_t)resident * 2048) ? 5 : 6;
                 if (dynamic) {                                   // the smallest chunk that keeps the launch under ~40 000 tickets (see k_update_pool)

@@ -417,7 +417,12 @@ class DeviceEvaluator:
         d = self.desc
         if d.model_kind != 0 or (d.solver_flags & _lib.SOLVER_LOCKSTEP) or B < 256:
             return False
-        return d.yield_kind in (3, 4) or (d.yield_kind == YIELD_KINDS["hosford"] and d.ls_max_evals > 0)
+        if d.yield_kind == YIELD_KINDS["hosford"]:
+            # FULL_3D with a >= 20 starts the Newton at the analytic warm start (cm::hosford_warm_start): lockstep kernels
+            warm = (d.def_type == 0 and d.yc[0] >= 20.0 and not (d.solver_flags & _lib.SOLVER_GENERAL_NEWTON)
+                    and not (d.ls_max_evals > 0 and d.ls_kind == 1) and d.hnn_width == 0)
+            return d.ls_max_evals > 0 and not warm
+        return d.yield_kind in (3, 4)
 
     def update(self, gradu, xi_prev, want_sigma=True, want_status=True, tangent=False, out=None):
         torch = _torch()

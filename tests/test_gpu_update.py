@@ -76,8 +76,11 @@ def test_bad_arguments_raise():
         ev.update(g.cpu(), torch.zeros((7, 8), dtype=torch.float64))
 
 
-def test_hosford_a100_notch_material(backend):
-    pc.check_hosford_a100(backend, B=4096)
+@pytest.mark.parametrize("reference_iteration", [False, True])
+def test_hosford_a100_notch_material(backend, reference_iteration):
+    """configs[2]'s material on both solver routes: the analytic warm start (default, lockstep kernels) and the reference's
+    iteration from x_prev (CM_SOLVER_GENERAL_NEWTON; B = 4096 >= 256: the work-pool kernel)."""
+    pc.check_hosford_a100(backend, B=4096, reference_iteration=reference_iteration)
 
 
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
@@ -120,8 +123,9 @@ def test_work_pool_route_equals_lockstep_kernels(surface):
         eps_y = 525.0 / 70.2e3
     else:
         values = hosford_values()
+        # (the reference's iteration from x_prev: the default -- Newton from the analytic warm start -- needs no pool)
         mk = lambda lock: NewtonSettings(500, 1e-12, 1e-12, {"max evals": 100, "sufficient decrease": 1e-4, "min backtrack factor": 0.5,
-                                                            "max backtrack factor": 0.9}, lockstep=lock)
+                                                            "max backtrack factor": 0.9}, j2_radial_line=False, lockstep=lock)
         evs = [DeviceEvaluator(*build_desc(values, newton=mk(lock))) for lock in (False, True)]
         eps_y = 2e-3
     g = torch.from_numpy(gauss_point_batch(B, seed=31, eps_y=eps_y)).cuda()
@@ -459,12 +463,17 @@ def test_full_size_hosford_a100():
     idx = np.sort(np.random.default_rng(6).choice(B, 1024, replace=False))
     tidx = torch.from_numpy(idx).cuda()
     mat = ol.Material(values)
-    st_o = ol.newton_settings(max_iters=500, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=100)
+    # The default route starts the Newton at the analytic warm start and returns states that satisfy the reference's residual
+    # to round-off, so the sample is compared with the oracle iterated to 1e-14: rtol 1e-10 (north star), atol = 10 x that
+    # tolerance in strain units, E x that for the stress.  (The reference's iteration at the deck's 1e-12 stops anywhere inside its
+    # tolerance ball -- states 1e-12 apart, 1e-9 relative on |xi| ~ 1e-3: that route's full-size check is tests/test_gpu_pool.py.)
+    st_o = ol.newton_settings(max_iters=500, abs_tol=1e-14, rel_tol=1e-14, ls_kind=ol.LS_TRACED, ls_max_evals=100)
     xi_o, sig_o, it_o, cv_o = mat.update_batch(st_o, g_host[:, idx], np.zeros((7, idx.size)))
     both = cv_o.astype(bool) & ok[tidx].cpu().numpy()
     assert both.mean() > 0.999
-    np.testing.assert_allclose(xi[:, tidx].cpu().numpy()[:, both], xi_o[:, both], rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(sig[:, tidx].cpu().numpy()[:, both], sig_o[:, both], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(xi[:, tidx].cpu().numpy()[:, both], xi_o[:, both], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(sig[:, tidx].cpu().numpy()[:, both], sig_o[:, both], rtol=1e-10, atol=1e-10)
+    assert float(((st & 0xFFFF) == 0).double().mean()) > 0.999              # converged at the warm start: one residual evaluation
     lo, n = 7_000_001, 65_537
     xi_s, sig_s, _ = ev.update(gradu[:, lo:lo + n].contiguous(), xi_prev[:, lo:lo + n].contiguous())
     assert torch.equal(xi_s, xi[:, lo:lo + n]) and torch.equal(sig_s, sig[:, lo:lo + n])
@@ -498,8 +507,10 @@ def test_full_size_hybrid_network_surface():
     xi_o, sig_o, it_o, cv_o = mat.update_batch(st_o, g_host[:, idx], np.zeros((7, idx.size)))
     both = cv_o.astype(bool) & ok[tidx].cpu().numpy()
     assert both.mean() > 0.99
-    np.testing.assert_allclose(xi[:, tidx].cpu().numpy()[:, both], xi_o[:, both], rtol=1e-9, atol=1e-11)
-    np.testing.assert_allclose(sig[:, tidx].cpu().numpy()[:, both], sig_o[:, both], rtol=1e-9, atol=1e-7)
+    # rtol 1e-10 (north star) with the atol the 1e-12 Newton tolerance sets: both iterations stop anywhere inside the tolerance
+    # ball ||C|| < 1e-12 (strain units), so states may differ by ~1e-11 and stresses by 2 mu x that = 5e4 x 1e-11
+    np.testing.assert_allclose(xi[:, tidx].cpu().numpy()[:, both], xi_o[:, both], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(sig[:, tidx].cpu().numpy()[:, both], sig_o[:, both], rtol=1e-10, atol=1e-6)
     lo, n = 1_234_567, 50_001
     xi_s, sig_s, _ = ev.update(gradu[:, lo:lo + n].contiguous(), xi_prev[:, lo:lo + n].contiguous())
     assert torch.equal(xi_s, xi[:, lo:lo + n]) and torch.equal(sig_s, sig[:, lo:lo + n])

@@ -147,8 +147,11 @@ def test_explicit_blocks_at_arbitrary_states(def_type, yield_kind, kw, rot, plas
             np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * max(1e-6, np.abs(So).max()), err_msg=str(path))
 
 
-def test_hosford_a100_notch_material():
-    pc.check_hosford_a100(BACKEND, B=1024)
+@pytest.mark.parametrize("reference_iteration", [False, True])
+def test_hosford_a100_notch_material(reference_iteration, solver_variant):
+    if solver_variant != "structured" and not reference_iteration:
+        pytest.skip("the warm start is a variant of the structured solver (cm::newton_fast)")
+    pc.check_hosford_a100(BACKEND, B=1024, reference_iteration=reference_iteration)
 
 
 @pytest.mark.parametrize("rot", [False, True])
