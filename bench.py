@@ -274,6 +274,10 @@ def main():
     ap.add_argument("--general-newton", action="store_true",
                     help="CM_SOLVER_GENERAL_NEWTON: force the general 7-dof Newton where the J2 radial-line "
                          "restriction (same iterates) would apply; side measurement")
+    ap.add_argument("--reference-iterates", action="store_true",
+                    help="CM_SOLVER_REFERENCE_ITERATES: no scalar return map / analytic warm start -- the Newton iteration starts at "
+                         "x_prev and reproduces the reference's iterates and iteration counts (Hill FULL_3D, J2 PLANE_STRESS, "
+                         "Hosford a >= 20 FULL_3D; side measurement)")
     ap.add_argument("--lockstep", action="store_true",
                     help="CM_SOLVER_LOCKSTEP: one point per lane for the whole kernel instead of the work-pool kernel (A/B)")
     ap.add_argument("--ls-evals", type=int, default=0,
@@ -378,6 +382,7 @@ def main():
     bytes_per_update = algorithmic_bytes(wl)
     from cmad_amd.models.deformation_types import DefType
     newton.lockstep = bool(args.lockstep)
+    newton.warm_start = not args.reference_iterates
     desc, info = build_desc(values, def_type=DefType.PLANE_STRESS if ps else (DefType.UNIAXIAL_STRESS if ux else DefType.FULL_3D),
                             newton=newton, hybrid=hybrid)
     ev = DeviceEvaluator(desc, info)
@@ -567,9 +572,15 @@ def main():
                            "line_search_max_evals": newton.line_search["max evals"],
                            "solver": ("make_newton_solve's Newton + Armijo search started at the analytic warm start (cm::hosford_warm_start); "
                                       "the returned state passes the reference's convergence test on the reference's residual"
-                                      if (wl.startswith("hosford_") and not args.general_newton) else
+                                      if (wl.startswith("hosford_") and not (args.general_newton or args.reference_iterates)) else
                                       "make_newton_solve's iteration from x_prev (work-pool kernel)"
                                       if wl.startswith("hosford_") else
+                                      "plane-stress scalar return map, then the 8-dof Newton in the coordinates of the J2 plane started at "
+                                      "its result (verified by the reference's convergence test; CM_SOLVER_REFERENCE_ITERATES starts at x_prev)"
+                                      if (ps and args.yield_surface == "j2" and wl.startswith("j2_") and not (args.general_newton or args.reference_iterates)) else
+                                      "Hill scalar return map, then the general 7-dof Newton started at its result (verified by the "
+                                      "reference's convergence test; CM_SOLVER_REFERENCE_ITERATES starts at x_prev)"
+                                      if (args.yield_surface == "hill" and not (ps or ux) and wl.startswith("j2_") and not (args.general_newton or args.reference_iterates)) else
                                       "8-dof Newton in the coordinates of the J2 plane it never leaves (identical iterates and "
                                       "iteration counts; CM_SOLVER_GENERAL_NEWTON turns it off)"
                                       if (ps and args.yield_surface == "j2" and wl.startswith("j2_") and not (args.general_newton or args.ls_evals > 0)) else

@@ -10,12 +10,13 @@ P_LAMBDA, P_MU, P_Y, P_VOCE_S, P_VOCE_D, P_LIN_K, P_YC0 = 0, 1, 2, 3, 4, 5, 6
 SOLVER_J2_RADIAL_LINE = 1
 SOLVER_GENERAL_NEWTON = 2
 SOLVER_LOCKSTEP = 4
+SOLVER_REFERENCE_ITERATES = 8
 STATUS_ITERS_MASK, STATUS_CONVERGED, STATUS_PLASTIC, STATUS_SINGULAR = 0xFFFF, 1 << 16, 1 << 17, 1 << 18
 LS_ARMIJO, LS_LEGACY = 0, 1
 CM_OK, CM_ERR_BAD_ARG, CM_ERR_UNSUPPORTED, CM_ERR_LAUNCH, CM_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
 EXPORTS = ["cm_hessians", "cm_hessians_rate", "cm_update_rate_tangent", "cm_update_rate_vjp", "cm_update_rate_and_vjp",
-           "cm_objective_grad_rate", "cm_adjoint_step_rate", "cm_evaluate_rate", "cm_update_rate", "cm_evaluate", "cm_abi_version", "cm_last_hip_error", "cm_sizeof_model_desc", "cm_update_and_vjp", "cm_num_xi", "cm_num_gradu", "cm_workspace_bytes", "cm_update",
+           "cm_objective_grad_rate", "cm_adjoint_step_rate", "cm_evaluate_rate", "cm_update_rate", "cm_evaluate", "cm_abi_version", "cm_last_hip_error", "cm_sizeof_model_desc", "cm_update_and_vjp", "cm_num_xi", "cm_num_gradu", "cm_workspace_bytes", "cm_update", "cm_update_ws", "cm_update_tangent_ws", "cm_update_workspace_bytes",
            "cm_update_tangent", "cm_update_vjp", "cm_objective_grad", "cm_adjoint_step", "cm_objective_grad_history", "cm_update_history", "cm_direct_step",
            "cm_param_blocks", "cm_param_adjoint_history", "cm_update_complex", "cm_adjoint_history", "cm_direct_history", "cm_direct_workspace_bytes", "cm_hessian_history", "cm_hessian_workspace_bytes",
            "cm_direct_history_ep", "cm_hessian_history_ep", "cm_hessian_ep_workspace_bytes"]
@@ -84,6 +85,9 @@ def lib():
     L.cm_num_gradu.argtypes = [md]; L.cm_num_gradu.restype = C.c_int
     L.cm_workspace_bytes.argtypes = [i64]; L.cm_workspace_bytes.restype = i64
     L.cm_update.argtypes = [md, i64, dp, dp, dp, dp, vp, vp]; L.cm_update.restype = C.c_int
+    L.cm_update_workspace_bytes.argtypes = [i64]; L.cm_update_workspace_bytes.restype = i64
+    L.cm_update_ws.argtypes = [md, i64, dp, dp, dp, dp, vp, vp, i64, vp]; L.cm_update_ws.restype = C.c_int
+    L.cm_update_tangent_ws.argtypes = [md, i64, dp, dp, dp, dp, dp, vp, vp, i64, vp]; L.cm_update_tangent_ws.restype = C.c_int
     L.cm_update_rate.argtypes = [md, i64, dp, dp, dp, dp, dp, vp, vp]; L.cm_update_rate.restype = C.c_int
     L.cm_update_rate_tangent.argtypes = [md, i64, dp, dp, dp, dp, dp, dp, vp, vp]; L.cm_update_rate_tangent.restype = C.c_int
     L.cm_update_rate_vjp.argtypes = [md, i64, dp, dp, dp, dp, dp, dp, dp, dp, vp, i64, vp]; L.cm_update_rate_vjp.restype = C.c_int

@@ -541,7 +541,9 @@ CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const d
     const double f0 = (phi_tr - (m.Y + hp.H)) * i2mu;
     const bool plastic0 = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
     n0sq = plastic0 ? f0 * f0 : 0.0;                                           // C(x_prev) = [0, f0] resp. 0 (elastic branch)
-    bool active = lane_valid && plastic0 && (f0 > 0.0);
+    // (a state that already passes the reference's test at x_prev is returned as it is, 0 iterations: re-applying a strain to
+    // its own result changes nothing, bit for bit)
+    bool active = lane_valid && plastic0 && (f0 > 0.0) && !(n0sq < m.abs_tol * m.abs_tol);
     if (!__any(active)) return false;
     const double d0 = s[0] - s[3], d1 = s[3] - s[5], d2 = s[5] - s[0];
     const double t0 = fabs(d0), t1 = fabs(d1), t2 = fabs(d2);
@@ -551,38 +553,40 @@ CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const d
     const double ia = rcp(a), ia1 = rcp(a - 1.0), ap = a * ia1, mu = m.mu;
     const double kf = exp_s<false>(-0.6931471805599453 * ia), c = 2.0 * kf;    // 2^(-1/a): phi = kf |d_m| on a face; q_m = c there
     // return onto the hexagon: face (one scalar equation), then -- when the second difference overtakes the first on the way --
-    // the corner (both faces active: dgam from the sum of the two equations, the split from their difference)
-    double g = 0.0;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const Hard h = hardening(m, alpha_p + g);
-        g -= (kf * (dm - twomu * c * g) - (m.Y + h.H)) * rcp(-twomu * c * kf - h.dH);
-    }
-    g = fmax(g, 0.0);
+    // the corner (both faces active: dgam from the sum of the two equations, the split from their difference).  Two Newton
+    // steps on the face (the first with the hardening already evaluated at alpha_prev), one on the corner from there with the
+    // flow stress linearised: three exponentials in all for a start that the iteration below only has to polish
+    double g = -(kf * dm - (m.Y + hp.H)) * rcp(-twomu * c * kf - hp.dH);
+    const Hard h1 = hardening(m, alpha_p + g);
+    const double g1 = g;
+    g = fmax(g - (kf * (dm - twomu * c * g) - (m.Y + h1.H)) * rcp(-twomu * c * kf - h1.dH), 0.0);
+    const double phi_f = m.Y + h1.H + h1.dH * (g - g1);                         // flow stress at the face solution (linearised)
     const bool corner = mu * c * g > dm - dj;
-    double gc = g;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const Hard h = hardening(m, alpha_p + gc);
-        gc -= (dm + dj - 6.0 * mu * gc - 2.0 * (m.Y + h.H)) * rcp(-6.0 * mu - 2.0 * h.dH);
-    }
-    gc = fmax(gc, 1e-300);
+    const double gc = fmax(g - (dm + dj - 6.0 * mu * g - 2.0 * phi_f) * rcp(-6.0 * mu - 2.0 * h1.dH), 1e-300);
     const double half_split = 0.5 * (dm - dj) * rcp(mu * gc);                  // (q_m - q_j) / 2 at the corner, q_m + q_j = 2
     double gam = corner ? gc : g;
     // q_j: the corner's split, or (face) what the second difference reaches at the face solution, r_j^(a-1).  Between the two
     // regimes -- the second difference ends within a few per cent of phi -- the face value overshoots (it ignores the flow q_j
     // itself causes) and the corner's split is about zero or below: start at 0.05 there (true values 0.01 .. 0.3)
     const double qj_c = fmin(fmax(1.0 - half_split, 0.05), 1.0);
-    const Hard hg = hardening(m, alpha_p + g);
-    const double rj_f = fmin(fmax((dj - mu * c * g) * rcp(m.Y + hg.H), 1e-300), 1.0);
-    const double wj_face = log_pos(rj_f) * (a - 1.0), wj_cap = log_pos(qj_c);
+    const double rj_f = fmin(fmax((dj - mu * c * g) * rcp(phi_f), 1e-300), 1.0);
+    const double wj_face = fmax(log_pos(rj_f) * (a - 1.0), -700.0), wj_cap = log_pos(qj_c);
     const bool capped = !corner && (wj_face > wj_cap);
     double wj = (corner || capped) ? wj_cap : wj_face;
     double wm = log_pos(corner ? 2.0 - qj_c : (capped ? c - 0.9 * qj_c : c));
     active = active && (gam > 0.0);
     bool done = !active, ok = false;
     for (int it = 0; it < kHosfordWarmMaxIt; ++it) {
-        const double qm = exp_s(wm), qj = exp_s(wj), rm = exp_s(wm * ia1), rj = exp_s(wj * ia1);
+        // q = e^w; r = e^(w / (a-1)): for the major difference |w_m / (a-1)| < 0.04 and its exponential is a short series
+        const double um = wm * ia1;
+        double rm = CM_SCALAR(1.0 / 720.0);
+        rm = __builtin_fma(um, rm, CM_SCALAR(1.0 / 120.0));
+        rm = __builtin_fma(um, rm, CM_SCALAR(1.0 / 24.0));
+        rm = __builtin_fma(um, rm, CM_SCALAR(1.0 / 6.0));
+        rm = __builtin_fma(um, rm, 0.5);
+        rm = __builtin_fma(um, rm, 1.0);
+        rm = __builtin_fma(um, rm, 1.0);
+        const double qm = exp_s<false>(wm), qj = exp_s<false>(wj), rj = exp_s<false>(wj * ia1);
         const Hard h = hardening(m, alpha_p + gam);
         const double phi = m.Y + h.H, mg = mu * gam;
         const double Rm = phi * rm - dm + mg * (2.0 * qm + qj), Rj = phi * rj - dj + mg * (2.0 * qj + qm);
@@ -592,6 +596,7 @@ CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const d
         if (!done && res < 1e-13) { done = true; ok = true; }                  // converged as evaluated
         // quadratic convergence: from 1e-7 the next iterate is converged to round-off, and newton_s checks it anyway
         const bool last = res < 1e-7;
+        double dwj = 0.0;
         if (!done) {
             const double J00 = phi * rm * ia1 + 2.0 * mg * qm, J01 = mg * qj, J02 = h.dH * rm + mu * (2.0 * qm + qj);
             const double J10 = mg * qm, J11 = phi * rj * ia1 + 2.0 * mg * qj, J12 = h.dH * rj + mu * (2.0 * qj + qm);
@@ -601,15 +606,19 @@ CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const d
             const double det = J00 * c00 + J01 * c01 + J02 * c02;
             const double idet = rcp(det);
             const double dwm = (Rm * c00 + J01 * (J12 * Rn) + J02 * (Rj * J21 - J11 * Rn)) * idet;
-            const double dwj = (J00 * (-J12 * Rn) + Rm * c01 + J02 * (J10 * Rn - Rj * J20)) * idet;
+            dwj = (J00 * (-J12 * Rn) + Rm * c01 + J02 * (J10 * Rn - Rj * J20)) * idet;
             const double dgm = (J00 * (J11 * Rn - Rj * J21) + J01 * (Rj * J20 - J10 * Rn) + Rm * c02) * idet;
-            // A step that lowers q = e^w is taken in the variable q (q <- q (1 - dw): the equations are nearly linear in q, and the
-            // exponential would creep down by one unit of w per iteration), a step that raises it in w (at most e^2 per step)
-            wm += (dwm > 0.0) ? log_pos(fmax(1.0 - dwm, 0.05)) : fmin(-dwm, 2.0);
-            wj += (dwj > 0.0) ? log_pos(fmax(1.0 - dwj, 0.05)) : fmin(-dwj, 2.0);
+            wm = fmin(fmax(wm - dwm, -3.0), 0.75);                             // q_m stays in [0.05, 2.1]
             gam = fmax(gam - dgm, 1e-3 * gam);
             if (last) { done = true; ok = true; }
         }
+        // A large step that LOWERS q_j = e^(w_j) is taken in the variable q_j (q <- q (1 - dw): the equations are nearly linear in
+        // it, and the exponential would creep down by one unit of w per iteration); everything else in w (at most e^2 up per step).
+        // The logarithm this needs is only evaluated while some lane of the wavefront takes such a step (the first one or two).
+        const bool qstep = (dwj > 0.25);
+        double lg = 0.0;
+        if (__any(qstep)) lg = log_pos(fmax(1.0 - dwj, 0.05));
+        wj = fmax(wj + (qstep ? lg : fmin(-dwj, 2.0)), -700.0);
         if (!__any(!done)) break;
     }
     ok = ok && (gam > 0.0) && (wm < 1.0) && (wj < 1.0);
@@ -622,6 +631,103 @@ CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const d
         x0[3] = xp[3] + gam * (p1 - p0);
         x0[5] = xp[5] + gam * (p2 - p1);
         x0[6] = alpha_p + gam;
+    }
+    return true;
+}
+
+// ---- Hill, FULL_3D: the classical scalar return map as warm start of the local Newton -----------------------------------------
+// For a quadratic surface phi = sqrt(s^T A s) the backward-Euler equations  s = s_trial - 2 mu dgam W^-1 A s / phi,
+// phi = Y + H(alpha_prev + dgam)  reduce to ONE scalar equation in kappa = 2 mu dgam / phi:
+//     (I + kappa W^-1 A) s = s_trial     3 x 3 on the normal entries (A3 has the null vector 1: in the orthonormal deviatoric
+//                                        coordinates y = E^T s_n, E = [(1,-1,0)/sqrt2, (1,1,-2)/sqrt6], a 2 x 2 system with
+//                                        A2 = E^T A3 E; the mean stress does not move) and three shear scalars
+//     F(kappa) = phi(kappa) - Y - H(alpha_prev + kappa phi(kappa) / 2mu) = 0 ,    phi^2 = y^T A2 y + sum_shear a_kk s_k^2
+//     phi phi' = -u^T (I + kappa A2)^-1 u - 1/2 sum_shear (a_kk s_k)^2 / (1 + kappa a_kk / 2) ,   u = A2 y
+// F is decreasing and convex on kappa >= 0, so Newton from kappa = 0 converges monotonically (~40 flops and one hardening
+// evaluation per step instead of the 7-dof step's ~240 instructions).  As with hosford_warm_start the result is only the START
+// of the reference's Newton: newton_s evaluates the reference residual there and applies the reference's convergence test
+// (relative to ||C(x_prev)||), so a converged map costs one residual evaluation and anything else is finished by the general
+// iteration.  CM_SOLVER_GENERAL_NEWTON / CM_SOLVER_REFERENCE_ITERATES keep the iteration from x_prev.
+constexpr int kHillWarmMaxIt = 12;
+CM_D bool hill_warm_start(const cm_model_desc& m, const double eg[6], const double* xp, double* x0, double& n0sq, bool lane_valid) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x0[k] = xp[k];
+    const QuadForm q = quad_form<CM_YIELD_HILL>(m);
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m);
+    double e[6], s[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) e[k] = eg[k] - xp[k];
+    const double lt = m.lambda * (e[0] + e[3] + e[5]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = twomu * e[k] + (kDiag[k] ? lt : 0.0);
+    // deviatoric coordinates of the normal entries and the 2 x 2 form of A3 in them
+    constexpr double r2 = 0.7071067811865476, r6 = 0.4082482904638631, r12 = 0.2886751345948129;
+    const double A11 = 0.5 * (q.a00 - 2.0 * q.a03 + q.a33);
+    const double A12 = (q.a00 - q.a33 - 2.0 * q.a05 + 2.0 * q.a35) * r12;
+    const double A22 = (q.a00 + q.a33 + 4.0 * q.a55 + 2.0 * q.a03 - 4.0 * q.a05 - 4.0 * q.a35) * (1.0 / 6.0);
+    const double yt1 = (s[0] - s[3]) * r2, yt2 = (s[0] + s[3] - 2.0 * s[5]) * r6;
+    const double h1 = 0.5 * q.a11, h2 = 0.5 * q.a22, h4 = 0.5 * q.a44;      // W^-1 A on the shear entries
+    const double ph2_tr = yt1 * (A11 * yt1 + A12 * yt2) + yt2 * (A12 * yt1 + A22 * yt2)
+                        + q.a11 * s[1] * s[1] + q.a22 * s[2] * s[2] + q.a44 * s[4] * s[4];
+    const double phi_tr = sqrt(fmax(ph2_tr, 0.0));
+    const double alpha_p = xp[6];
+    const Hard hp = hardening(m, alpha_p);
+    const double f0 = (phi_tr - (m.Y + hp.H)) * i2mu;
+    const bool plastic0 = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
+    n0sq = plastic0 ? f0 * f0 : 0.0;                                           // C(x_prev) = [0, f0] resp. 0 (elastic branch)
+    const bool active = lane_valid && plastic0 && (f0 > 0.0) && !(n0sq < m.abs_tol * m.abs_tol);     // (see hosford_warm_start)
+    if (!__any(active)) return true;
+    double kap = 0.0, phi = phi_tr, y1 = yt1, y2 = yt2, u1 = 0.0, u2 = 0.0, s1 = s[1], s2 = s[2], s4 = s[4];
+    bool done = !active, ok = false;
+    for (int it = 0; it < kHillWarmMaxIt; ++it) {
+        const double b11 = 1.0 + kap * A11, b22 = 1.0 + kap * A22, b12 = kap * A12;
+        const double idet = rcp(b11 * b22 - b12 * b12);
+        y1 = (b22 * yt1 - b12 * yt2) * idet; y2 = (b11 * yt2 - b12 * yt1) * idet;
+        const double i1 = rcp(1.0 + kap * h1), i2 = rcp(1.0 + kap * h2), i4 = rcp(1.0 + kap * h4);
+        s1 = s[1] * i1; s2 = s[2] * i2; s4 = s[4] * i4;
+        u1 = A11 * y1 + A12 * y2; u2 = A12 * y1 + A22 * y2;
+        const double t1 = q.a11 * s1, t2 = q.a22 * s2, t4 = q.a44 * s4;
+        const double ph2 = y1 * u1 + y2 * u2 + t1 * s1 + t2 * s2 + t4 * s4;
+        phi = sqrt(fmax(ph2, 0.0));
+        const double iphi = (ph2 > 0.0) ? rcp(phi) : 0.0;
+        // phi phi' = -u^T (I + kappa A2)^-1 u - 1/2 sum (a_kk s_k)^2 / (1 + kappa a_kk / 2)
+        const double v1 = (b22 * u1 - b12 * u2) * idet, v2 = (b11 * u2 - b12 * u1) * idet;
+        const double dphi = -(u1 * v1 + u2 * v2 + 0.5 * (t1 * t1 * i1 + t2 * t2 * i2 + t4 * t4 * i4)) * iphi;
+        const Hard h = hardening(m, alpha_p + kap * phi * i2mu);
+        const double F = phi - (m.Y + h.H), dF = dphi - h.dH * (phi + kap * dphi) * i2mu;
+        const double res = fabs(F) * rcp(phi_tr);
+        if (!done && !(res < 1e300)) done = true;
+        if (!done && res < 1e-14) { done = true; ok = true; }
+        const bool last = res < 1e-8;                              // quadratic convergence: the next iterate is converged to round-off
+        if (!done) {
+            // Newton in c = lb kappa / (1 + lb kappa), lb = 3/2 (J2's eigenvalue of W^-1 A; Hill's lie around it): phi ~ phi_trial
+            // (1 - c) and dgam ~ c phi_trial / (2 mu lb) are nearly LINEAR in c (exactly so for J2 with linear hardening), where in
+            // kappa phi ~ 1 / (1 + lb kappa) is strongly convex and Newton from kappa = 0 creeps (6-7 steps against 3-5)
+            constexpr double lb = 1.5;
+            const double w = 1.0 + lb * kap;
+            const double cn = fmin(fmax(lb * kap * rcp(w) - F * lb * rcp(dF * w * w), 0.0), 0.999999);
+            kap = cn * rcp(lb * (1.0 - cn));
+            if (last) { done = true; ok = true; }
+        }
+        if (!__any(!done)) break;
+    }
+    if (ok) {
+        // the state at kappa (one more evaluation of the linear maps at the final kappa), then x = x_prev + dgam n, n_k = (A s)_k / (phi w_k)
+        const double b11 = 1.0 + kap * A11, b22 = 1.0 + kap * A22, b12 = kap * A12;
+        const double idet = rcp(b11 * b22 - b12 * b12);
+        y1 = (b22 * yt1 - b12 * yt2) * idet; y2 = (b11 * yt2 - b12 * yt1) * idet;
+        s1 = s[1] * rcp(1.0 + kap * h1); s2 = s[2] * rcp(1.0 + kap * h2); s4 = s[4] * rcp(1.0 + kap * h4);
+        u1 = A11 * y1 + A12 * y2; u2 = A12 * y1 + A22 * y2;
+        const double ph2 = y1 * u1 + y2 * u2 + q.a11 * s1 * s1 + q.a22 * s2 * s2 + q.a44 * s4 * s4;
+        phi = sqrt(fmax(ph2, 0.0));
+        const double dg_over_phi = kap * i2mu;                     // dgam / phi
+        x0[0] = xp[0] + dg_over_phi * (u1 * r2 + u2 * r6);
+        x0[3] = xp[3] + dg_over_phi * (-u1 * r2 + u2 * r6);
+        x0[5] = xp[5] + dg_over_phi * (-2.0 * u2 * r6);
+        x0[1] = xp[1] + dg_over_phi * (0.5 * q.a11 * s1);
+        x0[2] = xp[2] + dg_over_phi * (0.5 * q.a22 * s2);
+        x0[4] = xp[4] + dg_over_phi * (0.5 * q.a44 * s4);
+        x0[6] = alpha_p + dg_over_phi * phi;
     }
     return true;
 }
@@ -755,6 +861,79 @@ CM_D uint32_t newton_j2_plane(const cm_model_desc& m, const double eg[6], const 
     bool running = lane_valid, fallback = false, first = true;
     uint32_t flags = 0;
     Hard hd;
+    if (!(m.solver_flags & CM_SOLVER_REFERENCE_ITERATES)) {                    // uniform
+        // Warm start: the classical plane-stress return map in the plane's coordinates (a legal optimisation,
+        // the iteration below stays the definition of the result).  At the solution r_a = r_b = 0 give p = 1 / (1 + g),
+        // q = t / (1 + g), the sigma_33 row is LINEAR in t for a given g,
+        //     t(g) = -(z:a / (1 + g) + Kz tr0) / (z:b / (1 + g) + Kz tr z) ,
+        // and what is left is one scalar equation in g = dgam 3 mu / phi (g = 0: the elastic step, whose stretch is t(0)):
+        //     F(g) = sqrt6 mu sqrt(S) / (1 + g) - Y - H(alpha_prev + g sqrt(S) / (c (1 + g))) ,  S = |a + t b|^2 ,  c = 3 / sqrt6 .
+        // ~70 instead of ~150 instructions per step, and an elastic point needs none.  The loop below then starts at the mapped
+        // state: it evaluates the plane's residual there and applies the reference's convergence test (relative tolerance against
+        // ||C(x_prev)||, computed here from the state at x_prev), so a converged map costs one evaluation; otherwise the plane's
+        // Newton continues from it (the Jacobian maps the plane to itself wherever the iterate sits in it).
+        const double tp = t;
+        bool plastic_prev, conv_prev;
+        {   // ||C(x_prev)||^2 = C6^2 + C7^2 (r_a = r_b = 0 at c = 0, dgam = 0)
+            const double P0 = aa + 2.0 * tp * ab + tp * tp * bb;
+            const double phi0 = sqrt6mu * sqrt(fmax(P0, 0.0));
+            const Hard h0 = hardening(m, alpha_p);
+            const double f0 = (phi0 - (m.Y + h0.H)) * i2mu;
+            plastic_prev = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
+            const double c6 = plastic_prev ? f0 : 0.0;
+            const double c7 = za + tp * zb + Kz * (tr0 + tp * trz);
+            rel2 = m.rel_tol * m.rel_tol * (c6 * c6 + c7 * c7);
+            first = false;
+            conv_prev = (c6 * c6 + c7 * c7) < abs2;
+        }
+        constexpr double c32 = 1.224744871391589;
+        double g = 0.0, tg = 0.0, Rg = 0.0;
+        // (a state that already passes the reference's test at x_prev is returned as it is, 0 iterations: re-applying a strain
+        // to its own result changes nothing, bit for bit)
+        bool done = !lane_valid || conv_prev, ok = false;
+        for (int wit = 0; wit < 12; ++wit) {
+            const double i1g = rcp(1.0 + g);
+            const double N = za * i1g + Kz * tr0, D = zb * i1g + Kz * trz, iD = rcp(D);
+            tg = -N * iD;
+            const double dt = (za * D - N * zb) * (i1g * i1g) * (iD * iD);
+            const double S = aa + 2.0 * tg * ab + tg * tg * bb, dS = 2.0 * (ab + tg * bb) * dt;
+            const double rS = (S > 0.0) ? rsqrt_pos(S) : 0.0;
+            Rg = S * rS;
+            const double dR = 0.5 * dS * rS;
+            const double phi_g = sqrt6mu * Rg * i1g, dphi = sqrt6mu * (dR * i1g - Rg * i1g * i1g);
+            const double dgam = g * Rg * i1g * (1.0 / c32), ddg = ((Rg + g * dR) * i1g - g * Rg * i1g * i1g) * (1.0 / c32);
+            const Hard h = hardening(m, alpha_p + dgam);
+            const double F = phi_g - (m.Y + h.H), dF = dphi - h.dH * ddg;
+            // Elastic step: g = 0, t = t(0).  Taken only when the state at x_prev -- with the OLD stretch -- is on the elastic
+            // branch too: a point that is plastic there but elastic once the stretch relaxes has two roots of the reference's
+            // residual (the elastic one and one on the plastic branch with dgam < 0), and which of them the reference's iteration
+            // from x_prev ends in is decided by its iterates -- such a lane starts at x_prev and retraces them.
+            if (!done && wit == 0 && !(F > 0.0)) { done = true; ok = !plastic_prev; }
+            const double res = fabs(F) * rcp(m.Y + h.H);
+            if (!done && !(res < 1e300)) done = true;
+            if (!done && res < 1e-14) { done = true; ok = true; }
+            const bool last = res < 1e-8;                      // quadratic convergence: the next iterate is converged to round-off
+            if (!done) {
+                // Newton in c = g / (1 + g) (= c_a): phi ~ phi(0) (1 - c) and dgam ~ c phi(0) / 3 mu are nearly linear in it -- in g,
+                // phi ~ 1 / (1 + g) is strongly convex and Newton from g = 0 creeps (6-7 steps against 3-4)
+                const double cn = fmin(fmax(g * i1g - F * rcp(dF) * (i1g * i1g), 0.0), 0.999999);
+                g = cn * rcp(1.0 - cn);
+                if (last) {
+                    done = true; ok = true;
+                    const double j1g = rcp(1.0 + g);
+                    tg = -(za * j1g + Kz * tr0) * rcp(zb * j1g + Kz * trz);
+                    const double S2 = aa + 2.0 * tg * ab + tg * tg * bb;
+                    Rg = sqrt(fmax(S2, 0.0));
+                }
+            }
+            if (!__any(!done)) break;
+        }
+        if (ok) {
+            const double i1g = rcp(1.0 + g);
+            ca = g * i1g; cb = tg * g * i1g; t = tg;
+            alpha = alpha_p + g * Rg * i1g * (1.0 / c32);
+        }
+    }
     double p, q, rP, phi, f, nsq;          // the evaluation at the current u: read after the loop (a stopped lane re-evaluates its unchanged u)
     bool plastic;
     for (;;) {
@@ -929,14 +1108,27 @@ constexpr bool has_j2_subspace() {
 // Hosford / FULL_3D: the reference's Newton started at the analytic warm start (hosford_warm_start) instead of x_prev
 template <int DEF, int YK, bool LS>
 constexpr bool has_hosford_warm_start() { return CM_HNN_BUILD_HAS_SUBSPACE && YK == CM_YIELD_HOSFORD && DEF == CM_FULL_3D; }
+// Hill / FULL_3D: the reference's Newton started at the scalar return map (hill_warm_start)
 template <int DEF, int YK, bool LS>
-constexpr bool has_fast_newton() { return has_j2_subspace<DEF, YK, LS>() || has_hosford_warm_start<DEF, YK, LS>(); }
+constexpr bool has_hill_warm_start() { return CM_HNN_BUILD_HAS_SUBSPACE && YK == CM_YIELD_HILL && DEF == CM_FULL_3D; }
+template <int DEF, int YK, bool LS>
+constexpr bool has_fast_newton() {
+    return has_j2_subspace<DEF, YK, LS>() || has_hosford_warm_start<DEF, YK, LS>() || has_hill_warm_start<DEF, YK, LS>();
+}
 template <int DEF, bool LS>
 CM_D uint32_t newton_j2_sub(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
                             bool lane_valid, EvalS<CM_YIELD_J2>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
     static_assert(has_j2_subspace<DEF, CM_YIELD_J2, LS>(), "J2 subspace Newton: FULL_3D and PLANE_STRESS");
     if constexpr (DEF == CM_FULL_3D) return newton_j2_line<LS>(m, eg, xp, x, lane_valid, ev, stage);
     else return newton_j2_plane<LS>(m, eg, z, xp, x, lane_valid, ev, stage);
+}
+// HOST side: does this description run the RL = true variants (what has_fast_newton<> offers)?  The J2 subspace iterations treat a
+// full step as the Armijo search's first trial; under the legacy backtracking (CM_LS_LEGACY) the acceptance test is another one,
+// so those configurations run the general path.  For Hill / Hosford the RL variants ARE the warm-started ones, which
+// CM_SOLVER_REFERENCE_ITERATES switches off (for J2 that flag is read inside newton_j2_plane: the subspace form stays).
+inline bool use_fast_newton(const cm_model_desc* m) {
+    if ((m->solver_flags & CM_SOLVER_GENERAL_NEWTON) || (m->ls_max_evals > 0 && m->ls_kind == CM_LS_LEGACY)) return false;
+    return m->yield_kind == CM_YIELD_J2 || !(m->solver_flags & CM_SOLVER_REFERENCE_ITERATES);
 }
 // the RL = true kernel variants' solver: what has_fast_newton<> promises for (DEF, YK); `ev` holds the evaluation at the returned x
 template <int DEF, int YK, bool LS>
@@ -946,7 +1138,9 @@ CM_D uint32_t newton_fast(const cm_model_desc& m, const double eg[6], const doub
     if constexpr (YK == CM_YIELD_J2) return newton_j2_sub<DEF, LS>(m, eg, z, xp, x, lane_valid, ev, stage);
     else {
         double x0[7], n0sq;
-        const bool warm = hosford_warm_start(m, eg, xp, x0, n0sq, lane_valid);
+        bool warm;
+        if constexpr (YK == CM_YIELD_HILL) warm = hill_warm_start(m, eg, xp, x0, n0sq, lane_valid);
+        else warm = hosford_warm_start(m, eg, xp, x0, n0sq, lane_valid);
         return newton_s<YK, LS, DEF>(m, eg, xp, x, lane_valid, ev, stage, z, PlainNorm{}, x0, warm ? &n0sq : nullptr);
     }
 }

@@ -456,6 +456,132 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
 #undef CM_HALF_BASE_STATIC
 }
 
+// ---- cm_update, screened: elastic points finish in a streaming kernel, the plastic ones are listed and solved densely -----------
+// FULL_3D only (an elastic trial state IS the answer there: C_e(x_prev) = 0 exactly, 0 iterations).  For the surfaces whose
+// residual evaluation costs thousands of instructions -- the network surfaces, Barlat, Hosford on the reference's iteration --
+// a lockstep wavefront drags its elastic lanes (about half of a typical batch) through every evaluation of its plastic ones,
+// and the work pool pays for its refill machinery on every pass.  With a caller-provided workspace of 4 B per point:
+//   k_screen        one point per lane, coalesced: trial stress, effective-stress VALUE (no normal, no Hessian), f0.  Elastic:
+//                   state, stress and status are final and stored here.  Plastic: the point's index is appended to a list
+//                   (one atomic per wavefront; ballot / mbcnt ranks inside it).
+//   k_update_listed lockstep Newton over the list: every lane of every wavefront holds a plastic point.
+// A point's result does not depend on its position in the list, so the output is independent of the order the wavefronts of
+// k_screen append in.  Costs: the inputs of the plastic points are read twice and their outputs are written by a second kernel
+// (partial rows): about 2x the algorithmic HBM bytes on kernels that run at 5-20 % of the HBM roof.
+#ifndef CM_SCREEN
+#define CM_SCREEN 1
+#endif
+template <int YK>
+constexpr bool screen_pays() { return CM_SCREEN != 0 && (is_dense_yield(YK) || YK == CM_YIELD_HOSFORD); }
+
+template <int YK, bool ROT>
+__global__ __launch_bounds__(kBlock) void k_screen(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ xi_prev,
+        double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status,
+        uint32_t* __restrict__ list, unsigned long long* __restrict__ count) {
+    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const bool valid = blk0 + threadIdx.x < B;
+    const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
+    gradu += blk0; xi_prev += blk0; xi += blk0;
+    if (sigma) sigma += blk0;
+    if (status) status += blk0;
+    double G[9], xp[7], eg[6], z[6];
+    load_soa<9, false>(gradu, B, b, G);                          // (temporal: the plastic points' rows are read again)
+    load_soa<7, false>(xi_prev, B, b, xp);
+    strain_from_gradu<CM_FULL_3D, ROT>(m, G, eg);
+    strain_z<CM_FULL_3D, ROT>(m, z);
+    Eval<CM_FULL_3D> ev;
+    strain_stress<CM_FULL_3D>(m, eg, z, xp, ev);                 // trial stress: what k_update stores for an elastic point
+    const double* s = ev.s;
+    double phi, gt[6], Hd[1];
+    yield_eval_p<YK, false>(m, s, phi, gt, Hd);                  // the value residual_s / residual see at x_prev
+    const double f0 = (phi - (m.Y + hardening(m, xp[6]).H)) * half_over_mu(m);
+    const bool plastic0 = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
+    if (valid && !plastic0) {                                    // cond_residual's elastic branch at x_prev: C = 0, nothing to iterate
+        double sg[6];
+        to_global<ROT>(m, s, sg);
+        store_soa<7>(xi, B, b, xp);
+        if (sigma) store_soa<6>(sigma, B, b, sg);
+        if (status) status[b] = CM_STATUS_CONVERGED;
+    }
+    // append the plastic points of this wavefront: one atomic for the wavefront, ranks from the ballot
+    const bool take = valid && plastic0;
+    const uint64_t mask = __ballot(take);
+    if (mask != 0ull) {
+        const int n = __popcll(mask);
+        unsigned long long base = 0ull;
+        if ((threadIdx.x & 63u) == 0u) base = atomicAdd(count, (unsigned long long)n);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const unsigned long long at = (((unsigned long long)hi << 32) | lo) + (unsigned long long)rank;
+        if (take && at < (unsigned long long)B) list[at] = (uint32_t)(blk0 + threadIdx.x);     // (at < B always, for a counter that started at 0)
+    }
+}
+// the list's length starts at zero: a one-thread kernel on the launch's stream (a kernel node under graph capture, like the work
+// pool's ticket -- no runtime call that a capturing stream could treat differently)
+__global__ void k_screen_reset(unsigned long long* count);
+#if CM_HAS_PART(0)
+__global__ void k_screen_reset(unsigned long long* count) { *count = 0ull; }
+#endif
+
+template <int YK, bool ROT, bool LS>
+constexpr int min_waves_listed() { return min_waves_update<CM_FULL_3D, YK, LS, false, false>(); }
+
+// the lockstep update of k_update over a list of points (FULL_3D); rows are addressed by point index (B * 8 < 2^32)
+template <int YK, bool ROT, bool LS>
+__global__ __launch_bounds__(kBlock, (min_waves_listed<YK, ROT, LS>())) void k_update_listed(cm_model_desc m, int64_t B,
+        const double* __restrict__ gradu, const double* __restrict__ xi_prev,
+        double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status,
+        const uint32_t* __restrict__ list, const unsigned long long* __restrict__ count) {
+    constexpr int NX = 7, NU = 9;
+    const unsigned long long nraw = *count;                      // uniform
+    const unsigned long long n = nraw < (unsigned long long)B ? nraw : (unsigned long long)B;
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * kBlock;
+    if (t0 >= n) return;
+    const bool valid = t0 + threadIdx.x < n;
+    const uint32_t pt = list[valid ? t0 + threadIdx.x : n - 1];  // tail lanes shadow the last listed point, never store
+    const uint32_t off = pt * 8u;
+    auto row_load = [&](const double* base, int k) {
+        cm_gcptr row = (cm_gcptr)(base + (int64_t)k * B);
+        asm volatile("" : "+s"(row));
+        return *(const __attribute__((address_space(1))) double*)(row + off);
+    };
+    auto row_store = [&](double* base, int k, double v) {
+        cm_gptr row = (cm_gptr)(base + (int64_t)k * B);
+        asm volatile("" : "+s"(row));
+        *(__attribute__((address_space(1))) double*)(row + off) = v;
+    };
+    double G[NU], xp[NX], x[NX], eg[6], z[6];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) G[k] = row_load(gradu, k);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) xp[k] = row_load(xi_prev, k);
+    strain_from_gradu<CM_FULL_3D, ROT>(m, G, eg);
+    strain_z<CM_FULL_3D, ROT>(m, z);
+    __shared__ double ls_stage[LS ? kLsSlots * kBlock : 1];
+    uint32_t st = newton_any<CM_FULL_3D, YK, LS, true, false>(m, eg, z, xp, x, valid, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock));
+    Eval<CM_FULL_3D> ev;
+    strain_stress<CM_FULL_3D>(m, eg, z, x, ev);
+    if (status) {
+        double phi, gt[6], Ht[6][6];
+        yield_eval<YK, false>(m, ev.s, phi, gt, Ht);
+        const double f = (phi - (m.Y + hardening(m, x[6]).H)) * 0.5 / m.mu;
+        if ((f > m.yield_tol) || (fabs(f) < m.yield_tol)) st |= CM_STATUS_PLASTIC;
+    }
+    double sg[6];
+    to_global<ROT>(m, ev.s, sg);
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) row_store(xi, k, x[k]);
+        if (sigma) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) row_store(sigma, k, sg[k]);
+        }
+        if (status) status[pt] = st;
+    }
+}
+
 // ---- cm_update_rate: rate-form model (small_rate_elastic_plastic) ------------------------------------------
 template <int DEF, int YK, bool ROT, bool LS, bool TANGENT = false>
 __global__ __launch_bounds__(kBlock) void k_update_rate(cm_model_desc m, int64_t B,
@@ -1453,6 +1579,11 @@ __global__ __launch_bounds__(64) void k_param_adjoint_history(cm_model_desc m, i
 
 // ---- dispatch --------------------------------------------------------------------------------------
 inline int64_t nblocks_of(int64_t B) { return (B + kBlock - 1) / kBlock; }
+// what the reducing entry points need of their workspace (cm_workspace_bytes adds the screened update's list behind it)
+inline int64_t reduce_workspace_bytes(int64_t B) {
+    const int64_t nb = B <= 0 ? 1 : nblocks_of(B);
+    return (nb + kRedBlocks + 1) * kRed * (int64_t)sizeof(double);   // block partials + stage rows + one result row
+}
 
 inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_PLASTIC) {
     if (m->model_kind != model_kind) return false;
@@ -1585,11 +1716,7 @@ inline int pool_resident_waves(const void* kernel) {
     return cus * per_cu;
 }
 
-// The J2 subspace iterations (newton_j2_line / newton_j2_plane) treat a full step as the Armijo search's first trial; under
-// the legacy backtracking (CM_LS_LEGACY) the acceptance test is another one, so those configurations run the general path.
-static inline bool use_subspace_newton(const cm_model_desc* m) {
-    return !(m->solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m->ls_max_evals > 0 && m->ls_kind == CM_LS_LEGACY);
-}
+static inline bool use_subspace_newton(const cm_model_desc* m) { return use_fast_newton(m); }      // cm_structured.hpp
 // Iteration-bound configurations (the network surfaces, Hosford under the line search: pool_pays<>) run cm_update on the work
 // pool.  The fused entry points below take the same route for them -- work-pool update, then the reverse sweep as a second
 // kernel over the stored states -- instead of the lockstep fused kernel, whose wavefronts wait for their slowest point
@@ -1645,9 +1772,24 @@ __global__ __launch_bounds__(kBlock) void k_tangent_state(cm_model_desc m, int64
     }
 }
 
+// workspace of the screened route: [0, 8) the list length, [256, 256 + 4 B) the list of plastic point indices
+constexpr int64_t kScreenListOffset = 256;
+static inline int64_t screen_workspace_bytes(int64_t B) { return kScreenListOffset + 4 * (B > 0 ? B : 1); }
+// Which configurations take the screened route (k_screen + k_update_listed) when the caller provides the workspace: FULL_3D,
+// total form, an evaluation expensive enough to pay for the second pass over the plastic points' rows -- the network surfaces,
+// Barlat, and Hosford on the reference's iteration (with the analytic warm start it is a two-evaluation kernel: lockstep).
+static inline bool screen_route(const cm_model_desc* m, int64_t B, const void* ws, int64_t ws_bytes) {
+    static const bool off = [] { const char* e = getenv("CM_DEBUG_NO_SCREEN"); return e && atoi(e) != 0; }();     // A/B against the work pool
+    if (!CM_SCREEN || off || !m || !ws || ws_bytes < screen_workspace_bytes(B) || ((uintptr_t)ws & 7)) return false;
+    if (m->model_kind != CM_SMALL_ELASTIC_PLASTIC || m->def_type != CM_FULL_3D || (m->solver_flags & CM_SOLVER_LOCKSTEP)) return false;
+    if (B < 4096 || B >= ((int64_t)1 << 29)) return false;      // 32-bit byte offsets into the rows
+    return is_dense_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && !hosford_warm_route(m));
+}
+
 template <bool TANGENT>
 int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
-                  double* xi, double* sigma, double* dsig, uint32_t* status, void* stream) {
+                  double* xi, double* sigma, double* dsig, uint32_t* status, void* stream,
+                  void* ws = nullptr, int64_t ws_bytes = 0) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
     if (!supported(m)) return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;                       // empty batch: nothing to read or write
@@ -1659,11 +1801,26 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
     if constexpr (TANGENT) {
         // iteration-bound configurations: work-pool update, then the tangent at the stored states as a second kernel
         if (pool_route(m, B)) {
-            const int rc = cm_update(m, B, gradu, xi_prev, xi, sigma, status, stream);
+            const int rc = cm_update_ws(m, B, gradu, xi_prev, xi, sigma, status, ws, ws_bytes, stream);
             if (rc != CM_OK) return rc;
             const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
                 if constexpr (pool_pays<Y, true>())
                     hipLaunchKernelGGL((k_tangent_state<D, Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, dsig, status);
+            });
+            if (!found) return CM_ERR_UNSUPPORTED;
+            return check_launch();
+        }
+    }
+    if constexpr (!TANGENT) {
+        if (screen_route(m, B, ws, ws_bytes)) {
+            unsigned long long* const count = (unsigned long long*)ws;
+            uint32_t* const list = (uint32_t*)((char*)ws + kScreenListOffset);
+            hipLaunchKernelGGL(k_screen_reset, dim3(1), dim3(1), 0, s, count);
+            const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
+                if constexpr (D == CM_FULL_3D && screen_pays<Y>()) {
+                    hipLaunchKernelGGL((k_screen<Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                    hipLaunchKernelGGL((k_update_listed<Y, R, LS>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                }
             });
             if (!found) return CM_ERR_UNSUPPORTED;
             return check_launch();
@@ -1723,7 +1880,7 @@ int launch_reverse(const cm_model_desc* m, int64_t B, const double* gradu, const
     if (B > 0 && (MODE == 0 || MODE == 2) && !xi_in) return CM_ERR_BAD_ARG;
     if ((MODE == 1 || MODE == 2) && !wsq6) return CM_ERR_BAD_ARG;
     if (!supported(m)) return CM_ERR_UNSUPPORTED;
-    if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (wbytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* partials = (double*)workspace;
     const int64_t nb = nblocks_of(B);
@@ -1763,7 +1920,7 @@ int launch_reverse_rate(const cm_model_desc* m, int64_t B, const double* gradu, 
     if (B > 0 && (MODE == 0 || MODE == 2) && !xi_in) return CM_ERR_BAD_ARG;
     if ((MODE == 1 || MODE == 2) && !wsq6) return CM_ERR_BAD_ARG;
     if (!supported(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || rate_dense(m, CM_SMALL_RATE_ELASTIC_PLASTIC) || rate_uniaxial_dense(m)) return CM_ERR_UNSUPPORTED;
-    if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (wbytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* partials = (double*)workspace;
     const int64_t nb = nblocks_of(B);
@@ -1793,7 +1950,7 @@ int launch_history(const cm_model_desc* m, int64_t B, int K, const double* gradu
     if (!m || B < 0 || K < 1 || !out || !workspace || (!wsq6 && !hc.sbar_hist)) return CM_ERR_BAD_ARG;
     if (B > 0 && (!gradu_hist || (!data_hist && !hc.sbar_hist) || !xi0 || !xi_hist)) return CM_ERR_BAD_ARG;
     if (!supported(m, MK) || rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m))) return CM_ERR_UNSUPPORTED;
-    if (wbytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (wbytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* partials = (double*)workspace;
     const int64_t nb = nblocks_of(B);
@@ -2117,7 +2274,7 @@ int cmi_objective_from_state(const cm_model_desc* m, int64_t B, const double* gr
 
 
 #if CM_HAS_PART(1) && !CM_HNN_VARIANT
-int cm_abi_version(void) { return 5; }
+int cm_abi_version(void) { return 6; }
 #endif
 
 #if CM_HAS_PART(1) && !CM_HNN_VARIANT
@@ -2145,10 +2302,15 @@ int cm_num_gradu(const cm_model_desc* m) {
 #endif
 
 #if CM_HAS_PART(1) && !CM_HNN_VARIANT
+// the reducing entry points' scratch, followed (8-byte aligned) by what cm_update_ws can use: a caller that sizes its workspace
+// from this one function serves both -- the fused entry points hand the tail to the update they start with
 int64_t cm_workspace_bytes(int64_t B) {
     if (B < 0) return CM_ERR_BAD_ARG;
-    const int64_t nb = B == 0 ? 1 : nblocks_of(B);
-    return (nb + kRedBlocks + 1) * kRed * (int64_t)sizeof(double);   // block partials + stage rows + one result row
+    return reduce_workspace_bytes(B) + screen_workspace_bytes(B);
+}
+int64_t cm_update_workspace_bytes(int64_t B) {
+    if (B < 0) return CM_ERR_BAD_ARG;
+    return screen_workspace_bytes(B);
 }
 #endif
 
@@ -2156,6 +2318,10 @@ int64_t cm_workspace_bytes(int64_t B) {
 int cm_update(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
               double* xi, double* sigma, uint32_t* status, void* stream) {
     return launch_update<false>(m, B, gradu, xi_prev, xi, sigma, nullptr, status, stream);
+}
+int cm_update_ws(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+                 double* xi, double* sigma, uint32_t* status, void* workspace, int64_t workspace_bytes, void* stream) {
+    return launch_update<false>(m, B, gradu, xi_prev, xi, sigma, nullptr, status, stream, workspace, workspace_bytes);
 }
 #endif
 
@@ -2206,6 +2372,11 @@ int cm_update_tangent(const cm_model_desc* m, int64_t B, const double* gradu, co
                       double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream) {
     return launch_update<true>(m, B, gradu, xi_prev, xi, sigma, dsigma_dgradu, status, stream);
 }
+int cm_update_tangent_ws(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
+                         double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+    return launch_update<true>(m, B, gradu, xi_prev, xi, sigma, dsigma_dgradu, status, stream, workspace, workspace_bytes);
+}
 #endif
 
 #if CM_HAS_PART(2)
@@ -2213,7 +2384,7 @@ int cm_update_vjp(const cm_model_desc* m, int64_t B, const double* gradu, const 
                   const double* sigma_bar, double* grad_p, double* xi_prev_bar, double* gradu_bar,
                   void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p) return CM_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     return launch_reverse<0>(m, B, gradu, xi_prev, xi, sigma_bar, nullptr, nullptr, nullptr, nullptr, xi_prev_bar,
                              gradu_bar, grad_p, 1, 0, workspace, workspace_bytes, stream);
 }
@@ -2224,9 +2395,11 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
                       const double* sigma_bar, double* xi, double* sigma, double* grad_p,
                       void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p || !xi) return CM_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     if (pool_route(m, B) && gradu && xi_prev && sigma_bar) {
-        const int rc = cm_update(m, B, gradu, xi_prev, xi, sigma, nullptr, stream);
+        // the update gets what the caller's workspace holds beyond the reduction's share (cm_workspace_bytes covers both)
+        const int64_t rb = reduce_workspace_bytes(B);
+        const int rc = cm_update_ws(m, B, gradu, xi_prev, xi, sigma, nullptr, (char*)workspace + rb, workspace_bytes - rb, stream);
         return rc != CM_OK ? rc : cm_update_vjp(m, B, gradu, xi_prev, xi, sigma_bar, grad_p, nullptr, nullptr, workspace, workspace_bytes, stream);
     }
     return launch_reverse<3>(m, B, gradu, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr, nullptr,
@@ -2404,8 +2577,9 @@ int cm_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, con
 int cm_objective_grad(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       const double* data, const double* wsq6, double* out, double* xi,
                       void* workspace, int64_t workspace_bytes, void* stream) {
-    if (xi && pool_route(m, B) && gradu && xi_prev && data && out && workspace && workspace_bytes >= cm_workspace_bytes(B)) {
-        const int rc = cm_update(m, B, gradu, xi_prev, xi, nullptr, nullptr, stream);   // needs somewhere to keep the states: only with xi
+    if (xi && pool_route(m, B) && gradu && xi_prev && data && out && workspace && workspace_bytes >= reduce_workspace_bytes(B)) {
+        const int64_t rb = reduce_workspace_bytes(B);
+        const int rc = cm_update_ws(m, B, gradu, xi_prev, xi, nullptr, nullptr, (char*)workspace + rb, workspace_bytes - rb, stream);   // needs somewhere to keep the states: only with xi
         return rc != CM_OK ? rc : cmi_objective_from_state(m, B, gradu, xi_prev, xi, data, wsq6, out, workspace, workspace_bytes, stream);
     }
     return launch_reverse<1>(m, B, gradu, xi_prev, nullptr, data, wsq6, nullptr, xi, nullptr, nullptr, nullptr,
@@ -2434,7 +2608,7 @@ int cm_update_rate_vjp(const cm_model_desc* m, int64_t B, const double* gradu, c
                        double* grad_p, double* xi_prev_bar, double* gradu_bar,
                        void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p) return CM_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     return launch_reverse_rate<0>(m, B, gradu, gradu_prev, xi_prev, xi, sigma_bar, nullptr, nullptr, nullptr, nullptr,
                                   xi_prev_bar, gradu_bar, grad_p, 1, 0, workspace, workspace_bytes, stream);
 }
@@ -2453,7 +2627,7 @@ int cm_update_rate_and_vjp(const cm_model_desc* m, int64_t B, const double* grad
                            const double* xi_prev, const double* sigma_bar, double* xi, double* sigma, double* grad_p,
                            void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p || (B > 0 && !xi)) return CM_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < cm_workspace_bytes(B)) return CM_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
     return launch_reverse_rate<3>(m, B, gradu, gradu_prev, xi_prev, nullptr, sigma_bar, nullptr, nullptr, xi, sigma, nullptr,
                                   nullptr, grad_p, 1, 0, workspace, workspace_bytes, stream);
 }

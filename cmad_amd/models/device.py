@@ -8,6 +8,7 @@ GPU) they raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -45,6 +46,12 @@ class NewtonSettings:
     # counts).  False forces the general 7 / 8-dof iteration (include/cmad_hip.h CM_SOLVER_GENERAL_NEWTON).  Ignored for
     # every other configuration.
     j2_radial_line: bool = True
+    # Warm starts (include/cmad_hip.h CM_SOLVER_REFERENCE_ITERATES): where the backward-Euler equations reduce to a scalar return
+    # map or a small benign system -- Hill / FULL_3D, J2 / PLANE_STRESS, Hosford a >= 20 / FULL_3D -- the kernels solve that first
+    # and start the reference's Newton at its result (same root; the reference's convergence test on the reference's residual
+    # still decides; `status` counts iterations from the warm start).  False: the iteration starts at x_prev and reproduces the
+    # reference's iterates and counts -- what the imperative `newton_solve` facade asks for, since it RETURNS the count.
+    warm_start: bool = True
     # cm_update runs the iteration-bound configurations on a work pool (a lane that has finished its point takes the next
     # one, include/cmad_hip.h CM_SOLVER_LOCKSTEP); True keeps one point per lane for the whole kernel (A/B measurements).
     lockstep: bool = False
@@ -227,7 +234,8 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
     if kind == "legacy":
         d.ls_c1, d.ls_lo = 1e-4, 0.5
     d.solver_flags = (0 if getattr(newton, "j2_radial_line", True) else _lib.SOLVER_GENERAL_NEWTON) | \
-                     (_lib.SOLVER_LOCKSTEP if getattr(newton, "lockstep", False) else 0)
+                     (_lib.SOLVER_LOCKSTEP if getattr(newton, "lockstep", False) else 0) | \
+                     (0 if getattr(newton, "warm_start", True) else _lib.SOLVER_REFERENCE_ITERATES)
     info = {"elastic_names": names, "lame_jac": J, "yield_type": ytype}
     if hybrid is not None:
         widths, packed = hybrid.packed(values)
@@ -388,7 +396,7 @@ class DeviceEvaluator:
         self.nu = self.L.cm_num_gradu(C.byref(desc))
         if self.nx < 0 or self.nu < 0:
             raise NotImplementedError("def_type not available in the HIP library")
-        self._ws = None
+        self._ws, self._captured_ws = {}, []
         self._nn_dev = None
         if "nn_packed" in info:                    # network weights live in device memory for the kernels
             torch = _torch()
@@ -401,11 +409,38 @@ class DeviceEvaluator:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def _workspace(self, B, device):
+        """Device scratch of `cm_workspace_bytes(B)` bytes (block partials of the reductions + the screened update's list,
+        include/cmad_hip.h).  One per STREAM -- launches on different streams may run at the same time -- and a private one for
+        every launch captured into a HIP graph, which keeps its workspace for all its replays."""
         torch = _torch()
         need = self.L.cm_workspace_bytes(B)
-        if self._ws is None or self._ws.numel() * 8 < need or self._ws.device != device:
-            self._ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=device)
-        return self._ws, need
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=device)      # from the graph's private pool
+            self._captured_ws.append(ws)
+            return ws, need
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 8 < need:
+            ws = self._ws[key] = torch.empty((need + 7) // 8, dtype=torch.float64, device=device)
+        return ws, need
+
+    def screened(self, B):
+        """True when `cm_update_ws` runs this configuration screened (k_screen + k_update_listed; `screen_route` in
+        cmad_hip.hip): FULL_3D, total form, the network surfaces / Barlat / Hosford on the reference's iteration, 4096 <= B < 2^29."""
+        d = self.desc
+        if d.model_kind != 0 or d.def_type != 0 or (d.solver_flags & _lib.SOLVER_LOCKSTEP) or not (4096 <= B < 2 ** 29):
+            return False
+        if os.environ.get("CM_DEBUG_NO_SCREEN", "0") not in ("", "0"):
+            return False
+        return d.yield_kind in (3, 4, 5) or (d.yield_kind == YIELD_KINDS["hosford"] and self.pool_route(B))
+
+    def _update_workspace(self, B, device):
+        """(workspace, bytes) for cm_update_ws: the evaluator's per-stream workspace when the screened route applies, else none
+        (the call is then plain cm_update; CM_DEBUG_NO_SCREEN=1 keeps the work pool for A/B measurements)."""
+        if not self.screened(B):
+            return None, 0
+        ws, need = self._workspace(B, device)
+        return ws, need
 
     # -- entry points
     def pool_route(self, B):
@@ -419,7 +454,7 @@ class DeviceEvaluator:
             return False
         if d.yield_kind == YIELD_KINDS["hosford"]:
             # FULL_3D with a >= 20 starts the Newton at the analytic warm start (cm::hosford_warm_start): lockstep kernels
-            warm = (d.def_type == 0 and d.yc[0] >= 20.0 and not (d.solver_flags & _lib.SOLVER_GENERAL_NEWTON)
+            warm = (d.def_type == 0 and d.yc[0] >= 20.0 and not (d.solver_flags & (_lib.SOLVER_GENERAL_NEWTON | _lib.SOLVER_REFERENCE_ITERATES))
                     and not (d.ls_max_evals > 0 and d.ls_kind == 1) and d.hnn_width == 0)
             return d.ls_max_evals > 0 and not warm
         return d.yield_kind in (3, 4)
@@ -438,12 +473,14 @@ class DeviceEvaluator:
         if tangent:
             ds = o.get("dsigma") if o.get("dsigma") is not None else torch.empty((6 * self.nu, B), dtype=torch.float64, device=dev)
             _check_soa(ds, 6 * self.nu, B, "dsigma")
-            rc = self.L.cm_update_tangent(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma),
-                                          _ptr(ds), _ptr(status), self._stream())
+            ws, need = self._update_workspace(B, dev)
+            rc = self.L.cm_update_tangent_ws(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma),
+                                             _ptr(ds), _ptr(status), _ptr(ws), need, self._stream())
             _lib.check(rc, "cm_update_tangent")
             return xi, sigma, status, ds.view(6, self.nu, B)
-        rc = self.L.cm_update(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma),
-                              _ptr(status), self._stream())
+        ws, need = self._update_workspace(B, dev)
+        rc = self.L.cm_update_ws(C.byref(self.desc), B, _ptr(gradu), _ptr(xi_prev), _ptr(xi), _ptr(sigma),
+                                 _ptr(status), _ptr(ws), need, self._stream())
         _lib.check(rc, "cm_update")
         return xi, sigma, status
 

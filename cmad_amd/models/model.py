@@ -573,7 +573,7 @@ class Model(ABC):
         """Solve the local problem for the gathered state with ONE `cm_update` launch; sets xi, returns
         (iters, converged).  Same algorithm as newton_solve / make_newton_solve (nonlinear_solver.py)."""
         import torch
-        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0})
+        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0}, warm_start=False)     # returns the reference's count
         if getattr(self, "_is_complex", False):
             return self._complex_newton(st)
         ev = self.device_evaluator(st)

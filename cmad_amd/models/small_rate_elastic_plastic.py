@@ -99,7 +99,7 @@ class SmallRateElasticPlastic(Model):
 
     def device_newton(self, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search=None):
         import torch
-        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0})
+        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0}, warm_start=False)     # returns the reference's count
         if self._is_complex:
             return self._complex_newton(st)
         ev = self.device_evaluator(st)

@@ -62,6 +62,17 @@ enum cm_param_index {
  * CM_SOLVER_J2_RADIAL_LINE is accepted for compatibility (the restriction is the default). */
 #define CM_SOLVER_J2_RADIAL_LINE 1
 #define CM_SOLVER_GENERAL_NEWTON 2
+/* Warm starts (default on).  Where the backward-Euler equations reduce to a scalar return map or a small benign system -- Hill
+ * in FULL_3D (one equation in kappa = 2 mu dgam / phi), J2 in PLANE_STRESS (one equation in g = 3 mu dgam / phi, the stretch
+ * eliminated through the sigma_33 row), Hosford with a >= 20 in FULL_3D (three equations in log-variables) -- the kernels solve
+ * that first and START the reference's Newton iteration at its result: the reference's residual is evaluated there and the
+ * reference's convergence test (relative to ||C(x_prev)||) decides, so a converged map costs one residual evaluation and
+ * anything else is finished by the reference's Newton steps / line search from there.  Same root to the Newton tolerance
+ * (SURVEY.md Appendix A); `status` counts the iterations taken FROM the warm start (usually 0).
+ * CM_SOLVER_REFERENCE_ITERATES switches the warm starts off: the iteration starts at x_prev and reproduces the reference's
+ * iterates and iteration counts (the invariant-subspace forms above stay on: they are the same iterates);
+ * CM_SOLVER_GENERAL_NEWTON switches both off. */
+#define CM_SOLVER_REFERENCE_ITERATES 8
 /* cm_update runs the iteration-bound configurations on a work pool: a lane that has finished its Gauss point takes the next one
  * instead of waiting for the slowest point of its wavefront (same iteration per point, same results).  The predicate
  * (pool_route() in cmad_hip.hip, DeviceEvaluator.pool_route in cmad_amd/models/device.py): total-form model, B >= 256, and
@@ -146,7 +157,7 @@ typedef struct cm_model_desc {
 } cm_model_desc;
 
 /* library / build info */
-int  cm_abi_version(void);                       /* 5: cm_model_desc.ls_kind (CM_LS_LEGACY), hnn_width / hnn_offset (network hardening); cm_hessian_history takes per-step stress curvature and
+int  cm_abi_version(void);                       /* 6: cm_update_ws / cm_update_tangent_ws / cm_update_workspace_bytes, cm_workspace_bytes includes the screened update's share; 5: cm_model_desc.ls_kind (CM_LS_LEGACY), hnn_width / hnn_offset (network hardening); cm_hessian_history takes per-step stress curvature and
                                                   * a state curvature; nn_weights layout carries the per-unit records */
 const char* cm_last_hip_error(void);             /* name of the last HIP error behind a CM_ERR_LAUNCH */
 int  cm_sizeof_model_desc(void);                 /* sizeof(cm_model_desc) as compiled, for binding checks */
@@ -165,6 +176,23 @@ int64_t cm_workspace_bytes(int64_t B);           /* scratch needed by the reduci
 int cm_update(const cm_model_desc* m, int64_t B,
               const double* gradu, const double* xi_prev,
               double* xi, double* sigma, uint32_t* status, void* stream);
+
+/*
+ * cm_update_ws / cm_update_tangent_ws: cm_update / cm_update_tangent with a caller-provided device workspace of at least
+ * cm_update_workspace_bytes(B) bytes (8-byte aligned; contents need not be preserved between calls; one workspace per stream).
+ * Same results.  With it the configurations whose residual evaluation is expensive (FULL_3D, total form: the network
+ * surfaces, Barlat, Hosford on the reference's iteration) run SCREENED instead of on the work pool: a streaming kernel
+ * finishes the points whose trial state is elastic (cond_residual's elastic branch at x_prev: C = 0, no iteration) and lists the
+ * others; the lockstep Newton then runs over the list, so every lane of every wavefront holds a plastic point.  Without a
+ * workspace (NULL / too small), or for any other configuration, these are cm_update / cm_update_tangent.  The fused entry points
+ * that start with an update (cm_update_and_vjp, cm_objective_grad with a state buffer, cm_update_tangent_ws) do the same with the
+ * part of their workspace beyond the reduction's share: cm_workspace_bytes(B) covers both.
+ */
+int64_t cm_update_workspace_bytes(int64_t B);
+int cm_update_ws(const cm_model_desc* m, int64_t B,
+                 const double* gradu, const double* xi_prev,
+                 double* xi, double* sigma, uint32_t* status,
+                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * cm_update_rate: the same update for the rate-form model (m->model_kind = CM_SMALL_RATE_ELASTIC_PLASTIC), whose
@@ -202,6 +230,10 @@ int cm_update_rate_tangent(const cm_model_desc* m, int64_t B,
 int cm_update_tangent(const cm_model_desc* m, int64_t B,
                       const double* gradu, const double* xi_prev,
                       double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status, void* stream);
+int cm_update_tangent_ws(const cm_model_desc* m, int64_t B,
+                         const double* gradu, const double* xi_prev,
+                         double* xi, double* sigma, double* dsigma_dgradu, uint32_t* status,
+                         void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * cm_update_vjp: reverse-mode sensitivities of one converged update for a given stress cotangent.

@@ -83,7 +83,7 @@ class HostSmallElasticPlastic(SmallElasticPlastic):
         return C[:, 0], J[:, :, 0], s[:, 0], S[:, :, 0], info
 
     def device_newton(self, max_iters=10, abs_tol=1e-14, rel_tol=1e-14, line_search=None):
-        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0})
+        st = NewtonSettings(max_iters, abs_tol, rel_tol, line_search or {"max evals": 0}, warm_start=False)    # as Model.device_newton
         if self._is_complex:
             return self._complex_newton(st)
         desc, info = self._desc(newton=st)

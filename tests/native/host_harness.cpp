@@ -51,7 +51,7 @@ static void run_update(const cm_model_desc& m, int64_t B, const double* gradu, c
             done = true;
         }
         if constexpr (has_fast_newton<DEF, YK, false>()) {          // same choice as launch_update (cmad_hip.hip)
-            if (!done && !g_dense && (!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY))) {
+            if (!done && !g_dense && use_fast_newton(&m)) {
                 st = ls ? newton_any<DEF, YK, true, true, true>(m, eg, z, xp, x, true, stage)
                         : newton_any<DEF, YK, false, true, true>(m, eg, z, xp, x, true, stage);
                 done = true;
@@ -321,7 +321,7 @@ static void run_history(const cm_model_desc& m, int64_t B, int K, const double* 
         const HostRowsIO io{B, b};
         bool done = false;
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<DEF, YK, false>()) {   // same choice as launch_history
-            if ((!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY))) {
+            if (use_fast_newton(&m)) {
                 if (ls) history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
                 else history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, data_hist, wsq6, xi0, xi_hist, true, stage, io, red, hc);
                 done = true;
@@ -344,7 +344,7 @@ static void run_primal_history(const cm_model_desc& m, int64_t B, int K, const d
         const HostRowsIO io{B, b};
         bool done = false;
         if constexpr (MK == CM_SMALL_ELASTIC_PLASTIC && has_fast_newton<DEF, YK, false>()) {
-            if ((!(m.solver_flags & CM_SOLVER_GENERAL_NEWTON) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY))) {
+            if (use_fast_newton(&m)) {
                 if (ls) primal_history_point<DEF, YK, ROT, true, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
                 else primal_history_point<DEF, YK, ROT, false, MK, true>(m, K, gradu_hist, xi0, xi_hist, sigma_hist, status_hist, true, stage, io);
                 done = true;

@@ -27,12 +27,16 @@ def rand_rot(rng):
     return q
 
 
-def settings_pair(ls):
+def settings_pair(ls, warm=False):
+    """(oracle settings, device settings).  warm = False (the parity suite's default): CM_SOLVER_REFERENCE_ITERATES -- the
+    iteration starts at x_prev as the reference's does, so that iteration counts are comparable; warm = True: the product
+    default (scalar return maps / analytic warm starts, include/cmad_hip.h), same states, counts from the warm start."""
     from cmad_amd.models.device import NewtonSettings
     if ls:
-        return (ol.newton_settings(max_iters=20, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=4),
-                NewtonSettings.traced(max_iters=20, abs_tol=1e-12, rel_tol=1e-12))
-    return ol.newton_settings(), NewtonSettings()
+        st_d = NewtonSettings.traced(max_iters=20, abs_tol=1e-12, rel_tol=1e-12)
+        st_d.warm_start = warm
+        return ol.newton_settings(max_iters=20, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=4), st_d
+    return ol.newton_settings(), NewtonSettings(warm_start=warm)
 
 
 def param_paths(yield_kind, values=None):
@@ -57,7 +61,7 @@ def leaf_grads(g_kp, info, mat, yield_kind, g_oracle, values=None):
 class Scenario:
     """Material + a non-trivial previous state + a load step, with the oracle's answers."""
 
-    def __init__(self, def_type, yield_kind, kw, rot, ls, B, seed=22, uniaxial_idx=0, values=None, eps_y=1e-3):
+    def __init__(self, def_type, yield_kind, kw, rot, ls, B, seed=22, uniaxial_idx=0, values=None, eps_y=1e-3, warm=False):
         """values: a complete parameter tree instead of the J2AnalyticalProblem one (eps_y = its yield strain, the scale of the
         synthetic strains)."""
         from cmad_amd.models.device import build_desc
@@ -66,7 +70,8 @@ class Scenario:
         self.yield_kind = yield_kind
         self.values = values if values is not None else ol.j2_voce_values(yield_kind=yield_kind, Q=rand_rot(rng) if rot else None, **kw)
         self.nd = {ol.FULL_3D: 3, ol.PLANE_STRESS: 2, ol.UNIAXIAL_STRESS: 1}[def_type]
-        self.st_o, self.st_d = settings_pair(ls)
+        self.st_o, self.st_d = settings_pair(ls, warm)
+        self.warm = warm
         self.B = B
         if def_type == ol.UNIAXIAL_STRESS:                 # grad u = the axial strain, +-4 yield strains
             self.mat = ol.Material(self.values, def_type=def_type, uniaxial_idx=uniaxial_idx)
@@ -96,20 +101,30 @@ def check_update(backend, sc):
         assert ((status >> 18) & 1).sum() == 0
         # the local Newton stops at ||C|| < 1e-14 (1e-12 with the FE settings), so two correct solves
         # of the same point may differ by ~10x that in xi (|xi| ~ 1e-3) and 2 mu x that in stress
-        np.testing.assert_allclose(xi_d, xi_o, rtol=1e-10, atol=XI_ATOL)
-        np.testing.assert_allclose(sig_d, sig_o, rtol=1e-10, atol=1e-8)
-        # identical algorithm -> identical iteration counts except where a norm sits at the tolerance
-        assert np.mean(it_d == it_o) > 0.98
-        assert np.abs(it_d - it_o).max() <= 1
+        # (a warm-started solve returns the root to round-off while the oracle's iteration stops anywhere inside its tolerance
+        # ball: with the FE settings' 1e-12 the two may differ by 10x that in xi)
+        warm_slack = 10.0 * sc.st_d.abs_tol if getattr(sc, "warm", False) else 0.0
+        np.testing.assert_allclose(xi_d, xi_o, rtol=1e-10, atol=max(XI_ATOL, warm_slack))
+        np.testing.assert_allclose(sig_d, sig_o, rtol=1e-10, atol=max(1e-8, 2e5 * warm_slack))
+        if getattr(sc, "warm", False):
+            # started at the return map's result: the reference's test usually passes there (0 iterations), never more work
+            assert (it_d <= np.maximum(it_o, 1)).mean() > 0.98
+        else:
+            # identical algorithm -> identical iteration counts except where a norm sits at the tolerance
+            assert np.mean(it_d == it_o) > 0.98
+            assert np.abs(it_d - it_o).max() <= 1
         assert (it_o > 0).mean() > 0.2          # a real share of plastic points
 
 
 def check_tangent(backend, sc):
     ds_o, _ = sc.mat.tangent_batch(sc.gradu, sc.xi1, sc.xi2)
     xi_d, sig_d, st, ds_d = backend.update(sc, sc.gradu, sc.xi1, tangent=True)
-    np.testing.assert_allclose(xi_d, sc.xi2, rtol=1e-10, atol=XI_ATOL)
+    warm_slack = 10.0 * sc.st_d.abs_tol if getattr(sc, "warm", False) else 0.0          # see check_update
+    np.testing.assert_allclose(xi_d, sc.xi2, rtol=1e-10, atol=max(XI_ATOL, warm_slack))
     scale = np.abs(ds_o).max()
-    np.testing.assert_allclose(ds_d, ds_o, rtol=1e-9, atol=1e-10 * scale)
+    # (warm: the two states sit up to 1e-12 apart inside the oracle's tolerance ball, and a sharply curved surface -- Hosford
+    # a = 64 -- turns that into a few 1e-9 of its tangent)
+    np.testing.assert_allclose(ds_d, ds_o, rtol=1e-8 if warm_slack else 1e-9, atol=(1e-9 if warm_slack else 1e-10) * scale)
 
 
 def check_vjp(backend, sc, incoming=False, grad_atol=1e-12):
@@ -447,7 +462,7 @@ def check_history(history, def_type, yield_kind, kw, rot, rate=False, ls=False, 
     mat = ol.Material(values, def_type=def_type, model_kind=ol.SMALL_RATE_EP if rate else 0, **extra)
     desc, info = build_desc(values, def_type=def_type, model_kind=1 if rate else 0, newton=st_d,
                             **({"uniaxial_stress_idx": uniaxial_idx} if extra else {}))
-    desc.solver_flags = solver_flags                    # 2 = CM_SOLVER_GENERAL_NEWTON (no J2 radial-line restriction)
+    desc.solver_flags |= solver_flags                   # 2 = CM_SOLVER_GENERAL_NEWTON (no J2 radial-line restriction); keeps settings_pair's CM_SOLVER_REFERENCE_ITERATES
     if def_type == ol.UNIAXIAL_STRESS:
         g0 = np.random.default_rng(seed + 2).uniform(-4e-3, 4e-3, size=(1, B))
     else:
@@ -566,14 +581,19 @@ def check_j2_radial_line(backend, B=4096, rot=False, def_type=ol.FULL_3D):
     span{dev(eps - eps_p_prev), dev z} x (alpha, F33) under PLANE_STRESS; CM_SOLVER_GENERAL_NEWTON (solver_flags = 2) forces
     the general 7 / 8-dof iteration.  Both must give the same states, stresses AND iteration counts as the oracle's general
     Newton, two load steps from a hardened state."""
-    for flags, ls in ((0, False), (2, False), (0, True), (2, True)):
-        sc = Scenario(def_type, "J2", {}, rot, ls, B=B)
+    # flags 8 = CM_SOLVER_REFERENCE_ITERATES (the subspace iteration, no warm start), 2 = CM_SOLVER_GENERAL_NEWTON, 0 = the product
+    # default (PLANE_STRESS: the plane's scalar return map first -- same states, counts from the warm start)
+    for flags, ls in ((8, False), (2, False), (8, True), (2, True), (0, False), (0, True)):
+        sc = Scenario(def_type, "J2", {}, rot, ls, B=B, warm=(flags == 0))
         sc.desc.solver_flags = flags
         check_update(backend, sc)
         for gradu, xp, it_o in ((sc.gradu0, sc.xi0, sc.it1), (sc.gradu, sc.xi1, sc.it2)):
             _, _, status = backend.update(sc, gradu, xp)
             it_d = (status.astype(np.uint32) & 0xFFFF).astype(np.int32)
-            assert np.mean(it_d == it_o) > 0.99, (flags, np.bincount(np.abs(it_d - it_o)))
+            if flags != 0 or def_type == ol.FULL_3D:            # (the radial line IS the scalar map: identical either way)
+                assert np.mean(it_d == it_o) > 0.99, (flags, np.bincount(np.abs(it_d - it_o)))
+            else:
+                assert np.mean(it_d == 0) > 0.99, np.bincount(it_d)
         check_vjp(backend, sc)
 
 
@@ -587,6 +607,7 @@ def check_line_search_rejections(backend, def_type=ol.FULL_3D, yield_kind="J2", 
     sc.st_o = ol.newton_settings(max_iters=30, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_TRACED, ls_max_evals=3, c1=0.6)
     sc.st_d = NewtonSettings.traced(max_iters=30, abs_tol=1e-12, rel_tol=1e-12,
                                     line_search_settings={"max evals": 3, "sufficient decrease": 0.6})
+    sc.st_d.warm_start = False                      # the reference's iterates from x_prev (a warm start would converge on arrival)
     sc.desc, sc.info = build_desc(sc.values, def_type=def_type, newton=sc.st_d)
     sc.xi1, sc.sig1, sc.it1, sc.cv1 = sc.mat.update_batch(sc.st_o, sc.gradu0, sc.xi0)
     sc.xi2, sc.sig2, sc.it2, sc.cv2 = sc.mat.update_batch(sc.st_o, sc.gradu, sc.xi1)
@@ -614,7 +635,7 @@ def check_legacy_line_search(backend, def_type=ol.FULL_3D, yield_kind="hosford",
     sc.values = ol.j2_voce_values(yield_kind=yield_kind, **kw)
     sc.mat = ol.Material(sc.values, def_type=def_type, uniaxial_idx=uniaxial_idx)
     sc.st_o = ol.newton_settings(max_iters=60, abs_tol=1e-12, rel_tol=1e-12, ls_kind=ol.LS_LEGACY, ls_max_evals=max_evals)
-    sc.st_d = NewtonSettings(60, 1e-12, 1e-12, {"max evals": max_evals, "kind": "legacy"})
+    sc.st_d = NewtonSettings(60, 1e-12, 1e-12, {"max evals": max_evals, "kind": "legacy"}, warm_start=False)
     sc.desc, sc.info = build_desc(sc.values, def_type=def_type, newton=sc.st_d, uniaxial_stress_idx=uniaxial_idx)
     if def_type == ol.UNIAXIAL_STRESS:
         g0 = np.random.default_rng(24).uniform(-4e-3, 4e-3, size=(1, B))
@@ -755,7 +776,7 @@ def check_edge_cases(backend, def_type=ol.FULL_3D):
         xp[7] = 1.0
     for cap in (1, 2, 3):
         sc = S(); sc.mat = ol.Material(values, def_type=def_type)
-        sc.desc, sc.info = build_desc(values, def_type=def_type, newton=NewtonSettings(max_iters=cap))
+        sc.desc, sc.info = build_desc(values, def_type=def_type, newton=NewtonSettings(max_iters=cap, warm_start=False))
         xi_o, sig_o, it_o, cv_o = sc.mat.update_batch(ol.newton_settings(max_iters=cap), g, xp)
         xi_d, sig_d, status = backend.update(sc, g, xp)
         status = status.astype(np.uint32)
@@ -1187,3 +1208,22 @@ def check_barlat_generic(hessians, param_blocks, def_type=ol.FULL_3D, seed=4):
     Sq = mat.dcauchy(ol.W_PARAMS, xi, xp, U)[_V6_OF_9][:, oc]
     np.testing.assert_allclose(dCp[19:, :, 0].T, Jq, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Jq).max()))
     np.testing.assert_allclose(dSp[19:, :, 0].T, Sq, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Sq).max()))
+
+
+def check_warm_start(backend, def_type, yield_kind, kw, rot, ls, B=1024):
+    """The product default for Hill / FULL_3D, J2 / PLANE_STRESS and Hosford (a >= 20) / FULL_3D: the scalar return map (resp.
+    the analytic warm start) first, then the reference's Newton from there (include/cmad_hip.h CM_SOLVER_REFERENCE_ITERATES is
+    the opt-out).  Against the oracle's general Newton from x_prev, two load steps from a hardened state: states, stresses,
+    consistent tangent and reverse sweep; nearly every point passes the reference's convergence test on arrival (0 iterations);
+    re-applying a strain to its own result is a 0-iteration step that returns the state bit for bit."""
+    sc = Scenario(def_type, yield_kind, kw, rot, ls, B=B, warm=True)
+    check_update(backend, sc)
+    for gradu, xp in ((sc.gradu0, sc.xi0), (sc.gradu, sc.xi1)):
+        xi_d, _, status = backend.update(sc, gradu, xp)
+        it_d = (status.astype(np.uint32) & 0xFFFF).astype(np.int32)
+        assert np.mean(it_d == 0) > (0.8 if yield_kind == "hosford" else 0.99), np.bincount(it_d)
+        xi_again, _, st2 = backend.update(sc, gradu, xi_d)
+        assert ((st2.astype(np.uint32) & 0xFFFF) == 0).all() and np.array_equal(xi_again, xi_d)
+    if not ls or yield_kind == "hosford":
+        check_tangent(backend, sc)
+        check_vjp(backend, sc)

@@ -17,8 +17,9 @@ CHILD = os.path.join(ROOT, "tests", "pool_child.py")
 pytestmark = pytest.mark.gpu
 
 
-def child(surface, case, B, **env):
-    e = {k: v for k, v in os.environ.items() if not k.startswith("CM_DEBUG_POOL")}
+def child(surface, case, B, screened=False, **env):
+    e = {k: v for k, v in os.environ.items() if not k.startswith("CM_DEBUG_")}
+    e["CM_DEBUG_NO_SCREEN"] = "0" if screened else "1"     # DeviceEvaluator.update hands cm_update_ws a workspace: keep the work pool
     e.update({k: str(v) for k, v in env.items()})
     res = subprocess.run([sys.executable, CHILD, surface, case, str(B)], capture_output=True, text=True, env=e, timeout=900)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
@@ -62,3 +63,20 @@ def test_replayed_graph_overlapping_eager_launches_on_other_streams(surface, slo
     if slots is not None:
         env["CM_DEBUG_POOL_SLOTS"] = slots
     child(surface, "streams", 150_000, **env)
+
+
+# ---- the screened route (cm_update_ws: k_screen + k_update_listed) through the same child: completeness on sentinel-prefilled
+# outputs and launch-size independence, graph capture (a private workspace per captured launch), streams (one per stream)
+@pytest.mark.parametrize("surface,B", [("hosford", 5_000_001), ("hybrid", 4_200_000)])
+def test_screened_route_writes_every_point(surface, B):
+    child(surface, "complete", B, screened=True)
+
+
+@pytest.mark.parametrize("surface,B", [("hosford", 1_000_000), ("hybrid", 600_000)])
+def test_screened_route_under_graph_capture(surface, B):
+    child(surface, "graph", B, screened=True)
+
+
+@pytest.mark.parametrize("surface", ["hosford", "hybrid"])
+def test_screened_route_on_overlapping_streams(surface):
+    child(surface, "streams", 150_000, screened=True)

@@ -55,6 +55,7 @@ def test_build_desc_and_errors():
         build_desc(bad)
     assert build_desc(j2_voce_values())[0].solver_flags == 0                              # radial-line restriction on
     assert build_desc(j2_voce_values(), newton=NewtonSettings(j2_radial_line=False))[0].solver_flags == 2
+    assert build_desc(j2_voce_values(), newton=NewtonSettings(warm_start=False))[0].solver_flags == 8    # CM_SOLVER_REFERENCE_ITERATES
 
 
 def test_fold_weight_and_data_is_exact():

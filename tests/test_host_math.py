@@ -328,7 +328,7 @@ def test_j2_radial_line_newton_matches_general_path(def_type, rot, solver_varian
     pc.check_j2_radial_line(BACKEND, B=2048, rot=rot, def_type=def_type)
     # the restricted iteration carried (nearly) every point: a handful per 10^4 may leave for the general path when the
     # reduced and the full residual norm straddle the tolerance
-    assert hh.subspace_fallbacks() <= 20
+    assert hh.subspace_fallbacks() <= 30          # (six runs of two load steps over 2048 points)
 
 
 @pytest.mark.parametrize("rot", [False, True])
@@ -641,3 +641,16 @@ def test_plain_newton_through_the_line_search_kernels(def_type, yield_kind, kw, 
     for a, b in zip(ref, got):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("ls", [False, True])
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
+                                                    (ol.FULL_3D, "hosford", {"a": 20.0}), (ol.FULL_3D, "hosford", {"a": 64.0})])
+def test_warm_started_newton_against_the_oracle(def_type, yield_kind, kw, rot, ls, solver_variant):
+    """Scalar return maps / analytic warm starts (the default of the batched entry points) against the oracle's general Newton."""
+    if yield_kind == "hosford" and not ls:
+        pytest.skip("plain Newton from x_prev does not converge for large Hosford exponents: nothing to compare with")
+    if solver_variant != "structured":
+        pytest.skip("the warm starts are variants of the structured solver")
+    pc.check_warm_start(BACKEND, def_type, yield_kind, kw, rot, ls, B=512)
