@@ -894,14 +894,17 @@ CM_D uint32_t newton_j2_plane(const cm_model_desc& m, const double eg[6], const 
         for (int wit = 0; wit < 12; ++wit) {
             const double i1g = rcp(1.0 + g);
             const double N = za * i1g + Kz * tr0, D = zb * i1g + Kz * trz, iD = rcp(D);
-            tg = -N * iD;
+            const double tn = -N * iD;
             const double dt = (za * D - N * zb) * (i1g * i1g) * (iD * iD);
-            const double S = aa + 2.0 * tg * ab + tg * tg * bb, dS = 2.0 * (ab + tg * bb) * dt;
+            const double S = aa + 2.0 * tn * ab + tn * tn * bb, dS = 2.0 * (ab + tn * bb) * dt;
             const double rS = (S > 0.0) ? rsqrt_pos(S) : 0.0;
-            Rg = S * rS;
+            const double Rn = S * rS;
+            // a lane that has finished keeps what it finished with: its result must not depend on how long the other lanes of
+            // its wavefront keep iterating (a batch gives the same bits however it is sliced into launches)
+            if (!done) { tg = tn; Rg = Rn; }
             const double dR = 0.5 * dS * rS;
-            const double phi_g = sqrt6mu * Rg * i1g, dphi = sqrt6mu * (dR * i1g - Rg * i1g * i1g);
-            const double dgam = g * Rg * i1g * (1.0 / c32), ddg = ((Rg + g * dR) * i1g - g * Rg * i1g * i1g) * (1.0 / c32);
+            const double phi_g = sqrt6mu * Rn * i1g, dphi = sqrt6mu * (dR * i1g - Rn * i1g * i1g);
+            const double dgam = g * Rn * i1g * (1.0 / c32), ddg = ((Rn + g * dR) * i1g - g * Rn * i1g * i1g) * (1.0 / c32);
             const Hard h = hardening(m, alpha_p + dgam);
             const double F = phi_g - (m.Y + h.H), dF = dphi - h.dH * ddg;
             // Elastic step: g = 0, t = t(0).  Taken only when the state at x_prev -- with the OLD stretch -- is on the elastic

@@ -474,12 +474,16 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
 template <int YK>
 constexpr bool screen_pays() { return CM_SCREEN != 0 && (is_dense_yield(YK) || YK == CM_YIELD_HOSFORD); }
 
+// 1024 lanes per workgroup: the append is ONE atomic per workgroup (wave counts summed through LDS).  All wavefronts of the grid
+// add to the same address, and the device serves about 80 M same-address atomics per second: one per wavefront -- 78 000 for
+// 5 x 10^6 points -- took 0.96 ms by itself (profiles/r04_screen_atomics.txt); one per 1024 points takes 0.06 ms.
+constexpr int kScreenBlock = 1024;
 template <int YK, bool ROT>
-__global__ __launch_bounds__(kBlock) void k_screen(cm_model_desc m, int64_t B,
+__global__ __launch_bounds__(kScreenBlock) void k_screen(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
         double* __restrict__ xi, double* __restrict__ sigma, uint32_t* __restrict__ status,
         uint32_t* __restrict__ list, unsigned long long* __restrict__ count) {
-    const int64_t blk0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t blk0 = (int64_t)blockIdx.x * kScreenBlock;
     const bool valid = blk0 + threadIdx.x < B;
     const unsigned b = valid ? threadIdx.x : (unsigned)(B - 1 - blk0);
     gradu += blk0; xi_prev += blk0; xi += blk0;
@@ -504,18 +508,27 @@ __global__ __launch_bounds__(kBlock) void k_screen(cm_model_desc m, int64_t B,
         if (sigma) store_soa<6>(sigma, B, b, sg);
         if (status) status[b] = CM_STATUS_CONVERGED;
     }
-    // append the plastic points of this wavefront: one atomic for the wavefront, ranks from the ballot
+    // append the workgroup's plastic points: ranks from the wave ballots, wave offsets through LDS, one atomic for the workgroup
+    __shared__ unsigned wave_n[kScreenBlock / 64];
+    __shared__ unsigned long long block_base;
     const bool take = valid && plastic0;
     const uint64_t mask = __ballot(take);
-    if (mask != 0ull) {
-        const int n = __popcll(mask);
-        unsigned long long base = 0ull;
-        if ((threadIdx.x & 63u) == 0u) base = atomicAdd(count, (unsigned long long)n);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+    const unsigned w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) wave_n[w] = (unsigned)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+#pragma unroll
+        for (int k = 0; k < kScreenBlock / 64; ++k) total += wave_n[k];
+        block_base = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    if (take) {
+        unsigned before = 0;
+        for (unsigned k = 0; k < w; ++k) before += wave_n[k];     // uniform per wavefront
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const unsigned long long at = (((unsigned long long)hi << 32) | lo) + (unsigned long long)rank;
-        if (take && at < (unsigned long long)B) list[at] = (uint32_t)(blk0 + threadIdx.x);     // (at < B always, for a counter that started at 0)
+        const unsigned long long at = block_base + before + (unsigned long long)rank;
+        if (at < (unsigned long long)B) list[at] = (uint32_t)(blk0 + threadIdx.x);        // (at < B always, for a counter that started at 0)
     }
 }
 // the list's length starts at zero: a one-thread kernel on the launch's stream (a kernel node under graph capture, like the work
@@ -1818,7 +1831,8 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
             hipLaunchKernelGGL(k_screen_reset, dim3(1), dim3(1), 0, s, count);
             const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
                 if constexpr (D == CM_FULL_3D && screen_pays<Y>()) {
-                    hipLaunchKernelGGL((k_screen<Y, R>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                    hipLaunchKernelGGL((k_screen<Y, R>), dim3((unsigned)((B + kScreenBlock - 1) / kScreenBlock)), dim3(kScreenBlock), 0, s,
+                                       md, B, gradu, xi_prev, xi, sigma, status, list, count);
                     hipLaunchKernelGGL((k_update_listed<Y, R, LS>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
                 }
             });

@@ -771,9 +771,18 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_hessian_history")
         return H
 
+    MAX_EXTENDED = 64          # kMaxEp in cmad_hip.hip: extended directions per second-order pass (the quadratic form's LDS tile)
+
+    def _check_extended(self, ep_index, what):
+        if len(ep_index) > self.MAX_EXTENDED:
+            raise NotImplementedError(f"{what}: {len(ep_index)} active leaves outside the 12 native kernel parameters; the second-order "
+                                      f"pass carries at most {self.MAX_EXTENDED} per evaluation (e.g. every weight of an ICNN [6, 16, 1] "
+                                      "is 135): activate a subset, or take gradients only (MPAdjointObjective has no such limit)")
+
     def direct_history_ep(self, ep_index, gradu_hist, xi_hist):
         """`cm_direct_history_ep`: forward sensitivities dxi_k/dp_e of the extended parameters over a stored history,
         (K+1, n_xi, n_ep, B) device tensor."""
+        self._check_extended(ep_index, "cm_direct_history_ep")
         torch = _torch()
         K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
         self._check_hist(gradu_hist, self.nu, K, B, "gradu_hist")
@@ -788,6 +797,7 @@ class DeviceEvaluator:
 
     def hessian_history_ep(self, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxi_dpe_hist, sigma_bar_hist, hss, hxx=None):
         """`cm_hessian_history_ep`: d2J/d[p, pe]2, (12 + n_ep, 12 + n_ep) device tensor (native parameters first, KP order)."""
+        self._check_extended(ep_index, "cm_hessian_history_ep")
         torch = _torch()
         K, B = gradu_hist.shape[0] - 1, gradu_hist.shape[2]
         ne = len(ep_index)
