@@ -2183,15 +2183,26 @@ int launch_hessian_history_ep(const cm_model_desc* m, int64_t B, int K, int n_ep
         const int64_t nthreads = nps * (int64_t)(nq * (nq + 1) / 2);
         const dim3 grid((unsigned)((nthreads + 63) / 64)), block(64);
         const size_t lds = (size_t)(nq * nq + nq * npt) * sizeof(double);
+        // The quadratic form's tile lives in dynamic LDS: (nq^2 + nq npt) doubles = 117 KB at n_ep = 64 (FULL_3D), above the 64 KB
+        // a kernel may use without asking.  Ask (gfx950 has 160 KB per CU); a device that refuses gets CM_ERR_UNSUPPORTED instead of
+        // a launch failure.
+        int dev = 0, lds_max = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); lds_max = 65536; }
+        bool lds_ok = true;
         const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
             if constexpr (!(MK == CM_SMALL_RATE_ELASTIC_PLASTIC && D == CM_UNIAXIAL_STRESS) && has_rate_dense<MK, Y>()) {
+                if (lds > 65536) {
+                    if (hipFuncSetAttribute((const void*)k_hessian_quadform_ep<nx_of<D, MK>()>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds) != hipSuccess) { (void)hipGetLastError(); lds_ok = false; return; }
+                } else if ((int64_t)lds > (int64_t)lds_max) { lds_ok = false; return; }
                 hipLaunchKernelGGL((k_hessian_weights_ep<D, CM_YIELD_ANY, kColdRot, MK>), grid, block, 0, s, md, B, K, n_ep, ep_index, gradu_hist,
                                    xi_hist, lam_hist, sbar_hist, h, hss_hist, hxx_hist, W);
                 hipLaunchKernelGGL((k_hessian_quadform_ep<nx_of<D, MK>()>), dim3((unsigned)nps), dim3(256), lds, s, B, K, n_ep, W, dx_dp_hist,
                                    dxe_hist, part);
             }
         });
-        if (!found) return CM_ERR_UNSUPPORTED;
+        if (!found || !lds_ok) return CM_ERR_UNSUPPORTED;
         if (check_launch() != CM_OK) return CM_ERR_LAUNCH;
     }
     cm_detail_sum_rows(s, part, nps, npt * npt, out);
@@ -2410,9 +2421,9 @@ int cm_update_and_vjp(const cm_model_desc* m, int64_t B, const double* gradu, co
                       void* workspace, int64_t workspace_bytes, void* stream) {
     if (!grad_p || !xi) return CM_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < reduce_workspace_bytes(B)) return CM_ERR_WORKSPACE;
-    if (pool_route(m, B) && gradu && xi_prev && sigma_bar) {
+    const int64_t rb = reduce_workspace_bytes(B);
+    if ((pool_route(m, B) || screen_route(m, B, (char*)workspace + rb, workspace_bytes - rb)) && gradu && xi_prev && sigma_bar) {
         // the update gets what the caller's workspace holds beyond the reduction's share (cm_workspace_bytes covers both)
-        const int64_t rb = reduce_workspace_bytes(B);
         const int rc = cm_update_ws(m, B, gradu, xi_prev, xi, sigma, nullptr, (char*)workspace + rb, workspace_bytes - rb, stream);
         return rc != CM_OK ? rc : cm_update_vjp(m, B, gradu, xi_prev, xi, sigma_bar, grad_p, nullptr, nullptr, workspace, workspace_bytes, stream);
     }
@@ -2591,8 +2602,9 @@ int cm_hessians_rate(const cm_model_desc* m, int64_t B, const double* gradu, con
 int cm_objective_grad(const cm_model_desc* m, int64_t B, const double* gradu, const double* xi_prev,
                       const double* data, const double* wsq6, double* out, double* xi,
                       void* workspace, int64_t workspace_bytes, void* stream) {
-    if (xi && pool_route(m, B) && gradu && xi_prev && data && out && workspace && workspace_bytes >= reduce_workspace_bytes(B)) {
-        const int64_t rb = reduce_workspace_bytes(B);
+    const int64_t rb = reduce_workspace_bytes(B);
+    if (xi && gradu && xi_prev && data && out && workspace && workspace_bytes >= rb &&
+        (pool_route(m, B) || screen_route(m, B, (char*)workspace + rb, workspace_bytes - rb))) {
         const int rc = cm_update_ws(m, B, gradu, xi_prev, xi, nullptr, nullptr, (char*)workspace + rb, workspace_bytes - rb, stream);   // needs somewhere to keep the states: only with xi
         return rc != CM_OK ? rc : cmi_objective_from_state(m, B, gradu, xi_prev, xi, data, wsq6, out, workspace, workspace_bytes, stream);
     }

@@ -90,7 +90,7 @@ class BatchedCalibrationObjective:
         out = self._out
         rate = getattr(model, "_model_kind", 0) == 1          # the rate form also takes the previous step's grad u
         prev = (lambda k: {"gradu_prev": g[k - 1]}) if rate else (lambda k: {})
-        pooled = (not rate) and ev.pool_route(self._B)
+        pooled = (not rate) and (ev.pool_route(self._B) or ev.screened(self._B))      # update kernel(s) + reverse kernel per step
         fused = (not pooled) if self._fused_history is None else bool(self._fused_history)
         if K == 1:
             # with a state buffer the entry point routes the iteration-bound configurations through the work pool

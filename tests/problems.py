@@ -57,7 +57,9 @@ def extended_leaf_problem(model_cls, yield_kind, active_rotation):
         # the input weights of the last layer and (deep) the weights between the hidden layers
         from cmad_amd.models import HybridHillEffectiveStress
         from cmad_amd.synthetic import al7079_hybrid_setup
-        icnn, values = al7079_hybrid_setup((6, 4, 3, 1) if yield_kind.endswith("deep") else (6, 5, 1))
+        # "network wide": 42 + 7 + 6 network entries + the rotation matrix = 64 extended directions, the second-order pass's limit
+        widths = (6, 4, 3, 1) if yield_kind.endswith("deep") else ((6, 7, 1) if yield_kind.endswith("wide") else (6, 5, 1))
+        icnn, values = al7079_hybrid_setup(widths)
         values = copy.deepcopy(values)
         values["plastic"]["flow stress"]["initial yield"]["Y"] = 200.0
         kw = {"effective_stress_fun": HybridHillEffectiveStress(icnn)}
@@ -76,11 +78,13 @@ def extended_leaf_problem(model_cls, yield_kind, active_rotation):
         flags["rotation matrix"] = True                        # an array leaf is active as a whole: nine entries
     if network:
         nn = flags["plastic"]["effective stress"]["neural network"]
-        flags["plastic"]["effective stress"]["hill"]["G"] = True
+        flags["plastic"]["effective stress"]["hill"]["G"] = not yield_kind.endswith("wide")     # (an extended leaf on this surface)
         nn["x params"][-1]["weights"] = True
         nn["x params"][0]["biases"] = True
         if nn["z params"][:-1]:
             nn["z params"][0]["weights"] = True
+        if yield_kind.endswith("wide"):
+            nn["x params"][0]["weights"] = True
     params = Parameters(values, flags, tree_map(lambda a: None, copy.deepcopy(values)))
     F = plane_stress_F(0.02, 3)
     model = model_cls(params, DefType.PLANE_STRESS, **kw)

@@ -975,6 +975,35 @@ def test_direct_adjoint_hessian_with_extended_leaves(yield_kind, active_rotation
 
 
 @pytest.mark.gpu
+def test_second_order_pass_at_its_extended_parameter_limit():
+    """64 active leaves outside the 12 native parameters (every input weight and bias of an ICNN [6, 7, 1], its pass-through
+    weights and the rotation matrix) -- the most `cm_hessian_history_ep` carries per evaluation: its quadratic form's tile is
+    117 KB of dynamic LDS, above what a kernel gets without asking (hipFuncSetAttribute).  Gradient = the adjoint gradient, the
+    Hessian is symmetric and three of its columns match central differences of the adjoint gradient; one leaf more raises a clear
+    NotImplementedError instead of a bare CM_ERR_BAD_ARG."""
+    from cmad_amd.objectives import MPAdjointObjective, MPDirectAdjointObjective
+    from problems import extended_leaf_problem
+    model, qoi, F = extended_leaf_problem(_models()[1], "network wide", True)
+    x = model.parameters.flat_active_values(True)
+    assert x.size == 1 + 64                                     # Y + 42 + 7 + 6 network entries + 9 rotation entries
+    J, grad, H = MPDirectAdjointObjective(qoi, F).evaluate(x)
+    ra = MPAdjointObjective(qoi, F).evaluate(x)
+    assert abs(J - ra.J) <= 1e-12 * abs(J)
+    np.testing.assert_allclose(grad, ra.grad, rtol=1e-9, atol=1e-11 * np.abs(ra.grad).max())
+    np.testing.assert_allclose(H, H.T, rtol=1e-8, atol=1e-9 * np.abs(H).max())
+    for k in (0, 7, x.size - 3):
+        h = 1e-5 * max(1.0, abs(x[k]))
+        xp_, xm_ = x.copy(), x.copy()
+        xp_[k] += h; xm_[k] -= h
+        col = (MPAdjointObjective(qoi, F).evaluate(xp_).grad - MPAdjointObjective(qoi, F).evaluate(xm_).grad) / (2 * h)
+        np.testing.assert_allclose(H[:, k], col, rtol=2e-4, atol=2e-5 * np.abs(H).max())
+    # one more array leaf (the z-layer's 7 weights): beyond the limit
+    ev = model.device_evaluator()
+    with pytest.raises(NotImplementedError):
+        ev._check_extended(list(range(65)), "cm_hessian_history_ep")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rate,scale_params", [(False, False), (True, True)])
 def test_complex_step_model_instances(rate, scale_params):
     """The reference's complex-step checks (tests/objectives/test_J2_fd_checks.py:301-386: SmallElasticPlastic unscaled,

@@ -270,7 +270,8 @@ def test_network_hardening_law_through_the_model_api():
     assert np.count_nonzero(np.abs(ra.grad) > 1e-9 * np.abs(ra.grad).max()) >= n - 1      # all but the output bias matter
 
 
-@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("network deep", False)])
+@pytest.mark.parametrize("yield_kind,active_rotation", [("hosford", False), ("hill", True), ("network deep", False),
+                                                        ("network wide", True)])      # (64 extended directions: the kernels' limit)
 def test_direct_adjoint_hessian_with_extended_leaves(yield_kind, active_rotation):
     """Second-order sensitivities w.r.t. leaves outside the 12 native kernel parameters -- the Hosford exponent, the nine
     entries of the rotation matrix -- together with a native one (Y): the reference takes Hessians over the whole params pytree

@@ -38,7 +38,8 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
     d = json.load(open(f))
     wl = d["tag"][len(tag) + 1:]
     bench = d.get("bench_trace.json", {})
-    kernels = {k: v for k, v in d["kernels"].items() if "reduce" not in k and "sum_rows" not in k}
+    kernels = {k: v for k, v in d["kernels"].items() if "reduce" not in k and "sum_rows" not in k and "k_screen_reset" not in k
+               and "k_pool_ticket_zero" not in k}            # (one-thread helper launches: microseconds, same grid at every batch size)
     # the workload's own kernel: the one with the most time that is not the 65536-point self-check launch
     main = max(kernels, key=lambda k: (kernels[k]["calls"], kernels[k]["avg_us"]))
     kv = kernels[main]
@@ -50,6 +51,8 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
     # a workload whose step is several kernels (work-pool update + tangent / reverse at the stored states): the roofline
     # fraction of the STEP divides the algorithmic bytes by the sum of their average durations, not by the dominant one's
     route = {short(k): v["avg_us"] for k, v in kernels.items() if v["calls"] == kv["calls"]}
+    if "k_reverse" in name:          # a fused kernel IS its step (the headline run also times the objective and two side variants)
+        route = {name: kv["avg_us"]}
     entry["step_kernels_us"] = route
     step_us = sum(route.values())
     if pts and bpu:
@@ -71,8 +74,18 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
             entry["active_lane_fraction"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             entry["hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+            # a step of several kernels (screened update: k_screen + k_update_listed; work pool + reverse): the step's traffic is
+            # the sum over its kernels
+            step_bytes = 0.0
+            for k in kernels:
+                if short(k) in route:
+                    fe = d.get("pmc_fetch", {}).get(k, {}).get("FETCH_SIZE", {}).get("mean", 0.0)
+                    wr = d.get("pmc_write", {}).get(k, {}).get("WRITE_SIZE", {}).get("mean", 0.0)
+                    step_bytes += fe * 1024 * 2 + wr * 1024
+            entry["step_hbm_bytes_per_launch"] = step_bytes
             if pts:
-                entry["hbm_bytes_per_point"] = entry["hbm_bytes_per_launch"] / pts
+                entry["hbm_bytes_per_point"] = step_bytes / pts
+                entry["dominant_kernel_hbm_bytes_per_point"] = entry["hbm_bytes_per_launch"] / pts
         if "SQ_INSTS_VALU_FMA_F64" in c:
             lanes = entry.get("active_lane_fraction", 1.0)
             flops = (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * lanes
