@@ -38,6 +38,7 @@ class ModelDesc(C.Structure):
         ("beta_equivalent_stress", C.c_double), ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double),
         ("beta_max_iters", C.c_int32), ("ls_kind", C.c_int32),
         ("hnn_width", C.c_int32), ("hnn_offset", C.c_int32),
+        ("hnn_nhidden", C.c_int32), ("hnn_widths", C.c_int32 * 4), ("reserved_tail", C.c_int32),
     ]
 
 

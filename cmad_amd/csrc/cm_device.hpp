@@ -1035,6 +1035,49 @@ CM_D HnnTerm hardening_network(const double* wv, int Hn, double alpha) {
     }
     return HnnTerm{so * acc, so * dacc};
 }
+// Widths [1, H1, ..., Hn, 1] with n >= 2 (cm_model_desc.hnn_nhidden, general weight layout: include/cmad_hip.h): the reference's
+// forward loops over any depth (simple_neural_network.py:19-23).  Forward pass carrying d/d alpha through the layers
+//   z = W^T a + b ,  a' = sigmoid(z) ,  da'/dalpha = sigmoid'(z) (W^T da/dalpha)
+// in two ping-pong arrays of kHnnMaxUnits entries (scratch-resident: correct, not fast -- an EXT-build feature like the deep
+// ICNN); forward(0) is the constant the host put behind the scales.
+constexpr int kHnnMaxHidden = 4, kHnnMaxUnits = 64;
+CM_D int hnn_general_size(const cm_model_desc& m) {           // doubles of the layers' weights and biases (scales follow)
+    int n = 0, nin = 1;
+    for (int l = 0; l < m.hnn_nhidden; ++l) { n += nin * m.hnn_widths[l] + m.hnn_widths[l]; nin = m.hnn_widths[l]; }
+    return n + nin + 1;
+}
+CM_D HnnTerm hardening_network_deep(const cm_model_desc& m, double alpha) {
+    const cm_uniform_ptr w = uniform_ptr(m.nn_weights + m.hnn_offset);
+    const int nh = m.hnn_nhidden, tail = hnn_general_size(m);
+    const double si = w[tail], so = w[tail + 1], f0 = w[tail + 2];
+    double a[2][kHnnMaxUnits], da[2][kHnnMaxUnits];
+    a[0][0] = si * alpha; da[0][0] = si;
+    int off = 0, nin = 1, cur = 0;
+    for (int l = 0; l < nh; ++l) {
+        const int nout = m.hnn_widths[l];
+        for (int o = 0; o < nout; ++o) {
+            double z = w[off + nin * nout + o], dz = 0.0;
+            for (int i = 0; i < nin; ++i) {
+                const double wio = w[off + i * nout + o];
+                z = __builtin_fma(wio, a[cur][i], z);
+                dz = __builtin_fma(wio, da[cur][i], dz);
+            }
+            const double e = exp_s(-fabs(z)), inv = rcp(1.0 + e);
+            const double sg = (z >= 0.0) ? inv : e * inv;
+            a[cur ^ 1][o] = sg;
+            da[cur ^ 1][o] = sg * (1.0 - sg) * dz;
+        }
+        off += nin * nout + nout;
+        nin = nout;
+        cur ^= 1;
+    }
+    double y = w[off + nin], dy = 0.0;                         // output layer: W[nin][1], b[1]
+    for (int i = 0; i < nin; ++i) {
+        y = __builtin_fma(w[off + i], a[cur][i], y);
+        dy = __builtin_fma(w[off + i], da[cur][i], dy);
+    }
+    return HnnTerm{so * (y - f0), so * dy};
+}
 CM_D Hard hardening(const cm_model_desc& m, double alpha) {
     Hard h; h.H = 0.0; h.dH = 0.0; h.expo = 0.0;
     if (m.has_voce) {
@@ -1045,7 +1088,8 @@ CM_D Hard hardening(const cm_model_desc& m, double alpha) {
     if (m.has_linear) { h.H += m.lin_K * alpha; h.dH += m.lin_K; }
     if constexpr (CM_HNN != 0) {
         if (m.hnn_width > 0) {                                  // uniform: the network hardening law, widths [1, H, 1] (cmad_hip.h)
-            const HnnTerm t = hardening_network(m.nn_weights + m.hnn_offset, m.hnn_width, alpha);
+            const HnnTerm t = (m.hnn_nhidden >= 2) ? hardening_network_deep(m, alpha)
+                                                   : hardening_network(m.nn_weights + m.hnn_offset, m.hnn_width, alpha);
             h.H += t.H;
             h.dH += t.dH;
         }

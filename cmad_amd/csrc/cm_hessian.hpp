@@ -217,7 +217,34 @@ CM_D T hardening_T(const cm_model_desc& m, const MatT<T>& p, const T& alpha) {
     T H = t_const<T>(0.0);
     if (m.has_voce) H = H + p.S * (1.0 - t_exp(-(p.D * alpha)));
     if (m.has_linear) H = H + p.K * alpha;
-    if (CM_HNN != 0 && m.hnn_width > 0) {                      // (only the HNN build of the library carries the law, cm_device.hpp)
+    if (CM_HNN != 0 && m.hnn_width > 0 && m.hnn_nhidden >= 2) {   // widths [1, H1, ..., Hn, 1]: cm::hardening_network_deep in arithmetic T
+        const int nh = m.hnn_nhidden, o = m.hnn_offset, tail = hnn_general_size(m);
+        const double si = p.nn[o + tail], so = p.nn[o + tail + 1];
+        auto sigmoid = [](const T& a) {
+            const bool pos = t_val(a) > 0.0;
+            const T e = t_exp(pos ? -a : a);
+            const T inv = 1.0 / (1.0 + e);
+            return pos ? inv : e * inv;
+        };
+        auto forward = [&](const T& x) {                       // every weight can carry the derivative direction (p.nn_at)
+            T a[2][kHnnMaxUnits];
+            a[0][0] = x;
+            int off = 0, nin = 1, cur = 0;
+            for (int l = 0; l < nh; ++l) {
+                const int nout = m.hnn_widths[l];
+                for (int v = 0; v < nout; ++v) {
+                    T z = p.nn_at(o + off + nin * nout + v);
+                    for (int i = 0; i < nin; ++i) z = z + p.nn_at(o + off + i * nout + v) * a[cur][i];
+                    a[cur ^ 1][v] = sigmoid(z);
+                }
+                off += nin * nout + nout; nin = nout; cur ^= 1;
+            }
+            T y = p.nn_at(o + off + nin);
+            for (int i = 0; i < nin; ++i) y = y + p.nn_at(o + off + i) * a[cur][i];
+            return y;
+        };
+        H = H + so * (forward(si * alpha) - forward(t_const<T>(0.0)));
+    } else if (CM_HNN != 0 && m.hnn_width > 0) {               // (only the HNN build of the library carries the law, cm_device.hpp)
         const int Hn = m.hnn_width, o = m.hnn_offset;
         const double si = p.nn[o + 3 * Hn + 1], so = p.nn[o + 3 * Hn + 2];
         auto sigmoid = [](const T& a) {

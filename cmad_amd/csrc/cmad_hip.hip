@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64, (min_waves_pool<DEF, YK>())) void k_update_pool
 #define CM_SCREEN 1
 #endif
 template <int YK>
-constexpr bool screen_pays() { return CM_SCREEN != 0 && (is_dense_yield(YK) || YK == CM_YIELD_HOSFORD); }
+constexpr bool screen_pays() { return CM_SCREEN != 0 && is_dense_yield(YK); }
 
 // 1024 lanes per workgroup: the append is ONE atomic per workgroup (wave counts summed through LDS).  All wavefronts of the grid
 // add to the same address, and the device serves about 80 M same-address atomics per second: one per wavefront -- 78 000 for
@@ -1603,15 +1603,21 @@ inline bool supported(const cm_model_desc* m, int model_kind = CM_SMALL_ELASTIC_
     if (m->def_type != CM_FULL_3D && m->def_type != CM_PLANE_STRESS && m->def_type != CM_UNIAXIAL_STRESS) return false;
     if (m->def_type == CM_UNIAXIAL_STRESS && (m->uniaxial_idx < 0 || m->uniaxial_idx > 2)) return false;
     if (m->hnn_width < 0 || (m->hnn_width > 0 && (!m->nn_weights || m->hnn_offset < 0))) return false;   // network hardening law
+    if (m->hnn_width > 0 && m->hnn_nhidden >= 2) {      // several hidden layers: the general forward pass (EXT build)
+        if (m->hnn_nhidden > kHnnMaxHidden || m->hnn_widths[0] != m->hnn_width) return false;
+        int units = 0;
+        for (int l = 0; l < m->hnn_nhidden; ++l) { if (m->hnn_widths[l] < 1) return false; units += m->hnn_widths[l]; }
+        if (units > kHnnMaxUnits) return false;
+    }
     // the EXT build: J2 / Hill / Hosford (+ the network hardening law) and the plain hybrid surface (+ multi-layer networks)
-    if (CM_HNN_VARIANT && is_dense_yield(m->yield_kind) && m->yield_kind != CM_YIELD_HYBRID_HILL_NN) return false;
+    if (CM_HNN_VARIANT && m->yield_kind == CM_YIELD_BARLAT) return false;      // (the EXT build: network features only)
     if (m->yield_kind == CM_YIELD_SCALED_HYBRID_HILL_NN && !(m->beta_equivalent_stress > 0.0 && m->beta_max_iters >= 0)) return false;
     if (is_nn_yield(m->yield_kind)) {                  // weights resident on the device
         if (!m->nn_weights || m->nn_widths[0] != 6) return false;
         if (m->nn_nlayers == 3)                        // one hidden layer [6, H, 1]: the fast evaluation (either build)
             return m->nn_widths[2] == 1 && m->nn_widths[1] >= 1 && m->nn_widths[1] <= 256;
         // more hidden layers: the general evaluation of the EXT build, plain hybrid surface only
-        if (!CM_HNN_VARIANT || m->yield_kind != CM_YIELD_HYBRID_HILL_NN || m->nn_nlayers < 3 || m->nn_nlayers > kIcnnMaxLayers) return false;
+        if (!CM_HNN_VARIANT || m->nn_nlayers < 3 || m->nn_nlayers > kIcnnMaxLayers) return false;
         int units = 0;
         for (int k = 1; k + 1 < m->nn_nlayers; ++k) { if (m->nn_widths[k] < 1) return false; units += m->nn_widths[k]; }
         return m->nn_widths[m->nn_nlayers - 1] == 1 && units <= kIcnnMaxUnits;
@@ -1686,9 +1692,9 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HOSFORD)
     CM_CASE(CM_FULL_3D, CM_YIELD_HYBRID_HILL_NN)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_HYBRID_HILL_NN)
-#if !CM_HNN_VARIANT                    // the EXT build leaves the other dense surfaces out (supported() refuses them there)
-    CM_CASE(CM_FULL_3D, CM_YIELD_SCALED_HYBRID_HILL_NN)
+    CM_CASE(CM_FULL_3D, CM_YIELD_SCALED_HYBRID_HILL_NN)      // (EXT build: with networks of several hidden layers, input_convex_neural_network.py:58-69)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
+#if !CM_HNN_VARIANT                    // the EXT build leaves Barlat out (supported() refuses it there)
     CM_CASE(CM_FULL_3D, CM_YIELD_BARLAT)
     CM_CASE(CM_PLANE_STRESS, CM_YIELD_BARLAT)
 #endif
@@ -1697,9 +1703,9 @@ inline bool dispatch(const cm_model_desc* m, F&& f) {
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HILL)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HOSFORD)
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_HYBRID_HILL_NN)
+        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
 #if !CM_HNN_VARIANT
         CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_BARLAT)
-        CM_CASE(CM_UNIAXIAL_STRESS, CM_YIELD_SCALED_HYBRID_HILL_NN)
 #endif
     }
 #undef CM_CASE
@@ -1796,7 +1802,9 @@ static inline bool screen_route(const cm_model_desc* m, int64_t B, const void* w
     if (!CM_SCREEN || off || !m || !ws || ws_bytes < screen_workspace_bytes(B) || ((uintptr_t)ws & 7)) return false;
     if (m->model_kind != CM_SMALL_ELASTIC_PLASTIC || m->def_type != CM_FULL_3D || (m->solver_flags & CM_SOLVER_LOCKSTEP)) return false;
     if (B < 4096 || B >= ((int64_t)1 << 29)) return false;      // 32-bit byte offsets into the rows
-    return is_dense_yield(m->yield_kind) || (m->yield_kind == CM_YIELD_HOSFORD && !hosford_warm_route(m));
+    // (Hosford on the reference's iteration stays on the work pool: its plastic points take 3 to 18 passes, and a lockstep
+    // wavefront over the list pays the maximum -- measured 2.63 ms screened against 1.39 ms on the pool, profiles/r04_sustained.txt)
+    return is_dense_yield(m->yield_kind);
 }
 
 template <bool TANGENT>

@@ -85,16 +85,16 @@ class HybridHillEffectiveStress:
     params["plastic"]["effective stress"]["neural network"] like the reference does.
     One hidden layer ([6, H, 1]) runs on the kernels' fast evaluation; more hidden layers ([6, H1, ..., Hn, 1], n <= 4,
     at most 64 hidden units) on the general one.  `ScaledHybridHillEffectiveStress` is the beta-rescaled variant
-    (`scaled_effective_stress`, :130-146; one hidden layer)."""
+    (`scaled_effective_stress`, :130-146), with the same networks."""
     yield_kind = 3
 
     def __init__(self, icnn):
         w = list(icnn.layer_widths)
         if len(w) < 3 or w[0] != 6 or w[-1] != 1:
             raise NotImplementedError("the HIP kernels evaluate ICNNs with layer widths [6, H1, ..., Hn, 1]")
-        if len(w) > 3 and (self.yield_kind != 3 or len(w) > 6 or sum(w[1:-1]) > 64):
-            raise NotImplementedError("networks with several hidden layers: plain hybrid surface, at most 4 hidden layers and "
-                                      "64 hidden units in all (general evaluation of the library's EXT build)")
+        if len(w) > 3 and (len(w) > 6 or sum(w[1:-1]) > 64):
+            raise NotImplementedError("networks with several hidden layers: at most 4 hidden layers and 64 hidden units in all "
+                                      "(general evaluation of the library's EXT build)")
         self.icnn = icnn
 
     def packed(self, values):
@@ -247,11 +247,20 @@ def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, 
         info["nn_packed"] = np.ascontiguousarray(packed, dtype=np.float64)   # the caller places it and sets d.nn_weights
     if "neural network" in hard:
         # the hardening network travels in the same device buffer, after the yield network's pack (if any)
-        from ..neural_networks.simple_neural_network import pack_hardening_network
-        Hn, hpack = pack_hardening_network(hard["neural network"], *hardening_nn)
+        from ..neural_networks.simple_neural_network import pack_hardening_network, pack_hardening_network_deep
         base = info.get("nn_packed", np.zeros(0))
+        if len(hard["neural network"]) == 2:                    # widths [1, H, 1]: the one-exponential-per-unit kernel loop
+            Hn, hpack = pack_hardening_network(hard["neural network"], *hardening_nn)
+            info["hnn"] = (int(Hn), int(base.size))
+        else:                                                   # [1, H1, ..., Hn, 1]: the general forward pass of the EXT build
+            hidden, hpack = pack_hardening_network_deep(hard["neural network"], *hardening_nn)
+            Hn = hidden[0]
+            d.hnn_nhidden = len(hidden)
+            for i, wdt in enumerate(hidden):
+                d.hnn_widths[i] = int(wdt)
+            info["hnn"] = (int(Hn), int(base.size))
+            info["hnn_hidden"] = [int(wdt) for wdt in hidden]
         d.hnn_width, d.hnn_offset = int(Hn), int(base.size)
-        info["hnn"] = (int(Hn), int(base.size))
         info["nn_packed"] = np.ascontiguousarray(np.concatenate([base, hpack]), dtype=np.float64)
     return d, info
 
@@ -314,6 +323,11 @@ def leaf_ep_index(path, info):
         ints = [k for k in path if isinstance(k, (int, np.integer))]
         layer, elem = int(ints[0]), (int(ints[-1]) if len(ints) > 1 else 0)
         what = names[-1]
+        if "hnn_hidden" in info:
+            # general layout: for every layer W[n_in][n_out] then b[n_out] (array leaves carry the flat element index)
+            sizes = [1] + info["hnn_hidden"] + [1]
+            loff = sum(sizes[l] * sizes[l + 1] + sizes[l + 1] for l in range(layer))
+            return EP_NN0 + off + loff + (elem if what == "weights" else sizes[layer] * sizes[layer + 1] + elem)
         if layer == 0:
             return EP_NN0 + off + (elem if what == "weights" else Hn + elem)
         return EP_NN0 + off + (2 * Hn + elem if what == "weights" else 3 * Hn)
@@ -426,13 +440,13 @@ class DeviceEvaluator:
 
     def screened(self, B):
         """True when `cm_update_ws` runs this configuration screened (k_screen + k_update_listed; `screen_route` in
-        cmad_hip.hip): FULL_3D, total form, the network surfaces / Barlat / Hosford on the reference's iteration, 4096 <= B < 2^29."""
+        cmad_hip.hip): FULL_3D, total form, the network surfaces and Barlat, 4096 <= B < 2^29."""
         d = self.desc
         if d.model_kind != 0 or d.def_type != 0 or (d.solver_flags & _lib.SOLVER_LOCKSTEP) or not (4096 <= B < 2 ** 29):
             return False
         if os.environ.get("CM_DEBUG_NO_SCREEN", "0") not in ("", "0"):
             return False
-        return d.yield_kind in (3, 4, 5) or (d.yield_kind == YIELD_KINDS["hosford"] and self.pool_route(B))
+        return d.yield_kind in (3, 4, 5)
 
     def _update_workspace(self, B, device):
         """(workspace, bytes) for cm_update_ws: the evaluator's per-stream workspace when the screened route applies, else none

@@ -81,7 +81,7 @@ def pack_hardening_network(nn_params, input_scale, output_scale):
     """Device layout of a [1, H, 1] hardening network (include/cmad_hip.h, hnn_width): W1[H], b1[H], W2[H], b2, in_scale,
     out_scale, then sigmoid(b1[u]) (what forward(0) needs, constant over the points).  Returns (H, packed)."""
     if len(nn_params) != 2:
-        raise NotImplementedError("the HIP kernels evaluate hardening networks with one hidden layer ([1, H, 1])")
+        raise ValueError("pack_hardening_network: one hidden layer; pack_hardening_network_deep handles [1, H1, ..., Hn, 1]")
     W1 = np.asarray(nn_params[0]["weights"], dtype=np.float64)
     b1 = np.asarray(nn_params[0]["biases"], dtype=np.float64).ravel()
     W2 = np.asarray(nn_params[1]["weights"], dtype=np.float64)
@@ -90,3 +90,26 @@ def pack_hardening_network(nn_params, input_scale, output_scale):
     if W1.shape != (1, H) or W2.shape != (H, 1) or b2.size != 1:
         raise NotImplementedError(f"hardening network layer shapes {W1.shape}, {W2.shape}: expected (1, H) and (H, 1)")
     return H, np.concatenate([W1.ravel(), b1, W2.ravel(), b2, [input_scale, output_scale], sigmoid(b1)])
+
+
+MAX_HIDDEN_LAYERS, MAX_HIDDEN_UNITS = 4, 64        # kHnnMaxHidden / kHnnMaxUnits of cmad_amd/csrc/cm_device.hpp
+
+
+def pack_hardening_network_deep(nn_params, input_scale, output_scale):
+    """Device layout of a hardening network with several hidden layers, widths [1, H1, ..., Hn, 1] (include/cmad_hip.h,
+    hnn_nhidden >= 2): for every layer W[n_in][n_out] (row-major, as stored) and b[n_out]; then in_scale, out_scale and
+    forward(0), the constant `forward_with_offset` subtracts.  Returns ([H1, ..., Hn], packed)."""
+    widths = [int(np.asarray(layer["biases"]).size) for layer in nn_params[:-1]]
+    if not (2 <= len(widths) <= MAX_HIDDEN_LAYERS) or sum(widths) > MAX_HIDDEN_UNITS:
+        raise NotImplementedError(f"hardening network with hidden widths {widths}: the kernels evaluate 1 to {MAX_HIDDEN_LAYERS} "
+                                  f"hidden layers with at most {MAX_HIDDEN_UNITS} hidden units in all")
+    n_in, parts = 1, []
+    for layer, n_out in zip(nn_params, widths + [1]):
+        W = np.asarray(layer["weights"], dtype=np.float64)
+        b = np.asarray(layer["biases"], dtype=np.float64).ravel()
+        if W.shape != (n_in, n_out) or b.size != n_out:
+            raise NotImplementedError(f"hardening network layer shapes {W.shape} / {b.shape}: expected ({n_in}, {n_out}) / ({n_out},)")
+        parts += [W.ravel(), b]
+        n_in = n_out
+    f0 = float(np.asarray(forward(np.zeros(1), nn_params)).ravel()[0])
+    return widths, np.concatenate(parts + [[input_scale, output_scale, f0]])

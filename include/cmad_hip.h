@@ -154,6 +154,14 @@ typedef struct cm_model_desc {
      * Added to the Voce / linear terms when those are present as well. */
     int32_t hnn_width;
     int32_t hnn_offset;
+    /* more than one hidden layer: widths [1, H1, ..., Hn, 1], forward (simple_neural_network.py:19-23) loops over any depth.
+     * hnn_nhidden = n (0 or 1: the one-hidden-layer layout above with H = hnn_width), 2 <= n <= 4 with at most 64 hidden units
+     * in all: hnn_widths[0 .. n-1] = H1 .. Hn, hnn_width = H1, and the weights at hnn_offset in the GENERAL layout
+     *   for l = 0 .. n:  W_l[n_in][n_out] (row-major, as params[l]["weights"]), b_l[n_out]        (n_in / n_out = 1, H1, ..., Hn, 1)
+     *   then in_scale, out_scale, forward(0)                                                          (forward(0): host-computed). */
+    int32_t hnn_nhidden;
+    int32_t hnn_widths[4];
+    int32_t reserved_tail;      /* keeps sizeof a multiple of 8 */
 } cm_model_desc;
 
 /* library / build info */
@@ -181,7 +189,7 @@ int cm_update(const cm_model_desc* m, int64_t B,
  * cm_update_ws / cm_update_tangent_ws: cm_update / cm_update_tangent with a caller-provided device workspace of at least
  * cm_update_workspace_bytes(B) bytes (8-byte aligned; contents need not be preserved between calls; one workspace per stream).
  * Same results.  With it the configurations whose residual evaluation is expensive (FULL_3D, total form: the network
- * surfaces, Barlat, Hosford on the reference's iteration) run SCREENED instead of on the work pool: a streaming kernel
+ * surfaces, Barlat; B >= 4096) run SCREENED instead of on the work pool / in lockstep: a streaming kernel
  * finishes the points whose trial state is elastic (cond_residual's elastic branch at x_prev: C = 0, no iteration) and lists the
  * others; the lockstep Newton then runs over the list, so every lane of every wavefront holds a plastic point.  Without a
  * workspace (NULL / too small), or for any other configuration, these are cm_update / cm_update_tangent.  The fused entry points

@@ -38,7 +38,8 @@ class Desc(C.Structure):
                 ("nn_nlayers", C.c_int), ("nn_widths", C.c_int * 8), ("nn_w", C.POINTER(C.c_double)),
                 ("beta_equivalent_stress", C.c_double), ("beta_max_iters", C.c_int),
                 ("beta_abs_tol", C.c_double), ("beta_rel_tol", C.c_double), ("barlat", C.c_double * 19),
-                ("hnn_width", C.c_int), ("hnn_w", C.POINTER(C.c_double))]
+                ("hnn_width", C.c_int), ("hnn_w", C.POINTER(C.c_double)),
+                ("hnn_nhidden", C.c_int), ("hnn_widths", C.c_int * 4)]
 
 
 class Newton(C.Structure):
@@ -170,7 +171,8 @@ class Material:
         """nn = (layer_widths, packed weights) selects the hybrid Hill + ICNN surface; scaled = (equivalent_stress,
         max_iters, abs_tol, rel_tol) wraps it in `scaled_effective_stress` (effective_stress.py:97-146);
         hardening_nn = (H, packed [W1[H], b1[H], W2[H], b2, in_scale, out_scale]) adds the network hardening law
-        (simple_neural_network.py:13-46 as hardening_funs["neural network"])."""
+        (simple_neural_network.py:13-46 as hardening_funs["neural network"]); ([H1, ..., Hn], packed [W_l, b_l for every layer,
+        in_scale, out_scale]) the same with several hidden layers."""
         self.values = values
         p = np.zeros(NP)
         p[P_Q:P_Q + 9] = np.asarray(values.get("rotation matrix", np.eye(3)), dtype=float).reshape(9)
@@ -206,9 +208,15 @@ class Material:
                          yield_tol, 0, (C.c_int * 8)(), None)
         self._hnn_keep = None
         if hardening_nn is not None:
-            Hn, hp = hardening_nn
+            Hn, hp = hardening_nn                       # H (widths [1, H, 1]) or the list of hidden widths [H1, ..., Hn], n >= 2
             self._hnn_keep = f64(hp)
-            self.desc.hnn_width = int(Hn)
+            if isinstance(Hn, (list, tuple)):
+                assert 2 <= len(Hn) <= 4
+                self.desc.hnn_width, self.desc.hnn_nhidden = int(Hn[0]), len(Hn)
+                for i, wdt in enumerate(Hn):
+                    self.desc.hnn_widths[i] = int(wdt)
+            else:
+                self.desc.hnn_width = int(Hn)
             self.desc.hnn_w = _p(self._hnn_keep)
         self._nn_keep = None
         if nn is not None:

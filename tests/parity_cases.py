@@ -666,11 +666,13 @@ def check_legacy_line_search(backend, def_type=ol.FULL_3D, yield_kind="hosford",
         assert np.mean(it_d == it_o) > 0.97, np.bincount(np.abs(it_d - it_o))
 
 
-def nn_hardening_values(H=5, with_voce=False, seed=4):
+def nn_hardening_values(H=5, with_voce=False, seed=4, hidden=None):
     """J2 + the network hardening law of examples/noisy_calibration.py:245-252 (SimpleNeuralNetwork [1, H, 1], input_scale 2,
-    output_scale 1e2), weights perturbed off the constant-bias initialisation: (values, network, packed [W1, b1, W2, b2, si, so])."""
+    output_scale 1e2), weights perturbed off the constant-bias initialisation: (values, network, packed [W1, b1, W2, b2, si, so]).
+    hidden = [H1, ..., Hn]: several hidden layers (the reference's forward loops over any depth, simple_neural_network.py:19-23);
+    packed is then every layer's W, b in order, then si, so."""
     from cmad_amd.neural_networks import SimpleNeuralNetwork
-    net = SimpleNeuralNetwork([1, H, 1], input_scale=2., output_scale=1e2)
+    net = SimpleNeuralNetwork([1] + list(hidden) + [1] if hidden else [1, H, 1], input_scale=2., output_scale=1e2)
     rng = np.random.default_rng(seed)
     for layer in net.params:
         layer["weights"] = layer["weights"] * rng.uniform(0.6, 1.6, size=layer["weights"].shape) * 6.0
@@ -680,29 +682,30 @@ def nn_hardening_values(H=5, with_voce=False, seed=4):
     if with_voce:
         hard = {"voce": {"S": 120., "D": 15.}, "neural network": net.params}
     values["plastic"]["flow stress"]["hardening"] = hard
-    packed = np.concatenate([net.params[0]["weights"].ravel(), net.params[0]["biases"], net.params[1]["weights"].ravel(),
-                             net.params[1]["biases"], [net.input_scale, net.output_scale]])
+    packed = np.concatenate([a for layer in net.params for a in (layer["weights"].ravel(), layer["biases"].ravel())] +
+                            [[net.input_scale, net.output_scale]])
     return values, net, packed
 
 
-def check_nn_hardening(backend, param_blocks, def_type=ol.FULL_3D, with_voce=False, B=512):
+def check_nn_hardening(backend, param_blocks, def_type=ol.FULL_3D, with_voce=False, B=512, hidden=None):
     """The network hardening law (cmad/neural_networks/simple_neural_network.py:13-46 as hardening_funs["neural network"],
     cmad/models/small_elastic_plastic.py:115) in the hand-derived kernels -- update over two load steps (states, stresses,
     iteration counts), reverse sweep (cotangents; gradient w.r.t. E, nu, Y) -- against the oracle, and the sensitivities
     w.r.t. every network weight (cm_param_blocks: forward-mode evaluation) against central differences of the oracle."""
     from cmad_amd.models.device import EP_NN0, NewtonSettings, build_desc, kp_to_leaf_grad
     from cmad_amd.synthetic import gauss_point_batch
-    values, net, packed = nn_hardening_values(with_voce=with_voce)
+    values, net, packed = nn_hardening_values(with_voce=with_voce, hidden=hidden)
     Hn = net.layer_widths[1]
+    onn = (list(hidden), packed) if hidden else (Hn, packed)          # oracle: widths [1, H, 1] or the list of hidden widths
 
     class S:
         pass
     sc = S()
     sc.values = values
-    sc.mat = ol.Material(values, def_type=def_type, hardening_nn=(Hn, packed))
+    sc.mat = ol.Material(values, def_type=def_type, hardening_nn=onn)
     sc.st_o, sc.st_d = settings_pair(False)
     sc.desc, sc.info = build_desc(values, def_type=def_type, newton=sc.st_d, hardening_nn=(net.input_scale, net.output_scale))
-    assert sc.desc.hnn_width == Hn and sc.info["hnn"] == (Hn, 0)
+    assert sc.desc.hnn_width == Hn and sc.info["hnn"] == (Hn, 0) and sc.desc.hnn_nhidden == (len(hidden) if hidden else 0)
     nd = 3 if def_type == ol.FULL_3D else 2
     g0 = gauss_point_batch(B, seed=22, skew=True, ndims=nd)
     g1 = gauss_point_batch(B, seed=23, skew=True, ndims=nd)
@@ -726,20 +729,23 @@ def check_nn_hardening(backend, param_blocks, def_type=ol.FULL_3D, with_voce=Fal
     b = int(np.argmax(sc.xi2[6] - sc.xi1[6]))
     xi_mid = 0.5 * (sc.xi1 + sc.xi2)
     assert sc.mat.yield_state(xi_mid[:, b], sc.gradu[:, b])[1] > 1e-6
-    nw = 3 * Hn + 1
+    nw = packed.size - 2                                             # every weight and bias (the two scales follow them)
     ep = [EP_NN0 + i for i in range(nw)]
     if "nn_packed" in sc.info:
         sc.desc.nn_weights = sc.info["nn_packed"].ctypes.data           # host build reads host memory; the GPU wrapper re-places it
     dC, dS = param_blocks(sc.desc, ep, sc.gradu[:, b:b + 1], sc.xi1[:, b:b + 1], xi_mid[:, b:b + 1], sc.mat.nx, info=sc.info)
     assert not dS.any()                                              # the stress does not see the hardening law
     for i in range(nw):
-        h = 1e-6 * max(1.0, abs(packed[i]))
+        # (several sigmoid layers in a row make the sensitivities small against the residual's own magnitude: a wider step keeps
+        # the round-off of the difference quotient below them)
+        h = (1e-4 if hidden else 1e-6) * max(1.0, abs(packed[i]))
         wp, wm = packed.copy(), packed.copy()
         wp[i] += h; wm[i] -= h
-        Cp = ol.Material(values, def_type=def_type, hardening_nn=(Hn, wp)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
-        Cm = ol.Material(values, def_type=def_type, hardening_nn=(Hn, wm)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
+        Cp = ol.Material(values, def_type=def_type, hardening_nn=(onn[0], wp)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
+        Cm = ol.Material(values, def_type=def_type, hardening_nn=(onn[0], wm)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
         fd = (Cp - Cm) / (2 * h)
-        np.testing.assert_allclose(dC[i, :, 0], fd, rtol=2e-6, atol=1e-7 * np.abs(dC).max(), err_msg=f"weight {i}")
+        np.testing.assert_allclose(dC[i, :, 0], fd, rtol=1e-5 if hidden else 2e-6, atol=max((2e-6 if hidden else 1e-7) * np.abs(dC).max(), 2e-14 if hidden else 0.0),     # (2e-14: the quotient's round-off floor)
+                                   err_msg=f"weight {i}")
     assert np.abs(dC[:, 6, 0]).max() > 0                             # ... and they are not all zero: the yield row sees every weight
 
 

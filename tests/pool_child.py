@@ -30,6 +30,12 @@ def evaluator(surface):
         nt = NewtonSettings.traced(max_iters=500, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 100})
         nt.j2_radial_line = False
         return DeviceEvaluator(*build_desc(values, newton=nt)), (values, None), 2e-3, dict(max_iters=500, ls_max_evals=100)
+    if surface == "barlat":                     # Yld2004-18p, Al7079 coefficients, a = 8 (screened route only: never on the pool)
+        import parity_cases as pc
+        import oracle_lib as ol
+        values = ol.j2_voce_values(yield_kind="barlat", barlat=pc.AL7079_BARLAT[:18] + [8.0])
+        nt = NewtonSettings.traced(max_iters=20, abs_tol=1e-12, rel_tol=1e-12)
+        return DeviceEvaluator(*build_desc(values, newton=nt)), (values, None), 1e-3, dict(max_iters=20, ls_max_evals=4)
     icnn, values = al7079_hybrid_setup()
     nt = NewtonSettings.traced(max_iters=50, abs_tol=1e-12, rel_tol=1e-12, line_search_settings={"max evals": 10})
     return (DeviceEvaluator(*build_desc(values, newton=nt, hybrid=HybridHillEffectiveStress(icnn))), (values, icnn), 525.0 / 70.2e3,
@@ -84,7 +90,7 @@ def main():
     surface, case, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
     from cmad_amd.synthetic import gauss_point_batch
     ev, values, eps_y, settings = evaluator(surface)
-    assert ev.pool_route(B), "configuration is not on the work-pool route"
+    assert ev.pool_route(B) or ev.screened(B), "configuration is on neither the work-pool nor the screened route"
     g_host = gauss_point_batch(B, seed=77, eps_y=eps_y)
     gradu = torch.from_numpy(g_host).cuda()
     xi_prev = torch.zeros((7, B), **F64)

@@ -905,8 +905,10 @@ def test_direct_adjoint_hessian_of_the_uniaxial_calibration_qoi():
     assert np.isfinite(qoi.d2J_dxi_dparams).all() and np.isfinite(qoi.d2J_dparams2).all()
 
 
-def test_network_hardening_law_through_the_model_api():
+@pytest.mark.parametrize("hidden", [None, [4, 3]])
+def test_network_hardening_law_through_the_model_api(hidden):
     """`SmallElasticPlastic(parameters, def_type, hardening_funs={"neural network": SimpleNeuralNetwork([1, 5, 1], ...).evaluate})`
+    (and widths [1, 4, 3, 1]: the reference's forward loops over any depth, simple_neural_network.py:19-23)
     as examples/noisy_calibration.py:245-252 builds it: the adjoint and the direct objective agree, and the gradient w.r.t.
     the initial yield and EVERY network weight and bias (active leaves of the params pytree) matches central differences."""
     import copy
@@ -916,7 +918,7 @@ def test_network_hardening_law_through_the_model_api():
     from cmad_amd.parameters.parameters import tree_map
     from cmad_amd.qois import Calibration
     import parity_cases as pc
-    values, net, _ = pc.nn_hardening_values()
+    values, net, _ = pc.nn_hardening_values(hidden=hidden)
     flags = tree_map(lambda a: False, copy.deepcopy(values))
     flags["plastic"]["flow stress"] = tree_map(lambda a: True, flags["plastic"]["flow stress"])
     params = Parameters(values, flags, tree_map(lambda a: None, copy.deepcopy(values)))
@@ -928,17 +930,18 @@ def test_network_hardening_law_through_the_model_api():
     qoi = Calibration(model, cauchy + np.random.default_rng(3).normal(0., 2., cauchy.shape), weight)
     x = 1.05 * model.parameters.flat_active_values(True)
     n = x.size
-    assert n == 1 + 3 * 5 + 1                                       # Y, W1[5], b1[5], W2[5], b2
+    assert n == (1 + 3 * 5 + 1 if hidden is None else 1 + (4 + 4) + (12 + 3) + (3 + 1))    # Y, then every weight and bias
     ra = MPAdjointObjective(qoi, F).evaluate(x)
     rd = MPDirectObjective(qoi, F).evaluate(x)
     assert abs(ra.J - rd.J) <= 1e-12 * abs(ra.J)
     np.testing.assert_allclose(rd.grad, ra.grad, rtol=1e-8, atol=1e-10 * np.abs(ra.grad).max())
     for k in range(n):
-        h = 1e-6 * max(1.0, abs(x[k]))
+        h = (1e-5 if hidden else 1e-6) * max(1.0, abs(x[k]))        # (small sensitivities through several sigmoid layers: wider step)
         xp_, xm_ = x.copy(), x.copy()
         xp_[k] += h; xm_[k] -= h
         fd = (MPAdjointObjective(qoi, F).evaluate(xp_).J - MPAdjointObjective(qoi, F).evaluate(xm_).J) / (2 * h)
-        np.testing.assert_allclose(ra.grad[k], fd, rtol=5e-5, atol=1e-7 * np.abs(ra.grad).max(), err_msg=f"active parameter {k}")
+        np.testing.assert_allclose(ra.grad[k], fd, rtol=2e-4 if hidden else 5e-5, atol=(1e-6 if hidden else 1e-7) * np.abs(ra.grad).max(),
+                                   err_msg=f"active parameter {k}")
     assert np.count_nonzero(np.abs(ra.grad) > 1e-9 * np.abs(ra.grad).max()) >= n - 1      # all but the output bias matter
     # the rate-form model, as the reference's example uses the law
     rmodel = SmallRateElasticPlastic(params, DefType.PLANE_STRESS, hardening_funs={"neural network": net.evaluate})

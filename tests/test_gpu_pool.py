@@ -65,18 +65,19 @@ def test_replayed_graph_overlapping_eager_launches_on_other_streams(surface, slo
     child(surface, "streams", 150_000, **env)
 
 
-# ---- the screened route (cm_update_ws: k_screen + k_update_listed) through the same child: completeness on sentinel-prefilled
-# outputs and launch-size independence, graph capture (a private workspace per captured launch), streams (one per stream)
-@pytest.mark.parametrize("surface,B", [("hosford", 5_000_001), ("hybrid", 4_200_000)])
+# ---- the screened route (cm_update_ws: k_screen + k_update_listed; the network surfaces and Barlat) through the same child:
+# completeness on sentinel-prefilled outputs and launch-size independence, graph capture (a private workspace per captured
+# launch), streams (one workspace per stream)
+@pytest.mark.parametrize("surface,B", [("hybrid", 4_200_000), ("barlat", 1_000_001)])
 def test_screened_route_writes_every_point(surface, B):
     child(surface, "complete", B, screened=True)
 
 
-@pytest.mark.parametrize("surface,B", [("hosford", 1_000_000), ("hybrid", 600_000)])
+@pytest.mark.parametrize("surface,B", [("hybrid", 600_000), ("barlat", 300_000)])
 def test_screened_route_under_graph_capture(surface, B):
     child(surface, "graph", B, screened=True)
 
 
-@pytest.mark.parametrize("surface", ["hosford", "hybrid"])
+@pytest.mark.parametrize("surface", ["hybrid", "barlat"])
 def test_screened_route_on_overlapping_streams(surface):
     child(surface, "streams", 150_000, screened=True)

@@ -97,6 +97,13 @@ def test_hybrid_hill_multi_layer_icnn(backend, def_type, widths):
     pc.check_hybrid_nn(backend, def_type, B=1024, rot=(def_type == ol.FULL_3D), widths=widths)
 
 
+@pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
+def test_scaled_hybrid_with_a_multi_layer_icnn(backend, def_type):
+    """`scaled_effective_stress` around a network with two hidden layers: the reference composes any ICNN with the beta-rescaling
+    (input_convex_neural_network.py:58-69 under effective_stress.py:130-146); EXT build of the library."""
+    pc.check_hybrid_nn(backend, def_type, B=768, rot=(def_type == ol.FULL_3D), scaled=True, widths=(6, 7, 5, 1))
+
+
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("yield_kind", ["J2", "hill", "hosford"])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
@@ -720,14 +727,15 @@ def test_j2_voce_analytical_golden(golden_dir, model_kind, def_type, yield_kind)
         assert np.linalg.norm(cauchy[:, :, 1:] - stress) < 1e-6
 
 
+@pytest.mark.parametrize("hidden", [None, [4, 3], [3, 2, 4]])       # widths [1, 5, 1] / [1, 4, 3, 1] / [1, 3, 2, 4, 1]
 @pytest.mark.parametrize("with_voce", [False, True])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
-def test_network_hardening_law(backend, def_type, with_voce):
+def test_network_hardening_law(backend, def_type, with_voce, hidden):
     """hardening_funs = {"neural network": SimpleNeuralNetwork([1, H, 1]).evaluate} (cmad/models/small_elastic_plastic.py:115,
     cmad/neural_networks/simple_neural_network.py:13-46): update, reverse sweep and weight sensitivities through the C-ABI
     against the oracle; also on the J2 subspace kernels (the default for J2) and the general path."""
     import gpu_api
-    pc.check_nn_hardening(backend, gpu_api.param_blocks, def_type, with_voce=with_voce, B=1500)
+    pc.check_nn_hardening(backend, gpu_api.param_blocks, def_type, with_voce=with_voce, B=1500, hidden=hidden)
 
 
 @pytest.mark.parametrize("surface", ["hybrid", "scaled hybrid", "barlat", "hosford reference iteration"])

@@ -583,15 +583,16 @@ def test_rate_form_with_a_dense_yield_surface(def_type, solver_variant):
                                       def_type, yk, kw, rate=True)
 
 
+@pytest.mark.parametrize("hidden", [None, [4, 3], [3, 2, 4]])
 @pytest.mark.parametrize("with_voce", [False, True])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])
-def test_network_hardening_law(def_type, with_voce, solver_variant):
+def test_network_hardening_law(def_type, with_voce, hidden, solver_variant):
     import host_harness_lib as hh
     if def_type == ol.UNIAXIAL_STRESS and solver_variant != "structured":
         pytest.skip("one solver form under UNIAXIAL_STRESS")
     if def_type == ol.UNIAXIAL_STRESS:
         pytest.skip("covered through the facade")
-    pc.check_nn_hardening(BACKEND, hh.param_blocks, def_type, with_voce=with_voce, B=192)
+    pc.check_nn_hardening(BACKEND, hh.param_blocks, def_type, with_voce=with_voce, B=192, hidden=hidden)
 
 
 DEEP = (6, 7, 5, 1)            # two hidden layers (the reference's forward loops over any number, input_convex_neural_network.py:58-69)
@@ -605,6 +606,7 @@ def test_hybrid_surface_with_a_multi_layer_network(def_type, solver_variant):
     second derivatives against the oracle's nested duals."""
     import host_harness_lib as hh
     pc.check_hybrid_nn(BACKEND, def_type, B=96, rot=(def_type == ol.PLANE_STRESS), widths=DEEP)
+    pc.check_hybrid_nn(BACKEND, def_type, B=64, rot=(def_type == ol.PLANE_STRESS), widths=DEEP, scaled=True)     # beta-rescaled around it
     if solver_variant == "structured":
         pc.check_param_blocks_network(hh.param_blocks, def_type, layer_widths=DEEP)
         pc.check_second_derivs_network(hh.hessians, def_type, layer_widths=DEEP)

@@ -20,3 +20,9 @@ run --workload hosford_update
 run --workload hybrid_update --points 5000000
 run --workload j2_update_vjp --yield-surface barlat8 --points 2000000
 run --workload j2_update --def-type uniaxial_stress --points 2000000
+run --workload j2_update_vjp --def-type plane_stress --reference-iterates
+run --workload j2_objective_grad --def-type plane_stress --reference-iterates
+run --workload j2_update_vjp --yield-surface hill --reference-iterates
+run --workload hosford_update --general-newton
+run --workload hosford_update_vjp
+run --workload hybrid_update_vjp --points 5000000
