@@ -1657,6 +1657,65 @@ CM_D double ls_trial_legacy(const cm_model_desc& m, double phi, double cc, doubl
 // Returns the status word.
 // FAST: UNIAXIAL_STRESS, total form: the step through uniaxial_solve (4 x 4) instead of the 9 x 9 LU (same delta).  The kernels
 // always use it; FAST = false is the dense reference path of the host tests.  No effect on the other configurations.
+// UNIAXIAL_STRESS with a quadratic surface (J2, Hill): the 1-d return map as warm start (include/cmad_hip.h "Warm starts";
+// CM_SOLVER_REFERENCE_ITERATES / CM_SOLVER_GENERAL_NEWTON opt out).  The elastic strain is e = sum_i c_i Z^i in the frame dyads
+// (strain_stress), so with isotropic elasticity and the two lateral constraint rows the stress at the solution is sigma_0 Z^0:
+//     c_1 = c_2 = -nu c_0 ,  sigma_0 = E c_0 ,  phi = h0 |sigma_0| ,  h0^2 = Z^0 . A Z^0 ,  n = sgn(sigma_0) N ,  N_k = (A Z^0)_k / (h0 w_k)
+// a CONSTANT flow direction, whose projections on the dyads are nu_i = Z^i . A Z^0 / h0 (nu_0 = h0).  One scalar equation
+//     F(dgam) = h0 E (|c_0,trial| - h0 dgam) - Y - H(alpha_prev + dgam) = 0        (linear in dgam but for the hardening law)
+// and the state follows: v = v_prev + dgam sgn N, alpha, x_7 = 1 + tau_1 + c_1, x_8 = 1 + tau_2 + c_2 (tau_i = (w o Z^i) . v).
+// Returns true when x0 holds a warm start.  `plastic_prev`: the branch the reference's first iterate takes at x_prev (with the OLD
+// stretches): a point plastic there but elastic once the stretches relax has two roots of the residual (cf. newton_j2_plane) and
+// is left to the reference's iteration.
+template <int YK>
+CM_D bool uniaxial_warm_start(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, bool plastic_prev,
+                              bool active, double* x0) {
+    static_assert(YK == CM_YIELD_J2 || YK == CM_YIELD_HILL, "quadratic surfaces");
+    const QuadForm q = quad_form<YK>(m);
+    const double* Z0 = z;
+    double AZ[6];
+    AZ[0] = q.a00 * Z0[0] + q.a03 * Z0[3] + q.a05 * Z0[5];
+    AZ[3] = q.a03 * Z0[0] + q.a33 * Z0[3] + q.a35 * Z0[5];
+    AZ[5] = q.a05 * Z0[0] + q.a35 * Z0[3] + q.a55 * Z0[5];
+    AZ[1] = q.a11 * Z0[1]; AZ[2] = q.a22 * Z0[2]; AZ[4] = q.a44 * Z0[4];
+    double h2 = 0.0, n1 = 0.0, n2 = 0.0, c0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        h2 += Z0[k] * AZ[k]; n1 += z[6 + k] * AZ[k]; n2 += z[12 + k] * AZ[k];
+        c0 += kW[k] * Z0[k] * (eg[k] - xp[k]);                   // c_0 at x_prev: axial strain minus tau_0
+        t1 += kW[k] * z[6 + k] * xp[k]; t2 += kW[k] * z[12 + k] * xp[k];
+    }
+    if (!(h2 > 0.0)) return false;
+    const double h0 = sqrt(h2), ih0 = rcp(h0);
+    n1 *= ih0; n2 *= ih0;
+    const double lm = m.lambda + m.mu, Em = m.mu * (3.0 * m.lambda + 2.0 * m.mu) * rcp(lm), nup = 0.5 * m.lambda * rcp(lm);
+    const double sgn = (c0 >= 0.0) ? 1.0 : -1.0, a0 = fabs(c0), alpha_p = xp[6];
+    double dg = 0.0;
+    bool done = !active, ok = false;
+    for (int it = 0; it < 12; ++it) {
+        const Hard h = hardening(m, alpha_p + dg);
+        const double F = h0 * Em * (a0 - h0 * dg) - (m.Y + h.H), dF = -h2 * Em - h.dH;
+        if (!done && it == 0 && !(F > 0.0)) { done = true; ok = !plastic_prev; }      // elastic step: dgam = 0, relaxed stretches
+        const double res = fabs(F) * rcp(m.Y + h.H);
+        if (!done && !(res < 1e300)) done = true;
+        if (!done && res < 1e-14) { done = true; ok = true; }
+        const bool last = res < 1e-8;                              // quadratic convergence: the next iterate is converged to round-off
+        if (!done) {
+            dg = fmax(dg - F * rcp(dF), 0.0);
+            if (last) { done = true; ok = true; }
+        }
+        if (!__any(!done)) break;
+    }
+    if (!ok) return false;
+    const double c0n = sgn * (a0 - h0 * dg), lat = -nup * c0n, sdg = sgn * dg;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x0[k] = xp[k] + sdg * AZ[k] * ih0 * kIW[k];
+    x0[6] = alpha_p + dg;
+    x0[7] = 1.0 + t1 + sdg * n1 + lat;
+    x0[8] = 1.0 + t2 + sdg * n2 + lat;
+    return true;
+}
+
 template <int DEF, int YK, int MK, bool LS, bool FAST = false>
 CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[6], const double* xp, double* x,
                      bool lane_valid) {
@@ -1673,6 +1732,24 @@ CM_D uint32_t newton(const cm_model_desc& m, const double eg[6], const double z[
     int it = 0;
     bool running = lane_valid;
     uint32_t flags = 0;
+    if constexpr (FAST && DEF == CM_UNIAXIAL_STRESS && MK == CM_SMALL_ELASTIC_PLASTIC && (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL)) {
+        // warm start (uniform switch): the 1-d return map, then the same loop from its result -- the test below, on the reference's
+        // residual and against ||C(x_prev)||, decides.  A state that already passes the test at x_prev stays as it is.
+        const bool warm_on = !(m.solver_flags & (CM_SOLVER_REFERENCE_ITERATES | CM_SOLVER_GENERAL_NEWTON)) &&
+                             !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY);
+        if (warm_on) {
+            double x0[NX];
+            const bool act = lane_valid && !((n0sq < rel2) || (n0sq < abs2));
+            if (__any(act)) {
+                const bool warm = uniaxial_warm_start<YK>(m, eg, z, xp, ev.plastic, act, x0);
+                if (warm && act) {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) x[k] = x0[k];
+                }
+                residual_mk<MK, DEF, YK, false>(m, eg, z, x, xp, ev, C, Ht);
+            }
+        }
+    }
     for (;;) {
         const double nsq = dot<NX>(C, C);
         const bool conv = (nsq < rel2) || (nsq < abs2);

@@ -744,7 +744,7 @@ def check_nn_hardening(backend, param_blocks, def_type=ol.FULL_3D, with_voce=Fal
         Cp = ol.Material(values, def_type=def_type, hardening_nn=(onn[0], wp)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
         Cm = ol.Material(values, def_type=def_type, hardening_nn=(onn[0], wm)).residual(xi_mid[:, b], sc.xi1[:, b], sc.gradu[:, b])
         fd = (Cp - Cm) / (2 * h)
-        np.testing.assert_allclose(dC[i, :, 0], fd, rtol=1e-5 if hidden else 2e-6, atol=max((2e-6 if hidden else 1e-7) * np.abs(dC).max(), 2e-14 if hidden else 0.0),     # (2e-14: the quotient's round-off floor)
+        np.testing.assert_allclose(dC[i, :, 0], fd, rtol=1e-5 if hidden else 2e-6, atol=max((2e-6 if hidden else 1e-7) * np.abs(dC).max(), 1e-13 if hidden else 0.0),     # (1e-13: the quotient's round-off floor)
                                    err_msg=f"weight {i}")
     assert np.abs(dC[:, 6, 0]).max() > 0                             # ... and they are not all zero: the yield row sees every weight
 
@@ -1216,13 +1216,13 @@ def check_barlat_generic(hessians, param_blocks, def_type=ol.FULL_3D, seed=4):
     np.testing.assert_allclose(dSp[19:, :, 0].T, Sq, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(Sq).max()))
 
 
-def check_warm_start(backend, def_type, yield_kind, kw, rot, ls, B=1024):
+def check_warm_start(backend, def_type, yield_kind, kw, rot, ls, B=1024, uniaxial_idx=0):
     """The product default for Hill / FULL_3D, J2 / PLANE_STRESS and Hosford (a >= 20) / FULL_3D: the scalar return map (resp.
     the analytic warm start) first, then the reference's Newton from there (include/cmad_hip.h CM_SOLVER_REFERENCE_ITERATES is
     the opt-out).  Against the oracle's general Newton from x_prev, two load steps from a hardened state: states, stresses,
     consistent tangent and reverse sweep; nearly every point passes the reference's convergence test on arrival (0 iterations);
     re-applying a strain to its own result is a 0-iteration step that returns the state bit for bit."""
-    sc = Scenario(def_type, yield_kind, kw, rot, ls, B=B, warm=True)
+    sc = Scenario(def_type, yield_kind, kw, rot, ls, B=B, warm=True, uniaxial_idx=uniaxial_idx)
     check_update(backend, sc)
     for gradu, xp in ((sc.gradu0, sc.xi0), (sc.gradu, sc.xi1)):
         xi_d, _, status = backend.update(sc, gradu, xp)
@@ -1232,4 +1232,61 @@ def check_warm_start(backend, def_type, yield_kind, kw, rot, ls, B=1024):
         assert ((st2.astype(np.uint32) & 0xFFFF) == 0).all() and np.array_equal(xi_again, xi_d)
     if not ls or yield_kind == "hosford":
         check_tangent(backend, sc)
-        check_vjp(backend, sc)
+        check_vjp(backend, sc, grad_atol=1e-9 if def_type == ol.UNIAXIAL_STRESS else 1e-12)
+
+
+def check_warm_start_edge_cases(backend, def_type, yield_kind, kw):
+    """The warm-started default route at the edges: zero and denormal strains (elastic: untouched), strain increments of 20 and
+    200 yield strains in one step (deep in the plastic range: the return maps start far from their roots), a step from a heavily
+    hardened state, and pure volumetric strain (no deviator: phi = 0).  States and stresses against the oracle's general Newton
+    wherever that converges; the backend must converge (or report non-convergence) without NaN everywhere."""
+    from cmad_amd.models.device import build_desc
+    from cmad_amd.synthetic import gauss_point_batch
+    ps, ux = def_type == ol.PLANE_STRESS, def_type == ol.UNIAXIAL_STRESS
+    nd, nu, nx = (2, 4, 8) if ps else ((1, 1, 9) if ux else (3, 9, 7))
+    values = ol.j2_voce_values(yield_kind=yield_kind, **kw)
+    ls = yield_kind == "hosford"                      # (plain Newton from x_prev does not converge for large Hosford exponents)
+
+    class S:
+        pass
+    sc = S()
+    sc.mat = ol.Material(values, def_type=def_type)
+    sc.st_o, sc.st_d = settings_pair(ls, warm=True)
+    sc.desc, sc.info = build_desc(values, def_type=def_type, newton=sc.st_d)
+    B = 256
+    x0 = np.tile(sc.mat.init_xi()[:, None], (1, B))
+    # zero / denormal strain
+    g = np.zeros((nu, B)); g[0, 1::2] = 1e-300
+    xi, sig, st = backend.update(sc, g, x0)
+    assert not (xi - x0).any() and np.isfinite(sig).all() and ((st.astype(np.uint32) & 0xFFFF) == 0).all()
+    # pure volumetric strain: no deviator
+    if not ux:
+        g = np.zeros((nu, B)); g[0] = g[nu - 1 if not ps else 3] = 3e-3
+        if not ps:
+            g[4] = 3e-3
+        xi, sig, st = backend.update(sc, g, x0)
+        assert np.isfinite(xi).all() and np.isfinite(sig).all() and ((st.astype(np.uint32) >> 16) & 1).all()
+    # large increments, and a second large step from the hardened state
+    for scale in (20.0, 200.0):
+        g = gauss_point_batch(B, seed=31, dev_scale=scale, ndims=nd)
+        if ux:
+            g = np.random.default_rng(31).uniform(-scale * 1e-3, scale * 1e-3, size=(1, B))
+        xi_o, sig_o, it_o, cv_o = sc.mat.update_batch(sc.st_o, g, x0)
+        xi_d, sig_d, st = backend.update(sc, g, x0)
+        st = st.astype(np.uint32)
+        assert np.isfinite(xi_d).all() and np.isfinite(sig_d).all()
+        ok = cv_o.astype(bool) & ((st >> 16) & 1).astype(bool)
+        # (at 200 yield strains the oracle's iteration from x_prev runs out of iterations on most points -- 31 % converge for Hill and
+        # Hosford a = 100 -- while the warm-started one converges everywhere: compared where both did)
+        assert ((st >> 16) & 1).mean() > 0.99 and ok.mean() > (0.2 if scale > 100 else 0.9), (scale, ((st >> 16) & 1).mean(), cv_o.mean())
+        tol = 10.0 * sc.st_d.abs_tol
+        np.testing.assert_allclose(xi_d[:, ok], xi_o[:, ok], rtol=1e-9, atol=max(1e-12, tol))
+        np.testing.assert_allclose(sig_d[:, ok], sig_o[:, ok], rtol=1e-9, atol=max(1e-7, 2e5 * tol))
+        if scale == 20.0:
+            g2 = 1.5 * g
+            okp = ok
+            xi_o2, sig_o2, _, cv_o2 = sc.mat.update_batch(sc.st_o, g2, xi_o)
+            xi_d2, sig_d2, st2 = backend.update(sc, g2, xi_o)
+            ok2 = okp & cv_o2.astype(bool) & ((st2.astype(np.uint32) >> 16) & 1).astype(bool)
+            assert ok2.mean() > 0.9
+            np.testing.assert_allclose(xi_d2[:, ok2], xi_o2[:, ok2], rtol=1e-9, atol=max(1e-12, tol))

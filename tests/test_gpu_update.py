@@ -786,9 +786,18 @@ def test_screened_route_is_taken_and_equals_the_lockstep_kernels():
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
-                                                    (ol.FULL_3D, "hosford", {"a": 20.0}), (ol.FULL_3D, "hosford", {"a": 64.0})])
+                                                    (ol.FULL_3D, "hosford", {"a": 20.0}), (ol.FULL_3D, "hosford", {"a": 64.0}),
+                                                    (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
 def test_warm_started_newton_against_the_oracle(backend, def_type, yield_kind, kw, rot, ls):
     """Scalar return maps / analytic warm starts (the default of the batched entry points) against the oracle's general Newton."""
     if yield_kind == "hosford" and not ls:
         pytest.skip("plain Newton from x_prev does not converge for large Hosford exponents: nothing to compare with")
-    pc.check_warm_start(backend, def_type, yield_kind, kw, rot, ls, B=4096)
+    pc.check_warm_start(backend, def_type, yield_kind, kw, rot, ls, B=4096, uniaxial_idx=2 if rot else 1)
+
+
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
+                                                    (ol.FULL_3D, "hosford", {"a": 100.0}), (ol.FULL_3D, "hosford", {"a": 20.0}),
+                                                    (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
+def test_warm_started_newton_edge_cases(backend, def_type, yield_kind, kw):
+    """Zero / volumetric strains, 20- and 200-yield-strain increments and a step from a heavily hardened state on the default route."""
+    pc.check_warm_start_edge_cases(backend, def_type, yield_kind, kw)

@@ -648,11 +648,22 @@ def test_plain_newton_through_the_line_search_kernels(def_type, yield_kind, kw, 
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
-                                                    (ol.FULL_3D, "hosford", {"a": 20.0}), (ol.FULL_3D, "hosford", {"a": 64.0})])
+                                                    (ol.FULL_3D, "hosford", {"a": 20.0}), (ol.FULL_3D, "hosford", {"a": 64.0}),
+                                                    (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
 def test_warm_started_newton_against_the_oracle(def_type, yield_kind, kw, rot, ls, solver_variant):
     """Scalar return maps / analytic warm starts (the default of the batched entry points) against the oracle's general Newton."""
     if yield_kind == "hosford" and not ls:
         pytest.skip("plain Newton from x_prev does not converge for large Hosford exponents: nothing to compare with")
     if solver_variant != "structured":
         pytest.skip("the warm starts are variants of the structured solver")
-    pc.check_warm_start(BACKEND, def_type, yield_kind, kw, rot, ls, B=512)
+    pc.check_warm_start(BACKEND, def_type, yield_kind, kw, rot, ls, B=512, uniaxial_idx=2 if rot else 1)
+
+
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
+                                                    (ol.FULL_3D, "hosford", {"a": 100.0}), (ol.FULL_3D, "hosford", {"a": 20.0}),
+                                                    (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
+def test_warm_started_newton_edge_cases(def_type, yield_kind, kw, solver_variant):
+    """Zero / volumetric strains, 20- and 200-yield-strain increments and a step from a heavily hardened state on the default route."""
+    if solver_variant != "structured":
+        pytest.skip("the warm starts are variants of the structured solver")
+    pc.check_warm_start_edge_cases(BACKEND, def_type, yield_kind, kw)
