@@ -111,7 +111,7 @@ def lib():
     L.cm_hessian_history_ep.argtypes = [md, i64, C.c_int32, C.c_int32, vp, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_double), dp, dp, dp, vp, i64, vp]
     L.cm_hessian_history_ep.restype = C.c_int
     L.cm_param_blocks.argtypes = [md, i64, C.c_int32, vp, dp, dp, dp, dp, dp, dp, vp]; L.cm_param_blocks.restype = C.c_int
-    L.cm_update_complex.argtypes = [md, i64, C.POINTER(C.c_double), dp, dp, dp, dp, dp, dp, vp, vp]; L.cm_update_complex.restype = C.c_int
+    L.cm_update_complex.argtypes = [md, i64, C.POINTER(C.c_double), dp, dp, dp, dp, dp, dp, dp, vp, vp]; L.cm_update_complex.restype = C.c_int
     L.cm_param_adjoint_history.argtypes = [md, i64, C.c_int32, C.c_int32, vp, dp, dp, dp, dp, dp, vp, i64, vp]
     L.cm_param_adjoint_history.restype = C.c_int
     L.cm_update_history.argtypes = [md, i64, C.c_int32, dp, dp, dp, dp, vp, vp]; L.cm_update_history.restype = C.c_int

@@ -2,6 +2,8 @@
 import os
 import shutil
 import subprocess
+import tempfile
+import time
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcmad_hip.so")
@@ -24,7 +26,7 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-NPARTS = 10         # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
+NPARTS = 11         # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
 
 
 def build(force=False, verbose=False, jobs=None):
@@ -43,16 +45,28 @@ def build(force=False, verbose=False, jobs=None):
            [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-DCM_HNN_VARIANT=1", "-DCM_RATE_DENSE=0",
              "-DCM_RATE_UNIAXIAL_DENSE=0", "-c", src, "-o", objs[NPARTS + k]] for k in range(NPARTS)]
     jobs = jobs or min(NPARTS, os.cpu_count() or 1)
+    # longest compiles first (measured: the arithmetic-T parts 9 / 10 and the reverse-sweep part 5 of either build), every
+    # free slot refilled as soon as ANY running compile ends
+    heavy = [NPARTS + 10, 10, NPARTS + 9, 9, 5, NPARTS + 5, 2, 1]
+    order = heavy + [k for k in range(2 * NPARTS) if k not in heavy]
+    pending = [cmds[k] for k in order]
     procs, failed = [], []
-    pending = list(cmds)
+    logs = {}
     while pending or procs:
         while pending and len(procs) < jobs:
             c = pending.pop(0)
-            procs.append((c, subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        c, p = procs.pop(0)
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            failed.append(" ".join(c) + "\n" + out)
+            log = tempfile.TemporaryFile(mode="w+")
+            procs.append((c, subprocess.Popen(c, stdout=log, stderr=subprocess.STDOUT, text=True), log))
+        done = [t for t in procs if t[1].poll() is not None]
+        if not done:
+            time.sleep(0.2)
+            continue
+        for c, p, log in done:
+            procs.remove((c, p, log))
+            if p.returncode != 0:
+                log.seek(0)
+                failed.append(" ".join(c) + "\n" + log.read())
+            log.close()
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -149,6 +149,10 @@ CM_D void t_seed(CX&) {}
 CM_D void t_seed(DC& x) { x.d = CX{1.0, 0.0}; }
 CM_D void t_seed2(CX&) {}
 CM_D void t_seed2(DC&) {}
+// the imaginary part of a complex-step parameter (real arithmetic types have none)
+template <class T> CM_D void t_add_imag(T&, double) {}
+CM_D void t_add_imag(CX& x, double im) { x.im += im; }
+CM_D void t_add_imag(DC& x, double im) { x.v.im += im; }
 CM_D void t_seed(double&) {}
 CM_D void t_seed(D1& x) { x.d = 1.0; }
 CM_D void t_seed(HD& x) { x.a = 1.0; }         // first differentiation direction of a hyper-dual ...
@@ -163,9 +167,11 @@ template <class T>
 struct MatT {
     T lambda, mu, Y, S, D, K, yc[19], Q[9];
     const double* nn;
+    const double* nn_im;             // complex-step instances: imaginary parts of the packed weights (same indexing), or null
     int nn_seed, nn_seed2;           // packed-weight index carrying the (first / second) derivative direction, or -1
     CM_D T nn_at(int i) const {
         T w = t_const<T>(nn[i]);
+        if (nn_im) t_add_imag(w, nn_im[i]);
         if (i == nn_seed) t_seed(w);
         if (i == nn_seed2) t_seed2(w);
         return w;
@@ -179,7 +185,7 @@ CM_D void mat_from_desc(const cm_model_desc& m, MatT<T>& p) {
     p.S = t_const<T>(m.voce_S); p.D = t_const<T>(m.voce_D); p.K = t_const<T>(m.lin_K);
     for (int k = 0; k < 19; ++k) p.yc[k] = t_const<T>(m.yc[k]);
     for (int k = 0; k < 9; ++k) p.Q[k] = t_const<T>(m.Q[k]);
-    p.nn = m.nn_weights; p.nn_seed = -1; p.nn_seed2 = -1;
+    p.nn = m.nn_weights; p.nn_im = nullptr; p.nn_seed = -1; p.nn_seed2 = -1;
 }
 
 // Extended parameter ("EP") index of the sensitivities beyond the 12 of cm_param_index: 0..11 = KP order,
@@ -460,8 +466,9 @@ CM_D void yield_T(const cm_model_desc& m, const MatT<T>& p, const T s[6], T& phi
         switch (m.yield_kind) {
             case CM_YIELD_J2: yield_T<CM_YIELD_J2, T>(m, p, s, phi, gt); break;
             case CM_YIELD_HILL: yield_T<CM_YIELD_HILL, T>(m, p, s, phi, gt); break;
-#if defined(CM_HNN_VARIANT) && CM_HNN_VARIANT             // the EXT build of the library: the plain hybrid surface is its only dense one
+#if defined(CM_HNN_VARIANT) && CM_HNN_VARIANT             // the EXT build of the library: the network surfaces are its only dense ones
             case CM_YIELD_HYBRID_HILL_NN: yield_T<CM_YIELD_HYBRID_HILL_NN, T>(m, p, s, phi, gt); break;
+            case CM_YIELD_SCALED_HYBRID_HILL_NN: yield_T<CM_YIELD_SCALED_HYBRID_HILL_NN, T>(m, p, s, phi, gt); break;
             default: yield_T<CM_YIELD_HOSFORD, T>(m, p, s, phi, gt); break;
 #else
             case CM_YIELD_HOSFORD: yield_T<CM_YIELD_HOSFORD, T>(m, p, s, phi, gt); break;
@@ -923,29 +930,33 @@ CM_D bool direct_column_ep(const cm_model_desc& m, const double* G, const double
 // states with the holomorphic Jacobian.  Here: the arithmetic-T model with T = CX for the residual and T = DC (duals over CX,
 // one column per evaluation) for d C / d x, an unpivoted complex LU, the reference's stopping rule on ||C||_2.
 // p_im[CM_NUM_PARAMS]: imaginary parts of the native parameters (KP order); the real parts are the model description's.
-template <class T> CM_D void mat_add_imag(MatT<T>&, const double*);
-template <> CM_D void mat_add_imag<CX>(MatT<CX>& p, const double* p_im) {
-    p.lambda.im = p_im[CM_P_LAMBDA]; p.mu.im = p_im[CM_P_MU]; p.Y.im = p_im[CM_P_Y];
-    p.S.im = p_im[CM_P_VOCE_S]; p.D.im = p_im[CM_P_VOCE_D]; p.K.im = p_im[CM_P_LIN_K];
-    for (int k = 0; k < CM_NUM_PARAMS - CM_P_YC0; ++k) p.yc[k].im = p_im[CM_P_YC0 + k];
-}
-template <> CM_D void mat_add_imag<DC>(MatT<DC>& p, const double* p_im) {
-    p.lambda.v.im = p_im[CM_P_LAMBDA]; p.mu.v.im = p_im[CM_P_MU]; p.Y.v.im = p_im[CM_P_Y];
-    p.S.v.im = p_im[CM_P_VOCE_S]; p.D.v.im = p_im[CM_P_VOCE_D]; p.K.v.im = p_im[CM_P_LIN_K];
-    for (int k = 0; k < CM_NUM_PARAMS - CM_P_YC0; ++k) p.yc[k].v.im = p_im[CM_P_YC0 + k];
+// ext_im (may be null): imaginary parts of the extended parameters in EP order from CM_EP_YC6 on -- yc[6..18] (13), Q row-major
+// (9), then every packed network weight (indexed like cm_model_desc.nn_weights).
+constexpr int kCxExtNN0 = CM_EP_NN0 - CM_EP_YC6;                 // 22: where the network weights start in ext_im
+template <class T>
+CM_D void mat_add_imag(MatT<T>& p, const double* p_im, const double* ext_im) {
+    t_add_imag(p.lambda, p_im[CM_P_LAMBDA]); t_add_imag(p.mu, p_im[CM_P_MU]); t_add_imag(p.Y, p_im[CM_P_Y]);
+    t_add_imag(p.S, p_im[CM_P_VOCE_S]); t_add_imag(p.D, p_im[CM_P_VOCE_D]); t_add_imag(p.K, p_im[CM_P_LIN_K]);
+    for (int k = 0; k < CM_NUM_PARAMS - CM_P_YC0; ++k) t_add_imag(p.yc[k], p_im[CM_P_YC0 + k]);
+    if (ext_im) {
+        for (int k = 0; k < 13; ++k) t_add_imag(p.yc[6 + k], ext_im[k]);
+        for (int k = 0; k < 9; ++k) t_add_imag(p.Q[k], ext_im[13 + k]);
+        p.nn_im = ext_im + kCxExtNN0;
+    }
 }
 
 // x: in = the starting iterate, out = the returned state; C, sg: residual and global Cauchy stress at the returned state.
 // G: grad u (rate form: grad u - grad u_prev).  max_iters = 0 evaluates C and sg at x.  Returns the status word.
 template <int DEF, int YK, int MK>
-CM_D uint32_t newton_cx(const cm_model_desc& m, const double* p_im, const double* G, const CX* xp, CX* x, CX* C, CX sg[6]) {
+CM_D uint32_t newton_cx(const cm_model_desc& m, const double* p_im, const double* ext_im, const double* G, const CX* xp, CX* x, CX* C,
+                        CX sg[6]) {
     constexpr int NX = nx_of<DEF, MK>();
     MatT<CX> p;
     mat_from_desc<CX>(m, p);
-    mat_add_imag<CX>(p, p_im);
+    mat_add_imag<CX>(p, p_im, ext_im);
     MatT<DC> pd;
     mat_from_desc<DC>(m, pd);
-    mat_add_imag<DC>(pd, p_im);
+    mat_add_imag<DC>(pd, p_im, ext_im);
     auto norm2 = [&]() { double n = 0.0; for (int k = 0; k < NX; ++k) n += C[k].re * C[k].re + C[k].im * C[k].im; return n; };
     model_eval_T<DEF, YK, MK, CX>(m, p, G, x, xp, C, sg);
     const double n0 = norm2(), rel2 = m.rel_tol * m.rel_tol * n0, abs2 = m.abs_tol * m.abs_tol;

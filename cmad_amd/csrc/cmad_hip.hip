@@ -21,7 +21,7 @@
 #include "cm_pool.hpp"
 #include "cm_hessian.hpp"
 
-// The library can be built from this one file in nine independent pieces (hipcc -DCM_PART=0..8, see
+// The library can be built from this one file in eleven independent pieces (hipcc -DCM_PART=0..10, see
 // cmad_amd/build.py) so the template instantiations compile in parallel; without CM_PART everything is one TU.
 //   9: cm_param_blocks, cm_param_adjoint_history (extended parameter sensitivities)
 //   0: cm_update            2: cm_update_vjp, cm_adjoint_step   4: cm_update_tangent          6: cm_objective_grad,
@@ -1538,8 +1538,8 @@ __global__ __launch_bounds__(64) void k_param_blocks(cm_model_desc m, int64_t B,
 // arrays are (2, rows, B): the real rows, then the imaginary rows.
 struct ParamImag { double v[CM_NUM_PARAMS]; };
 template <int DEF, int YK, int MK>
-__global__ __launch_bounds__(64) void k_update_cx(cm_model_desc m, int64_t B, ParamImag pim, const double* __restrict__ gradu,
-        const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev, double* __restrict__ xi,
+__global__ __launch_bounds__(64) void k_update_cx(cm_model_desc m, int64_t B, ParamImag pim, const double* __restrict__ ext_im,
+        const double* __restrict__ gradu, const double* __restrict__ gradu_prev, const double* __restrict__ xi_prev, double* __restrict__ xi,
         double* __restrict__ residual, double* __restrict__ sigma, uint32_t* __restrict__ status) {
     constexpr int NX = nx_of<DEF, MK>(), NU = Dims<DEF>::NU;
     const int64_t pt = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(64) void k_update_cx(cm_model_desc m, int64_t B, Pa
         xp[k] = CX{xi_prev[(int64_t)k * B + pt], xi_prev[(int64_t)(NX + k) * B + pt]};
         x[k] = CX{xi[(int64_t)k * B + pt], xi[(int64_t)(NX + k) * B + pt]};
     }
-    const uint32_t st = newton_cx<DEF, YK, MK>(m, pim.v, G, xp, x, C, sg);
+    const uint32_t st = newton_cx<DEF, YK, MK>(m, pim.v, ext_im, G, xp, x, C, sg);
     for (int k = 0; k < NX; ++k) { xi[(int64_t)k * B + pt] = x[k].re; xi[(int64_t)(NX + k) * B + pt] = x[k].im; }
     if (residual) for (int k = 0; k < NX; ++k) { residual[(int64_t)k * B + pt] = C[k].re; residual[(int64_t)(NX + k) * B + pt] = C[k].im; }
     if (sigma) for (int k = 0; k < 6; ++k) { sigma[(int64_t)k * B + pt] = sg[k].re; sigma[(int64_t)(6 + k) * B + pt] = sg[k].im; }
@@ -1839,9 +1839,16 @@ int launch_update(const cm_model_desc* m, int64_t B, const double* gradu, const 
             hipLaunchKernelGGL(k_screen_reset, dim3(1), dim3(1), 0, s, count);
             const bool found = dispatch<true, 1>(m, [&]<int D, int Y, bool R, bool LS>() {
                 if constexpr (D == CM_FULL_3D && screen_pays<Y>()) {
-                    hipLaunchKernelGGL((k_screen<Y, R>), dim3((unsigned)((B + kScreenBlock - 1) / kScreenBlock)), dim3(kScreenBlock), 0, s,
-                                       md, B, gradu, xi_prev, xi, sigma, status, list, count);
-                    hipLaunchKernelGGL((k_update_listed<Y, R, LS>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                    // (the dense surfaces have no Q = I kernels elsewhere -- dispatch hands R = true; these two small families do:
+                    // the rotation products are 12 % of k_screen's instructions)
+                    const dim3 sgrid((unsigned)((B + kScreenBlock - 1) / kScreenBlock)), sblock(kScreenBlock);
+                    if (md.rotation_is_identity) {
+                        hipLaunchKernelGGL((k_screen<Y, false>), sgrid, sblock, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                        hipLaunchKernelGGL((k_update_listed<Y, false, LS>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                    } else {
+                        hipLaunchKernelGGL((k_screen<Y, true>), sgrid, sblock, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                        hipLaunchKernelGGL((k_update_listed<Y, true, LS>), grid, block, 0, s, md, B, gradu, xi_prev, xi, sigma, status, list, count);
+                    }
                 }
             });
             if (!found) return CM_ERR_UNSUPPORTED;
@@ -2217,6 +2224,8 @@ int launch_hessian_history_ep(const cm_model_desc* m, int64_t B, int K, int n_ep
     return check_launch();
 }
 
+#endif
+#if CM_HAS_PART(10)                      // (a part of their own: the arithmetic-T model in complex arithmetic is the longest compile)
 template <int MK>
 int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu,
                         const double* gradu_prev, const double* xi_prev, const double* xi, double* dC, double* dS, void* stream) {
@@ -2237,12 +2246,15 @@ int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32
 }
 
 template <int MK>
-int launch_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* gradu, const double* gradu_prev,
-                          const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status, void* stream) {
+int launch_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* ext_im, const double* gradu,
+                          const double* gradu_prev, const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status,
+                          void* stream) {
     if (!m || B < 0) return CM_ERR_BAD_ARG;
-    // the reference runs its complex-step checks on the J2 analytical problem; the quadratic and Hosford surfaces continue
-    // analytically the same way, the eigen-decomposition of Barlat and the network surfaces are left out
-    if (!supported(m, MK) || is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+    // the reference runs its complex-step checks on the J2 analytical problem; every surface continues analytically the same
+    // way (Barlat's Jacobi rotations and the |.| of its differences are decided on real parts, softplus on the real part of its
+    // argument)
+    if (!supported(m, MK) || (is_dense_yield(m->yield_kind) && (rate_dense(m, MK) || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && rate_uniaxial_dense(m)))))
+        return CM_ERR_UNSUPPORTED;
     if (B == 0) return CM_OK;
     if (!p_im || !gradu || !xi_prev || !xi || (MK == CM_SMALL_RATE_ELASTIC_PLASTIC && !gradu_prev)) return CM_ERR_BAD_ARG;
     ParamImag pim;
@@ -2252,8 +2264,8 @@ int launch_update_complex(const cm_model_desc* m, int64_t B, const double* p_im,
     const dim3 grid((unsigned)((B + 63) / 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
     const bool found = dispatch<true>(m, [&]<int D, int Y, bool R, bool LS>() {
-        if constexpr (!is_dense_yield(Y))
-            hipLaunchKernelGGL((k_update_cx<D, CM_YIELD_ANY, MK>), grid, block, 0, s, md, B, pim, gradu, gradu_prev, xi_prev, xi, residual, sigma, status);
+        if constexpr (has_generic_eval(Y) && (MK == CM_SMALL_ELASTIC_PLASTIC || (has_rate_dense<MK, Y>() && has_rate_uniaxial_dense<D, Y>())))
+            hipLaunchKernelGGL((k_update_cx<D, CM_YIELD_ANY, MK>), grid, block, 0, s, md, B, pim, ext_im, gradu, gradu_prev, xi_prev, xi, residual, sigma, status);
     });
     if (!found) return CM_ERR_UNSUPPORTED;
     return check_launch();
@@ -2512,6 +2524,8 @@ int cm_hessian_history_ep(const cm_model_desc* m, int64_t B, int32_t K, int32_t 
     return launch_hessian_history_ep<CM_SMALL_ELASTIC_PLASTIC>(m, B, K, n_ep, ep_index, gradu_hist, xi_hist, lam_hist, dxi_dp_hist, dxi_dpe_hist,
                                                                sigma_bar_hist, hss6, hss_hist, hxx_hist, hess, workspace, workspace_bytes, stream);
 }
+#endif
+#if CM_HAS_PART(10)
 int cm_param_blocks(const cm_model_desc* m, int64_t B, int32_t n_ep, const int32_t* ep_index,
                     const double* gradu, const double* gradu_prev, const double* xi_prev, const double* xi,
                     double* dC_dp, double* dsigma_dp, void* stream) {
@@ -2520,12 +2534,13 @@ int cm_param_blocks(const cm_model_desc* m, int64_t B, int32_t n_ep, const int32
         return launch_param_blocks<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, n_ep, ep_index, gradu, gradu_prev, xi_prev, xi, dC_dp, dsigma_dp, stream);
     return launch_param_blocks<CM_SMALL_ELASTIC_PLASTIC>(m, B, n_ep, ep_index, gradu, nullptr, xi_prev, xi, dC_dp, dsigma_dp, stream);
 }
-int cm_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* gradu, const double* gradu_prev,
-                      const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status, void* stream) {
+int cm_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* ext_im, const double* gradu,
+                      const double* gradu_prev, const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status,
+                      void* stream) {
     if (!m) return CM_ERR_BAD_ARG;
     if (m->model_kind == CM_SMALL_RATE_ELASTIC_PLASTIC)
-        return launch_update_complex<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, p_im, gradu, gradu_prev, xi_prev, xi, residual, sigma, status, stream);
-    return launch_update_complex<CM_SMALL_ELASTIC_PLASTIC>(m, B, p_im, gradu, nullptr, xi_prev, xi, residual, sigma, status, stream);
+        return launch_update_complex<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, p_im, ext_im, gradu, gradu_prev, xi_prev, xi, residual, sigma, status, stream);
+    return launch_update_complex<CM_SMALL_ELASTIC_PLASTIC>(m, B, p_im, ext_im, gradu, nullptr, xi_prev, xi, residual, sigma, status, stream);
 }
 int cm_param_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
                              const double* gradu_hist, const double* xi_hist, const double* lam_hist,

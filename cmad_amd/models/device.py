@@ -136,12 +136,6 @@ def complex_native_parameters(values, yield_type):
     pair through the same conversion table as the real path (analytic in its arguments), the flow-stress and yield coefficients
     as they are.  `cm_update_complex` takes the imaginary parts; the real parts are the model description's."""
     from .elastic_constants import ElasticConstants
-    # a perturbation of any other leaf (rotation matrix, ...) would be dropped silently and Im J / h would read 0 for it: the
-    # reference's complex instance carries the perturbation through the whole pytree (small_elastic_plastic.py:118-127)
-    rot = values.get("rotation matrix")
-    if rot is not None and np.iscomplexobj(rot) and np.any(np.imag(np.asarray(rot)) != 0.0):
-        raise NotImplementedError("complex-step perturbation of 'rotation matrix': cm_update_complex carries imaginary parts of "
-                                  "the 12 native kernel parameters only (elastic constants, flow stress, Hill / Hosford coefficients)")
     ec = ElasticConstants.from_params({k: complex(v) for k, v in values["elastic"].items()})
     kp = np.zeros(_lib.CM_NUM_PARAMS, dtype=complex)
     kp[_lib.P_LAMBDA], kp[_lib.P_MU] = ec.lmbda, ec.mu
@@ -159,6 +153,34 @@ def complex_native_parameters(values, yield_type):
     elif yield_type == "hosford":
         kp[_lib.P_YC0] = complex(eff["hosford"]["a"])
     return kp
+
+
+def complex_parameter_parts(values, flat_paths, info):
+    """(p_imag (12,), ext_imag or None) of a complex parameter tree: the imaginary parts `cm_update_complex` takes.  The reference's
+    complex instance carries a perturbation of ANY leaf through the model (small_elastic_plastic.py:118-127); here the 12 native
+    parameters go in `p_imag` and every other leaf the kernels read -- Barlat coefficients, rotation matrix, network weights of the
+    yield surface and of the hardening law -- in `ext_imag`, indexed like the extended parameter index (`leaf_ep_index`) from 12
+    on: 13 + 9 + one entry per packed network double.  `flat_paths`: `Parameters.flat_paths()` of the tree."""
+    from ..parameters.parameters import ravel_pytree
+    p_im = complex_native_parameters(values, info["yield_type"]).imag.copy()
+    flat = np.asarray(ravel_pytree(values)[0])
+    n_nn = int(np.asarray(info["nn_packed"]).size) if "nn_packed" in info else 0
+    ext = None
+    if np.iscomplexobj(flat):
+        for path, v in zip(flat_paths, flat):
+            im = float(np.imag(v))
+            if im == 0.0:
+                continue
+            e = leaf_ep_index(path, info)
+            if e is None:                             # a native parameter: complex_native_parameters carries it
+                continue
+            if e < _lib.CM_NUM_PARAMS:
+                p_im[e] = im
+            else:
+                if ext is None:
+                    ext = np.zeros(EP_NN0 - EP_YC6 + n_nn)
+                ext[e - EP_YC6] = im
+    return p_im, ext
 
 
 def build_desc(values, def_type=DefType.FULL_3D, model_kind=0, yield_tol=1e-14, uniaxial_stress_idx=0,
@@ -521,11 +543,12 @@ class DeviceEvaluator:
         _lib.check(rc, "cm_update_rate")
         return xi, sigma, status
 
-    def update_complex(self, p_imag, gradu, xi_prev, xi_start, gradu_prev=None):
+    def update_complex(self, p_imag, gradu, xi_prev, xi_start, gradu_prev=None, ext_imag=None):
         """`cm_update_complex`: the local Newton solve of a complex-step model instance (reference `Model(..., is_complex=True)`
-        under `newton_solve`).  p_imag: (12,) imaginary parts of the native parameters (host); gradu (n_gradu, B) real;
-        xi_prev, xi_start (2, n_xi, B): real rows then imaginary rows.  Returns (xi (2, n_xi, B), residual (2, n_xi, B),
-        sigma (2, 6, B), status); `max_iters = 0` in the description evaluates residual and stress at xi_start."""
+        under `newton_solve`).  p_imag: (12,) imaginary parts of the native parameters (host); ext_imag: imaginary parts of the
+        extended parameters (`complex_parameter_parts`; host array or None); gradu (n_gradu, B) real; xi_prev, xi_start
+        (2, n_xi, B): real rows then imaginary rows.  Returns (xi (2, n_xi, B), residual (2, n_xi, B), sigma (2, 6, B), status);
+        `max_iters = 0` in the description evaluates residual and stress at xi_start."""
         torch = _torch()
         B = gradu.shape[1]
         _check_soa(gradu, self.nu, B, "gradu")
@@ -540,7 +563,13 @@ class DeviceEvaluator:
         sigma = torch.empty((2, 6, B), dtype=torch.float64, device=dev)
         status = torch.empty((B,), dtype=torch.int32, device=dev)
         pim = (C.c_double * _lib.CM_NUM_PARAMS)(*[float(v) for v in p_imag])
-        rc = self.L.cm_update_complex(C.byref(self.desc), B, pim, _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(xi), _ptr(res),
+        ext = None
+        if ext_imag is not None:
+            n_nn = int(np.asarray(self.info["nn_packed"]).size) if "nn_packed" in self.info else 0
+            if np.asarray(ext_imag).shape != (EP_NN0 - EP_YC6 + n_nn,):
+                raise ValueError(f"ext_imag: expected {EP_NN0 - EP_YC6 + n_nn} entries (13 + 9 + the packed network doubles)")
+            ext = torch.from_numpy(np.ascontiguousarray(ext_imag, dtype=np.float64)).to(dev)
+        rc = self.L.cm_update_complex(C.byref(self.desc), B, pim, _ptr(ext), _ptr(gradu), _ptr(gp), _ptr(xi_prev), _ptr(xi), _ptr(res),
                                       _ptr(sigma), _ptr(status), self._stream())
         _lib.check(rc, "cm_update_complex")
         return xi, res, sigma, status

@@ -63,8 +63,6 @@ class Model(ABC):
         return {}
 
     def __init__(self) -> None:
-        if getattr(self, "_is_complex", False) and (self._hybrid is not None or self._hardening_nn is not None):
-            raise NotImplementedError("complex-step instances: J2 / Hill / Hosford with Voce / linear hardening (cm_update_complex)")
         self._deriv_mode = DerivType.DNONE
         self.newton_settings = NewtonSettings()
         self.parameters.compute_mixed_block_shapes(self._num_eqs)
@@ -187,23 +185,24 @@ class Model(ABC):
 
     # ------------------------------------------------------------------ complex-step instances (reference: is_complex=True)
     def _complex_arrays(self):
-        """(p_imag (12,), gradu (n, 1), gradu_prev or None, xi_prev (2, n_xi, 1), xi (2, n_xi, 1)) of the gathered state."""
-        from .device import complex_native_parameters
+        """(p_imag (12,), ext_imag or None, gradu (n, 1), gradu_prev or None, xi_prev (2, n_xi, 1), xi (2, n_xi, 1)) of the
+        gathered state."""
+        from .device import complex_parameter_parts
         _, info = self._desc()
-        kp = complex_native_parameters(self.parameters.values, info["yield_type"])
+        p_im, ext_im = complex_parameter_parts(self.parameters.values, self.parameters.flat_paths(), info)
         split = lambda blocks: np.stack([f(np.concatenate([np.atleast_1d(np.asarray(b, dtype=complex)).ravel() for b in blocks]))
                                          for f in (np.real, np.imag)])[:, :, None]
         G = np.asarray(self._U.grad_fields["u"], dtype=np.float64).reshape(-1, 1)
         Gp = np.asarray(self._U_prev.grad_fields["u"], dtype=np.float64).reshape(-1, 1) if self._model_kind == 1 else None
-        return kp.imag.copy(), G, Gp, np.ascontiguousarray(split(self._xi_prev)), np.ascontiguousarray(split(self._xi))
+        return p_im, ext_im, G, Gp, np.ascontiguousarray(split(self._xi_prev)), np.ascontiguousarray(split(self._xi))
 
     def _complex_solve(self, settings: NewtonSettings):
         """One `cm_update_complex` launch at the gathered state, started at the current xi: (xi, C, sigma6, status word), complex."""
         import torch
-        p_im, G, Gp, xp, x0 = self._complex_arrays()
+        p_im, ext_im, G, Gp, xp, x0 = self._complex_arrays()
         ev = self.device_evaluator(settings)
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
-        xi, res, sig, status = ev.update_complex(p_im, t(G), t(xp), t(x0), gradu_prev=t(Gp))
+        xi, res, sig, status = ev.update_complex(p_im, t(G), t(xp), t(x0), gradu_prev=t(Gp), ext_imag=ext_im)
         c = lambda a: a.cpu().numpy()[0, :, 0] + 1j * a.cpu().numpy()[1, :, 0]
         return c(xi), c(res), c(sig), int(status.cpu().numpy().astype(np.uint32)[0])
 

@@ -537,13 +537,18 @@ int cm_param_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, int32
  * imperative Newton (cmad/models/nonlinear_solver.py:14-85, plain steps) on the complex residual with the holomorphic Jacobian;
  * |.| and the branch select are decided on real parts (complex-step convention).
  *   in : p_im[CM_NUM_PARAMS] (HOST) imaginary parts of the native parameters, KP order -- the real parts are the description's;
+ *        ext_im (DEVICE, may be NULL = all zero): imaginary parts of every other parameter the model reads, in the order of the
+ *        extended parameter index from 12 on (cm_param_blocks): yc[6..18] (13 Barlat coefficients), Q row-major (9), then one
+ *        entry per double of cm_model_desc.nn_weights (22 + the length of that buffer doubles in all);
  *        gradu[n_gradu][B] (real), gradu_prev (rate form, else NULL), xi_prev[2][n_xi][B] (real rows, then imaginary rows)
  *   i/o: xi[2][n_xi][B]: in = the starting iterate (the reference starts at the model's current state), out = the returned state
  *   out: residual[2][n_xi][B], sigma[2][6][B] at the returned state (either may be NULL), status[B] (may be NULL)
- * max_iters = 0 evaluates residual and stress at xi.  J2 / Hill / Hosford; both model kinds; every deformation type.
+ * max_iters = 0 evaluates residual and stress at xi.  Every yield surface and hardening law; both model kinds; every deformation
+ * type.
  */
-int cm_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* gradu, const double* gradu_prev,
-                      const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status, void* stream);
+int cm_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* ext_im, const double* gradu,
+                      const double* gradu_prev, const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status,
+                      void* stream);
 
 #ifdef __cplusplus
 }

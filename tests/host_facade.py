@@ -56,9 +56,9 @@ class HostHistoryEngine:
 
 def _host_complex_solve(model, settings):
     """Model._complex_solve on the host build of cm::newton_cx."""
-    p_im, G, Gp, xp, x0 = model._complex_arrays()
+    p_im, ext_im, G, Gp, xp, x0 = model._complex_arrays()
     desc, _ = model._desc(newton=settings)
-    xi, res, sig, st = hh.update_complex(desc, p_im, G, xp, x0, gradu_prev=Gp)
+    xi, res, sig, st = hh.update_complex(desc, p_im, G, xp, x0, gradu_prev=Gp, ext_imag=ext_im)
     c = lambda a: a[0, :, 0] + 1j * a[1, :, 0]
     return c(xi), c(res), c(sig), int(st[0])
 

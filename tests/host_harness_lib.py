@@ -239,7 +239,7 @@ def param_blocks(desc, ep_index, gradu, xi_prev, xi, nx, gradu_prev=None, info=N
     return dC, dS
 
 
-def update_complex(desc, p_imag, gradu, xi_prev, xi_start, gradu_prev=None):
+def update_complex(desc, p_imag, gradu, xi_prev, xi_start, gradu_prev=None, ext_imag=None):
     """cm_update_complex on the host build (cm::newton_cx): complex arrays as (2, rows, B).  Returns (xi, residual, sigma, status)."""
     L = lib()
     c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
@@ -248,8 +248,9 @@ def update_complex(desc, p_imag, gradu, xi_prev, xi_start, gradu_prev=None):
     B, nx = gradu.shape[1], xi.shape[1]
     res = np.zeros((2, nx, B)); sig = np.zeros((2, 6, B)); st = np.zeros(B, dtype=np.uint32)
     pim = np.ascontiguousarray(p_imag, dtype=np.float64)
-    rc = L.hh_update_complex(C.byref(desc), C.c_int64(B), _p(pim), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi), _p(res), _p(sig),
-                             st.ctypes.data_as(C.c_void_p))
+    ext = None if ext_imag is None else np.ascontiguousarray(ext_imag, dtype=np.float64)
+    rc = L.hh_update_complex(C.byref(desc), C.c_int64(B), _p(pim), _p(ext), _p(gradu), _p(gradu_prev), _p(xi_prev), _p(xi), _p(res),
+                             _p(sig), st.ctypes.data_as(C.c_void_p))
     assert rc == 0
     return xi, res, sig, st
 

@@ -642,11 +642,10 @@ int hh_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* 
     return dispatch<true>(m, [&]<int D, int Y, bool R>() { body.template operator()<D, Y, CM_SMALL_ELASTIC_PLASTIC>(); });
 }
 // cm_update_complex's per-point body (cm::newton_cx): complex arrays as (2, rows, B)
-int hh_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* gradu, const double* gradu_prev,
-                      const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status) {
-    if (is_dense_yield(m->yield_kind)) return CM_ERR_UNSUPPORTED;
+int hh_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* ext_im, const double* gradu,
+                      const double* gradu_prev, const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status) {
     auto body = [&]<int D, int Y, int MK>() {
-        if constexpr (!is_dense_yield(Y)) {
+        {
             constexpr int NX = nx_of<D, MK>(), NU = Dims<D>::NU;
             for (int64_t pt = 0; pt < B; ++pt) {
                 double G[NU];
@@ -656,7 +655,7 @@ int hh_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, con
                     xp[k] = CX{xi_prev[k * B + pt], xi_prev[(NX + k) * B + pt]};
                     x[k] = CX{xi[k * B + pt], xi[(NX + k) * B + pt]};
                 }
-                const uint32_t st = newton_cx<D, Y, MK>(*m, p_im, G, xp, x, C, sg);
+                const uint32_t st = newton_cx<D, CM_YIELD_ANY, MK>(*m, p_im, ext_im, G, xp, x, C, sg);
                 for (int k = 0; k < NX; ++k) { xi[k * B + pt] = x[k].re; xi[(NX + k) * B + pt] = x[k].im; }
                 if (residual) for (int k = 0; k < NX; ++k) { residual[k * B + pt] = C[k].re; residual[(NX + k) * B + pt] = C[k].im; }
                 if (sigma) for (int k = 0; k < 6; ++k) { sigma[k * B + pt] = sg[k].re; sigma[(6 + k) * B + pt] = sg[k].im; }

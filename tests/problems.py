@@ -45,7 +45,7 @@ def plane_stress_F(strain_increment=0.02, num_pts_per_increment=50):
     return F
 
 
-def extended_leaf_problem(model_cls, yield_kind, active_rotation):
+def extended_leaf_problem(model_cls, yield_kind, active_rotation, is_complex=False):
     """PLANE_STRESS calibration history whose active leaves lie outside the 12 native kernel parameters: the Hosford exponent
     and/or the rotation matrix (differentiated by forward-mode evaluation of the whole model, cm_param_blocks)."""
     from cmad_amd.models import DefType
@@ -56,13 +56,14 @@ def extended_leaf_problem(model_cls, yield_kind, active_rotation):
         # hybrid Hill + ICNN surface, one ("network") or two ("network deep") hidden layers; active: Y, one Hill coefficient,
         # the input weights of the last layer and (deep) the weights between the hidden layers
         from cmad_amd.models import HybridHillEffectiveStress
+        from cmad_amd.models.device import ScaledHybridHillEffectiveStress
         from cmad_amd.synthetic import al7079_hybrid_setup
         # "network wide": 42 + 7 + 6 network entries + the rotation matrix = 64 extended directions, the second-order pass's limit
         widths = (6, 4, 3, 1) if yield_kind.endswith("deep") else ((6, 7, 1) if yield_kind.endswith("wide") else (6, 5, 1))
         icnn, values = al7079_hybrid_setup(widths)
         values = copy.deepcopy(values)
         values["plastic"]["flow stress"]["initial yield"]["Y"] = 200.0
-        kw = {"effective_stress_fun": HybridHillEffectiveStress(icnn)}
+        kw = {"effective_stress_fun": ScaledHybridHillEffectiveStress(icnn, 525.0) if "scaled" in yield_kind else HybridHillEffectiveStress(icnn)}
     else:
         base = params_J2_voce(yield_kind=yield_kind, scale_params=False)
         values = copy.deepcopy(base.values)
@@ -87,13 +88,94 @@ def extended_leaf_problem(model_cls, yield_kind, active_rotation):
             nn["x params"][0]["weights"] = True
     params = Parameters(values, flags, tree_map(lambda a: None, copy.deepcopy(values)))
     F = plane_stress_F(0.02, 3)
+    if is_complex:
+        kw["is_complex"] = True
     model = model_cls(params, DefType.PLANE_STRESS, **kw)
     n = F.shape[2]
     t = np.linspace(0.0, 1.0, n)
     data = np.zeros((3, 3, n))
     data[0, 0] = 260.0 * np.tanh(4 * t); data[1, 1] = 180.0 * t; data[0, 1] = data[1, 0] = 15.0 * np.sin(3 * t)
     weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.; weight[0, 1] = weight[1, 0] = 0.7
-    return model, Calibration(model, data, weight), F
+    return model, Calibration(model, data.astype(complex) if is_complex else data, weight), F
+
+
+def complex_step_problem(model_cls, kind, is_complex):
+    """(model, qoi, F) of the complex-step checks beyond the reference's J2 case: "barlat" (active: Y, two coefficients in the
+    native yc slots' range and beyond it, the exponent), "hardening network" / "hardening network deep" (every weight and bias
+    of the network hardening law), or one of `extended_leaf_problem`'s network surfaces with the rotation matrix active."""
+    from cmad_amd.models import DefType
+    from cmad_amd.qois import Calibration
+    if not (kind == "barlat" or kind.startswith("hardening network")):
+        return extended_leaf_problem(model_cls, kind, True, is_complex=is_complex)
+    import parity_cases as pc
+    kw = {"is_complex": True} if is_complex else {}
+    if kind == "barlat":
+        from cmad_amd.models.device import BARLAT_NAMES
+        import oracle_lib as ol
+        values = ol.j2_voce_values()
+        values["plastic"]["effective stress"] = {"barlat": dict(zip(BARLAT_NAMES, pc.AL7079_BARLAT[:18] + [8.0]))}
+        th = 0.35
+        values["rotation matrix"] = np.array([[np.cos(th), -np.sin(th), 0.], [np.sin(th), np.cos(th), 0.], [0., 0., 1.]])
+        flags = tree_map(lambda a: False, copy.deepcopy(values))
+        flags["plastic"]["flow stress"]["initial yield"]["Y"] = True
+        for name in ("sp_13", "dp_23", "dp_66", "a"):
+            flags["plastic"]["effective stress"]["barlat"][name] = True
+    else:
+        values, net, _ = pc.nn_hardening_values(hidden=[4, 3] if kind.endswith("deep") else None)
+        kw["hardening_funs"] = {"neural network": net.evaluate}
+        flags = tree_map(lambda a: False, copy.deepcopy(values))
+        flags["plastic"]["flow stress"] = tree_map(lambda a: True, flags["plastic"]["flow stress"])
+    params = Parameters(values, flags, tree_map(lambda a: None, copy.deepcopy(values)))
+    F = plane_stress_F(0.02, 3)
+    model = model_cls(params, DefType.PLANE_STRESS, **kw)
+    n = F.shape[2]
+    t = np.linspace(0.0, 1.0, n)
+    data = np.zeros((3, 3, n))
+    data[0, 0] = 260.0 * np.tanh(4 * t); data[1, 1] = 180.0 * t; data[0, 1] = data[1, 0] = 15.0 * np.sin(3 * t)
+    weight = np.zeros((3, 3)); weight[0, 0] = weight[1, 1] = 1.; weight[0, 1] = weight[1, 0] = 0.7
+    return model, Calibration(model, data.astype(complex) if is_complex else data, weight), F
+
+
+def check_complex_step_extended(model_cls, kind):
+    """`Model(..., is_complex=True)` on the configurations the reference's own complex-step test does not reach (its
+    `is_complex` is a constructor flag of every configuration, cmad/models/small_elastic_plastic.py:90,118-127): Barlat, the
+    network surfaces, the network hardening law, with perturbed leaves outside the 12 native kernel parameters (Barlat
+    coefficients, rotation matrix, network weights).  Im J(p + i h d) / h at h = 1e-20 -- no derivative code at all -- equals
+    d . grad J of the REAL model's adjoint objective to round-off, and Re J is the real objective."""
+    from cmad_amd.models import mp_U_from_F, newton_solve
+    from cmad_amd.objectives import MPAdjointObjective
+    model, qoi, F = complex_step_problem(model_cls, kind, False)
+    model_c, qoi_c, _ = complex_step_problem(model_cls, kind, True)
+    assert model_c.dtype is complex
+    x = model.parameters.flat_active_values(True)
+    ra = MPAdjointObjective(qoi, F).evaluate(x)
+
+    def J_complex(flat_complex):
+        model_c.parameters.set_active_values_from_flat(flat_complex, is_complex=True)
+        model_c.set_xi_to_init_vals()
+        acc = 0.0 + 0.0j
+        for step in range(1, F.shape[2]):
+            model_c.gather_global(mp_U_from_F(F[:, :, step]), mp_U_from_F(F[:, :, step - 1]))
+            newton_solve(model_c, max_iters=30)
+            qoi_c.evaluate(step)
+            acc = acc + qoi_c.J()
+            model_c.advance_xi()
+        return complex(acc)
+
+    J0 = J_complex(x.astype(complex))
+    assert J0.imag == 0.0 and abs(J0.real - ra.J) <= 1e-9 * abs(ra.J)
+    rng = np.random.default_rng(22)
+    h = 1e-20
+    for _ in range(2):
+        d = rng.uniform(-1.0, 1.0, size=x.size)
+        Jc = J_complex(x.astype(complex) + 1j * h * d)
+        assert abs(Jc.real - ra.J) <= 1e-9 * abs(ra.J)
+        np.testing.assert_allclose(Jc.imag / h, d @ ra.grad, rtol=1e-7, atol=1e-9 * np.abs(ra.grad).max())
+    # one leaf at a time: every active entry's perturbation reaches the kernel (none is dropped on the way)
+    for k in range(x.size):
+        e = np.zeros(x.size); e[k] = 1.0
+        np.testing.assert_allclose(J_complex(x.astype(complex) + 1j * h * e).imag / h, ra.grad[k], rtol=1e-6,
+                                   atol=1e-9 * np.abs(ra.grad).max(), err_msg=f"active parameter {k}")
 
 
 def _same_structure(a, b):

@@ -1014,3 +1014,14 @@ def test_complex_step_model_instances(rate, scale_params):
     from cmad_amd.models import SmallElasticPlastic, SmallRateElasticPlastic
     from problems import check_complex_step
     check_complex_step(SmallRateElasticPlastic if rate else SmallElasticPlastic, scale_params, num_pts_per_increment=25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["barlat", "network", "network scaled deep", "hardening network deep"])
+def test_complex_step_instances_on_dense_surfaces_and_extended_leaves(kind):
+    """`is_complex=True` is a constructor flag of every configuration in the reference (small_elastic_plastic.py:90,118-127):
+    Barlat, the network surfaces (plain; beta-rescaled around two hidden layers) and the deep network hardening law, with
+    perturbed Barlat coefficients / rotation matrix / network weights, on cm_update_complex."""
+    from cmad_amd.models import SmallElasticPlastic
+    from problems import check_complex_step_extended
+    check_complex_step_extended(SmallElasticPlastic, kind)

@@ -450,13 +450,14 @@ def test_second_derivatives_network_surfaces(def_type, scaled):
     pc.check_second_derivs_network(gpu_api.hessians, def_type, scaled=scaled)
 
 
+@pytest.mark.parametrize("scaled", [False, True])
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS])
-def test_multi_layer_network_sensitivities(def_type):
-    """Two hidden layers: weight sensitivities (cm_param_blocks; extended-parameter index = position in the weight blob)
-    against central differences of the oracle, second derivatives against its nested duals."""
+def test_multi_layer_network_sensitivities(def_type, scaled):
+    """Two hidden layers (plain and beta-rescaled surface): weight sensitivities (cm_param_blocks; extended-parameter index =
+    position in the weight blob) against central differences of the oracle, second derivatives against its nested duals."""
     import gpu_api
-    pc.check_param_blocks_network(gpu_api.param_blocks, def_type, layer_widths=(6, 7, 5, 1))
-    pc.check_second_derivs_network(gpu_api.hessians, def_type, layer_widths=(6, 7, 5, 1))
+    pc.check_param_blocks_network(gpu_api.param_blocks, def_type, scaled=scaled, layer_widths=(6, 7, 5, 1))
+    pc.check_second_derivs_network(gpu_api.hessians, def_type, scaled=scaled, layer_widths=(6, 7, 5, 1))
 
 
 @pytest.mark.parametrize("def_type", [ol.FULL_3D, ol.PLANE_STRESS, ol.UNIAXIAL_STRESS])

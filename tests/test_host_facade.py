@@ -370,16 +370,30 @@ def test_hardening_funs_is_the_reference_lookup_table():
     assert model._hardening_nn is None
 
 
-def test_complex_perturbation_outside_the_native_parameters_is_refused():
-    """`cm_update_complex` carries the imaginary parts of the 12 native kernel parameters; a complex perturbation of the
-    rotation matrix must raise instead of reading as a zero directional derivative."""
+def test_complex_perturbations_of_every_leaf_are_carried():
+    """`cm_update_complex` takes the imaginary parts of the 12 native kernel parameters by value and those of every other leaf
+    (rotation matrix, Barlat coefficients, network weights) in the extended array, indexed like `leaf_ep_index`: nothing is
+    dropped on the way (a dropped perturbation would read as a zero directional derivative)."""
     import copy
-    from cmad_amd.models.device import complex_native_parameters
+    from cmad_amd.models.device import EP_Q0, EP_YC6, build_desc, complex_parameter_parts, real_tree
+    from cmad_amd.parameters import Parameters
+    from cmad_amd.parameters.parameters import tree_map
     from cmad_amd.synthetic import j2_voce_values
     values = copy.deepcopy(j2_voce_values())
     values["plastic"]["flow stress"]["initial yield"]["Y"] = 200. + 1e-20j
-    kp = complex_native_parameters(values, "J2")
-    assert kp[2].imag == 1e-20 and kp[0].imag == 0.0
-    values["rotation matrix"] = np.eye(3) + 1e-20j * np.ones((3, 3))
-    with pytest.raises(NotImplementedError):
-        complex_native_parameters(values, "J2")
+    values["rotation matrix"] = np.eye(3) + 1e-20j * np.arange(9.).reshape(3, 3)
+    real = real_tree(values)                                # (the tree's key paths do not depend on the dtype of its leaves)
+    params = Parameters(real, tree_map(lambda a: False, copy.deepcopy(real)), tree_map(lambda a: None, copy.deepcopy(real)))
+    _, info = build_desc(real)
+    p_im, ext = complex_parameter_parts(values, params.flat_paths(), info)
+    assert p_im[2] == 1e-20 and p_im[0] == 0.0
+    assert ext.shape == (22,) and not ext[:EP_Q0 - EP_YC6].any()
+    np.testing.assert_array_equal(ext[EP_Q0 - EP_YC6:], 1e-20 * np.arange(9.))
+    values["rotation matrix"] = np.eye(3)
+    assert complex_parameter_parts(values, params.flat_paths(), info)[1] is None           # nothing beyond the native 12: no array
+
+
+@pytest.mark.parametrize("kind", ["barlat", "network", "network scaled deep", "hardening network deep"])
+def test_complex_step_instances_on_dense_surfaces_and_extended_leaves(kind):
+    from problems import check_complex_step_extended
+    check_complex_step_extended(HostSmallElasticPlastic, kind)

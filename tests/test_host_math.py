@@ -608,8 +608,9 @@ def test_hybrid_surface_with_a_multi_layer_network(def_type, solver_variant):
     pc.check_hybrid_nn(BACKEND, def_type, B=96, rot=(def_type == ol.PLANE_STRESS), widths=DEEP)
     pc.check_hybrid_nn(BACKEND, def_type, B=64, rot=(def_type == ol.PLANE_STRESS), widths=DEEP, scaled=True)     # beta-rescaled around it
     if solver_variant == "structured":
-        pc.check_param_blocks_network(hh.param_blocks, def_type, layer_widths=DEEP)
-        pc.check_second_derivs_network(hh.hessians, def_type, layer_widths=DEEP)
+        for scaled in (False, True):
+            pc.check_param_blocks_network(hh.param_blocks, def_type, scaled=scaled, layer_widths=DEEP)
+            pc.check_second_derivs_network(hh.hessians, def_type, scaled=scaled, layer_widths=DEEP)
 
 
 @pytest.mark.parametrize("yield_kind,kw", pc.YIELDS)
