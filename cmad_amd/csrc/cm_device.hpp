@@ -1097,6 +1097,36 @@ CM_D Hard hardening(const cm_model_desc& m, double alpha) {
     return h;
 }
 
+// ---- single-precision seeds ---------------------------------------------------------------------------------------------------
+// The scalar return maps that warm-start the local Newton (cm_structured.hpp, newton<> below) first run a few steps in float:
+// 1/x, 1/sqrt(x), e^x and log(x) are ONE instruction each there (v_rcp_f32, v_rsq_f32, v_exp_f32, v_log_f32 against 5 / 7 / 22 /
+// ~30 in double), and a seed good to 1e-6 leaves the double-precision loop one or two quadratically converging steps.  Nothing of
+// it reaches the result except as a starting point: the map is polished in double and then checked by the reference's Newton.
+#if defined(CM_HOST_BUILD)
+CM_D float rcp_f(float a) { return 1.0f / a; }
+CM_D float rsq_f(float a) { return 1.0f / std::sqrt(a); }
+CM_D float exp_f(float a) { return std::exp(a); }
+CM_D float log_f(float a) { return std::log(a); }
+#else
+CM_D float rcp_f(float a) { return __builtin_amdgcn_rcpf(a); }
+CM_D float rsq_f(float a) { return __builtin_amdgcn_rsqf(a); }
+CM_D float exp_f(float a) { return __builtin_amdgcn_exp2f(a * 1.4426950408889634f); }
+CM_D float log_f(float a) { return __builtin_amdgcn_logf(a) * 0.6931471805599453f; }
+#endif
+// the Voce / linear hardening laws in float (the network law has no seed: hardening_seed_ok)
+struct HardF { float H, dH; };
+CM_D bool hardening_seed_ok(const cm_model_desc& m) { return CM_HNN == 0 || m.hnn_width <= 0; }     // uniform
+CM_D HardF hardening_f(const cm_model_desc& m, float alpha) {
+    HardF h; h.H = 0.0f; h.dH = 0.0f;
+    if (m.has_voce) {
+        const float S = (float)m.voce_S, D = (float)m.voce_D, e = exp_f(-D * alpha);
+        h.H += S * (1.0f - e);
+        h.dH += S * D * e;
+    }
+    if (m.has_linear) { h.H += (float)m.lin_K * alpha; h.dH += (float)m.lin_K; }
+    return h;
+}
+
 // Cel a = 2 mu a + lambda (a0+a3+a5) d
 CM_D void apply_cel(const cm_model_desc& m, const double a[6], double out[6]) {
     const double t = m.lambda * (a[0] + a[3] + a[5]), twomu = 2.0 * m.mu;

@@ -550,30 +550,85 @@ CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const d
     const bool m0 = (t0 >= t1) && (t0 >= t2), m1 = !m0 && (t1 >= t2), m2 = !m0 && !m1;
     const bool j0 = (m1 && t0 >= t2) || (m2 && t0 >= t1), j1 = (m0 && t1 >= t2) || (m2 && !(t0 >= t1)), j2 = !(m2 || j0 || j1);
     const double dm = m0 ? t0 : (m1 ? t1 : t2), dj = j0 ? t0 : (j1 ? t1 : t2);
-    const double ia = rcp(a), ia1 = rcp(a - 1.0), ap = a * ia1, mu = m.mu;
-    const double kf = exp_s<false>(-0.6931471805599453 * ia), c = 2.0 * kf;    // 2^(-1/a): phi = kf |d_m| on a face; q_m = c there
-    // return onto the hexagon: face (one scalar equation), then -- when the second difference overtakes the first on the way --
-    // the corner (both faces active: dgam from the sum of the two equations, the split from their difference).  Two Newton
-    // steps on the face (the first with the hardening already evaluated at alpha_prev), one on the corner from there with the
-    // flow stress linearised: three exponentials in all for a start that the iteration below only has to polish
-    double g = -(kf * dm - (m.Y + hp.H)) * rcp(-twomu * c * kf - hp.dH);
-    const Hard h1 = hardening(m, alpha_p + g);
-    const double g1 = g;
-    g = fmax(g - (kf * (dm - twomu * c * g) - (m.Y + h1.H)) * rcp(-twomu * c * kf - h1.dH), 0.0);
-    const double phi_f = m.Y + h1.H + h1.dH * (g - g1);                         // flow stress at the face solution (linearised)
-    const bool corner = mu * c * g > dm - dj;
-    const double gc = fmax(g - (dm + dj - 6.0 * mu * g - 2.0 * phi_f) * rcp(-6.0 * mu - 2.0 * h1.dH), 1e-300);
-    const double half_split = 0.5 * (dm - dj) * rcp(mu * gc);                  // (q_m - q_j) / 2 at the corner, q_m + q_j = 2
-    double gam = corner ? gc : g;
-    // q_j: the corner's split, or (face) what the second difference reaches at the face solution, r_j^(a-1).  Between the two
-    // regimes -- the second difference ends within a few per cent of phi -- the face value overshoots (it ignores the flow q_j
-    // itself causes) and the corner's split is about zero or below: start at 0.05 there (true values 0.01 .. 0.3)
-    const double qj_c = fmin(fmax(1.0 - half_split, 0.05), 1.0);
-    const double rj_f = fmin(fmax((dj - mu * c * g) * rcp(phi_f), 1e-300), 1.0);
-    const double wj_face = fmax(log_pos(rj_f) * (a - 1.0), -700.0), wj_cap = log_pos(qj_c);
-    const bool capped = !corner && (wj_face > wj_cap);
-    double wj = (corner || capped) ? wj_cap : wj_face;
-    double wm = log_pos(corner ? 2.0 - qj_c : (capped ? c - 0.9 * qj_c : c));
+    const double ia1 = rcp(a - 1.0), ap = a * ia1, mu = m.mu;
+    double gam, wj, wm;
+    if (hardening_seed_ok(m)) {
+        // The start in float (cm_device.hpp, "single-precision seeds"; exponentials and logarithms are one instruction each
+        // there): the return onto the hexagon -- face (one scalar equation: two Newton steps), then, when the second
+        // difference overtakes the first on the way, the corner (both faces active: dgam from the sum of the two equations, the
+        // split from their difference; flow stress linearised) -- followed by Newton steps on the three equations themselves
+        // until they hold to 1e-4; the double-precision loop below then needs one or two steps.
+        const float af = (float)a, ia1f = (float)ia1, apf = (float)ap, muf = (float)mu, twomuf = 2.0f * muf;
+        const float dmf = (float)dm, djf = (float)dj, Yf = (float)m.Y, alf = (float)alpha_p;
+        const float kf = exp_f(-0.6931471805599453f * rcp_f(af)), c = 2.0f * kf;   // 2^(-1/a): phi = kf |d_m| on a face; q_m = c there
+        const HardF hq = hardening_f(m, alf);
+        float g = -(kf * dmf - (Yf + hq.H)) * rcp_f(-twomuf * c * kf - hq.dH);
+        const HardF h1 = hardening_f(m, alf + g);
+        const float g1 = g;
+        g = fmaxf(g - (kf * (dmf - twomuf * c * g) - (Yf + h1.H)) * rcp_f(-twomuf * c * kf - h1.dH), 0.0f);
+        const float phi_f = Yf + h1.H + h1.dH * (g - g1);                       // flow stress at the face solution (linearised)
+        const bool corner = muf * c * g > dmf - djf;
+        const float gc = fmaxf(g - (dmf + djf - 6.0f * muf * g - 2.0f * phi_f) * rcp_f(-6.0f * muf - 2.0f * h1.dH), 1e-30f);
+        const float half_split = 0.5f * (dmf - djf) * rcp_f(muf * gc);          // (q_m - q_j) / 2 at the corner, q_m + q_j = 2
+        float gf = corner ? gc : g;
+        // q_j: the corner's split, or (face) what the second difference reaches at the face solution, r_j^(a-1).  Between the two
+        // regimes -- the second difference ends within a few per cent of phi -- the face value overshoots (it ignores the flow
+        // q_j itself causes) and the corner's split is about zero or below: start at 0.05 there (true values 0.01 .. 0.3)
+        const float qj_c = fminf(fmaxf(1.0f - half_split, 0.05f), 1.0f);
+        const float rj_f = fminf(fmaxf((djf - muf * c * g) * rcp_f(phi_f), 1e-30f), 1.0f);
+        const float wj_face = fmaxf(log_f(rj_f) * (af - 1.0f), -80.0f), wj_cap = log_f(qj_c);
+        const bool capped = !corner && (wj_face > wj_cap);
+        float wjf = (corner || capped) ? wj_cap : wj_face;
+        float wmf = log_f(corner ? 2.0f - qj_c : (capped ? c - 0.9f * qj_c : c));
+        bool sdone = !(active && gf > 0.0f);
+        for (int it = 0; it < 8; ++it) {
+            const float rm = exp_f(wmf * ia1f), qm = exp_f(wmf), qj = exp_f(wjf), rj = exp_f(wjf * ia1f);
+            const HardF h = hardening_f(m, alf + gf);
+            const float phi = Yf + h.H, mg = muf * gf;
+            const float Rm = phi * rm - dmf + mg * (2.0f * qm + qj), Rj = phi * rj - djf + mg * (2.0f * qj + qm);
+            const float Rn = qm * rm + qj * rj - 2.0f;
+            const float res = fmaxf(fmaxf(fabsf(Rm), fabsf(Rj)) * rcp_f(dmf), fabsf(Rn));
+            if (!(res >= 1e-4f)) sdone = true;                                  // (also: not finite)
+            if (!sdone) {
+                const float J00 = phi * rm * ia1f + 2.0f * mg * qm, J01 = mg * qj, J02 = h.dH * rm + muf * (2.0f * qm + qj);
+                const float J10 = mg * qm, J11 = phi * rj * ia1f + 2.0f * mg * qj, J12 = h.dH * rj + muf * (2.0f * qj + qm);
+                const float J20 = apf * qm * rm, J21 = apf * qj * rj;
+                const float c00 = -J12 * J21, c01 = J12 * J20, c02 = J10 * J21 - J11 * J20;
+                const float idet = rcp_f(J00 * c00 + J01 * c01 + J02 * c02);
+                const float dwm = (Rm * c00 + J01 * (J12 * Rn) + J02 * (Rj * J21 - J11 * Rn)) * idet;
+                const float dwj = (J00 * (-J12 * Rn) + Rm * c01 + J02 * (J10 * Rn - Rj * J20)) * idet;
+                const float dgm = (J00 * (J11 * Rn - Rj * J21) + J01 * (Rj * J20 - J10 * Rn) + Rm * c02) * idet;
+                wmf = fminf(fmaxf(wmf - dwm, -3.0f), 0.75f);
+                gf = fmaxf(gf - dgm, 1e-3f * gf);
+                // a large step that LOWERS q_j is taken in the variable q_j (see the loop below)
+                wjf = fmaxf(wjf + ((dwj > 0.25f) ? log_f(fmaxf(1.0f - dwj, 0.05f)) : fminf(-dwj, 2.0f)), -80.0f);
+            }
+            if (!__any(!sdone)) break;
+        }
+        const bool fin = (gf > 0.0f) && (gf < 1e30f) && (wmf > -4.0f) && (wjf > -90.0f);   // finite (a NaN fails every comparison)
+        gam = fin ? (double)gf : 0.0;                                           // (0: the lane leaves the warm start below)
+        wj = fin ? (double)wjf : 0.0;
+        wm = fin ? (double)wmf : 0.0;
+    } else {
+        const double ia = rcp(a);
+        const double kf = exp_s<false>(-0.6931471805599453 * ia), c = 2.0 * kf;    // 2^(-1/a): phi = kf |d_m| on a face; q_m = c there
+        // return onto the hexagon in double (the network hardening law has no float twin): see above
+        double g = -(kf * dm - (m.Y + hp.H)) * rcp(-twomu * c * kf - hp.dH);
+        const Hard h1 = hardening(m, alpha_p + g);
+        const double g1 = g;
+        g = fmax(g - (kf * (dm - twomu * c * g) - (m.Y + h1.H)) * rcp(-twomu * c * kf - h1.dH), 0.0);
+        const double phi_f = m.Y + h1.H + h1.dH * (g - g1);
+        const bool corner = mu * c * g > dm - dj;
+        const double gc = fmax(g - (dm + dj - 6.0 * mu * g - 2.0 * phi_f) * rcp(-6.0 * mu - 2.0 * h1.dH), 1e-300);
+        const double half_split = 0.5 * (dm - dj) * rcp(mu * gc);
+        gam = corner ? gc : g;
+        const double qj_c = fmin(fmax(1.0 - half_split, 0.05), 1.0);
+        const double rj_f = fmin(fmax((dj - mu * c * g) * rcp(phi_f), 1e-300), 1.0);
+        const double wj_face = fmax(log_pos(rj_f) * (a - 1.0), -700.0), wj_cap = log_pos(qj_c);
+        const bool capped = !corner && (wj_face > wj_cap);
+        wj = (corner || capped) ? wj_cap : wj_face;
+        wm = log_pos(corner ? 2.0 - qj_c : (capped ? c - 0.9 * qj_c : c));
+    }
     active = active && (gam > 0.0);
     bool done = !active, ok = false;
     for (int it = 0; it < kHosfordWarmMaxIt; ++it) {
@@ -679,6 +734,47 @@ CM_D bool hill_warm_start(const cm_model_desc& m, const double eg[6], const doub
     if (!__any(active)) return true;
     double kap = 0.0, phi = phi_tr, y1 = yt1, y2 = yt2, u1 = 0.0, u2 = 0.0, s1 = s[1], s2 = s[2], s4 = s[4];
     bool done = !active, ok = false;
+    // Newton in c = lb kappa / (1 + lb kappa), lb = 3/2 (J2's eigenvalue of W^-1 A; Hill's lie around it): phi ~ phi_trial (1 - c)
+    // and dgam ~ c phi_trial / (2 mu lb) are nearly LINEAR in c (exactly so for J2 with linear hardening), where in kappa
+    // phi ~ 1 / (1 + lb kappa) is strongly convex and Newton from kappa = 0 creeps (6-7 steps against 3-5)
+    constexpr double lb = 1.5;
+    {   // kappa = 0: the trial state itself (B = I, the hardening at alpha_prev is already there)
+        u1 = A11 * yt1 + A12 * yt2; u2 = A12 * yt1 + A22 * yt2;
+        const double t1 = q.a11 * s[1], t2 = q.a22 * s[2], t4 = q.a44 * s[4];
+        const double iphi = (ph2_tr > 0.0) ? rcp(phi_tr) : 0.0;
+        const double dphi = -(u1 * u1 + u2 * u2 + 0.5 * (t1 * t1 + t2 * t2 + t4 * t4)) * iphi;
+        const double F = phi_tr - (m.Y + hp.H), dF = dphi - hp.dH * phi_tr * i2mu;
+        const double cn = fmin(fmax(-F * lb * rcp(dF), 0.0), 0.999999);
+        if (!done) kap = cn * rcp(lb * (1.0 - cn));
+    }
+    if (hardening_seed_ok(m)) {
+        // two Newton steps in float from there (cm_device.hpp, "single-precision seeds")
+        const float A11f = (float)A11, A12f = (float)A12, A22f = (float)A22, yt1f = (float)yt1, yt2f = (float)yt2;
+        const float h1f = (float)h1, h2f = (float)h2, h4f = (float)h4, s1t = (float)s[1], s2t = (float)s[2], s4t = (float)s[4];
+        const float a11f = (float)q.a11, a22f = (float)q.a22, a44f = (float)q.a44;
+        const float Yf = (float)m.Y, apf = (float)alpha_p, i2muf = (float)i2mu, lbf = (float)lb;
+        float kf = (float)kap;
+#pragma unroll
+        for (int sit = 0; sit < 2; ++sit) {
+            const float b11 = 1.0f + kf * A11f, b22 = 1.0f + kf * A22f, b12 = kf * A12f;
+            const float idet = rcp_f(b11 * b22 - b12 * b12);
+            const float z1 = (b22 * yt1f - b12 * yt2f) * idet, z2 = (b11 * yt2f - b12 * yt1f) * idet;
+            const float i1 = rcp_f(1.0f + kf * h1f), i2 = rcp_f(1.0f + kf * h2f), i4 = rcp_f(1.0f + kf * h4f);
+            const float r1 = s1t * i1, r2f = s2t * i2, r4 = s4t * i4;
+            const float w1 = A11f * z1 + A12f * z2, w2 = A12f * z1 + A22f * z2;
+            const float t1 = a11f * r1, t2 = a22f * r2f, t4 = a44f * r4;
+            const float ph2 = z1 * w1 + z2 * w2 + t1 * r1 + t2 * r2f + t4 * r4;
+            const float rph = rsq_f(ph2), ph = ph2 * rph;
+            const float v1 = (b22 * w1 - b12 * w2) * idet, v2 = (b11 * w2 - b12 * w1) * idet;
+            const float dph = -(w1 * v1 + w2 * v2 + 0.5f * (t1 * t1 * i1 + t2 * t2 * i2 + t4 * t4 * i4)) * rph;
+            const HardF h = hardening_f(m, apf + kf * ph * i2muf);
+            const float F = ph - (Yf + h.H), dF = dph - h.dH * (ph + kf * dph) * i2muf;
+            const float w = 1.0f + lbf * kf;
+            const float cn = lbf * kf * rcp_f(w) - F * lbf * rcp_f(dF * w * w);
+            if (cn >= 0.0f && cn < 0.999999f) kf = cn * rcp_f(lbf * (1.0f - cn));   // (a step out of the interval, or not finite, is dropped)
+        }
+        if (!done) kap = (double)kf;
+    }
     for (int it = 0; it < kHillWarmMaxIt; ++it) {
         const double b11 = 1.0 + kap * A11, b22 = 1.0 + kap * A22, b12 = kap * A12;
         const double idet = rcp(b11 * b22 - b12 * b12);
@@ -688,26 +784,21 @@ CM_D bool hill_warm_start(const cm_model_desc& m, const double eg[6], const doub
         u1 = A11 * y1 + A12 * y2; u2 = A12 * y1 + A22 * y2;
         const double t1 = q.a11 * s1, t2 = q.a22 * s2, t4 = q.a44 * s4;
         const double ph2 = y1 * u1 + y2 * u2 + t1 * s1 + t2 * s2 + t4 * s4;
-        phi = sqrt(fmax(ph2, 0.0));
-        const double iphi = (ph2 > 0.0) ? rcp(phi) : 0.0;
+        const double iphi = (ph2 > 0.0) ? rsqrt_pos(ph2) : 0.0;
+        phi = ph2 * iphi;
         // phi phi' = -u^T (I + kappa A2)^-1 u - 1/2 sum (a_kk s_k)^2 / (1 + kappa a_kk / 2)
         const double v1 = (b22 * u1 - b12 * u2) * idet, v2 = (b11 * u2 - b12 * u1) * idet;
         const double dphi = -(u1 * v1 + u2 * v2 + 0.5 * (t1 * t1 * i1 + t2 * t2 * i2 + t4 * t4 * i4)) * iphi;
         const Hard h = hardening(m, alpha_p + kap * phi * i2mu);
         const double F = phi - (m.Y + h.H), dF = dphi - h.dH * (phi + kap * dphi) * i2mu;
-        const double res = fabs(F) * rcp(phi_tr);
+        const double res = fabs(F);
         if (!done && !(res < 1e300)) done = true;
-        if (!done && res < 1e-14) { done = true; ok = true; }
-        const bool last = res < 1e-8;                              // quadratic convergence: the next iterate is converged to round-off
+        if (!done && res < 1e-14 * phi_tr) { done = true; ok = true; }
         if (!done) {
-            // Newton in c = lb kappa / (1 + lb kappa), lb = 3/2 (J2's eigenvalue of W^-1 A; Hill's lie around it): phi ~ phi_trial
-            // (1 - c) and dgam ~ c phi_trial / (2 mu lb) are nearly LINEAR in c (exactly so for J2 with linear hardening), where in
-            // kappa phi ~ 1 / (1 + lb kappa) is strongly convex and Newton from kappa = 0 creeps (6-7 steps against 3-5)
-            constexpr double lb = 1.5;
             const double w = 1.0 + lb * kap;
             const double cn = fmin(fmax(lb * kap * rcp(w) - F * lb * rcp(dF * w * w), 0.0), 0.999999);
             kap = cn * rcp(lb * (1.0 - cn));
-            if (last) { done = true; ok = true; }
+            if (res < 1e-8 * phi_tr) { done = true; ok = true; }   // quadratic convergence: this iterate is converged to round-off
         }
         if (!__any(!done)) break;
     }
@@ -867,17 +958,17 @@ CM_D uint32_t newton_j2_plane(const cm_model_desc& m, const double eg[6], const 
         // q = t / (1 + g), the sigma_33 row is LINEAR in t for a given g,
         //     t(g) = -(z:a / (1 + g) + Kz tr0) / (z:b / (1 + g) + Kz tr z) ,
         // and what is left is one scalar equation in g = dgam 3 mu / phi (g = 0: the elastic step, whose stretch is t(0)):
-        //     F(g) = sqrt6 mu sqrt(S) / (1 + g) - Y - H(alpha_prev + g sqrt(S) / (c (1 + g))) ,  S = |a + t b|^2 ,  c = 3 / sqrt6 .
-        // ~70 instead of ~150 instructions per step, and an elastic point needs none.  The loop below then starts at the mapped
+        //     F(g) = sqrt6 mu sqrt(S) / (1 + g) - Y - H(alpha_prev + g sqrt(S) / (k (1 + g))) ,  S = |a + t b|^2 ,  k = 3 / sqrt6 .
+        // ~80 instead of ~150 instructions per step (two of them in float), and an elastic point needs none.  The loop below then starts at the mapped
         // state: it evaluates the plane's residual there and applies the reference's convergence test (relative tolerance against
         // ||C(x_prev)||, computed here from the state at x_prev), so a converged map costs one evaluation; otherwise the plane's
         // Newton continues from it (the Jacobian maps the plane to itself wherever the iterate sits in it).
         const double tp = t;
         bool plastic_prev, conv_prev;
+        const Hard h0 = hardening(m, alpha_p);
         {   // ||C(x_prev)||^2 = C6^2 + C7^2 (r_a = r_b = 0 at c = 0, dgam = 0)
             const double P0 = aa + 2.0 * tp * ab + tp * tp * bb;
-            const double phi0 = sqrt6mu * sqrt(fmax(P0, 0.0));
-            const Hard h0 = hardening(m, alpha_p);
+            const double phi0 = sqrt6mu * ((P0 > 0.0) ? P0 * rsqrt_pos(P0) : 0.0);
             const double f0 = (phi0 - (m.Y + h0.H)) * i2mu;
             plastic_prev = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
             const double c6 = plastic_prev ? f0 : 0.0;
@@ -886,55 +977,71 @@ CM_D uint32_t newton_j2_plane(const cm_model_desc& m, const double eg[6], const 
             first = false;
             conv_prev = (c6 * c6 + c7 * c7) < abs2;
         }
-        constexpr double c32 = 1.224744871391589;
-        double g = 0.0, tg = 0.0, Rg = 0.0;
+        // The map in c = g / (1 + g) (= c_a of the plane): 1 / (1 + g) = 1 - c, so with w = 1 - c
+        //     t(c) = -(z:a w + Kz tr0) / (z:b w + Kz tr z) ,  phi = sqrt6 mu R w ,  dgam = c R / (3 / sqrt6) ,  R = sqrt(S(t(c)))
+        // -- phi ~ phi(0) (1 - c) and dgam ~ c phi(0) / 3 mu are nearly linear in c (in g, phi ~ 1 / (1 + g) is strongly convex and
+        // Newton from g = 0 creeps: 6-7 steps against 3-4), and no division by 1 + g is left.  ~80 instructions per step.
+        constexpr double ic32 = 0.816496580927726;                  // sqrt6 / 3
+        const double n0 = Kz * tr0, d0 = Kz * trz;
+        double c = 0.0;
         // (a state that already passes the reference's test at x_prev is returned as it is, 0 iterations: re-applying a strain
         // to its own result changes nothing, bit for bit)
         bool done = !lane_valid || conv_prev, ok = false;
-        for (int wit = 0; wit < 12; ++wit) {
-            const double i1g = rcp(1.0 + g);
-            const double N = za * i1g + Kz * tr0, D = zb * i1g + Kz * trz, iD = rcp(D);
-            const double tn = -N * iD;
-            const double dt = (za * D - N * zb) * (i1g * i1g) * (iD * iD);
+        {   // c = 0: the elastic step (stretch t(0)); the hardening there is the one at alpha_prev
+            const double iD = rcp(zb + d0), N = za + n0;
+            const double tn = -N * iD, dt = (za * (zb + d0) - N * zb) * (iD * iD);
             const double S = aa + 2.0 * tn * ab + tn * tn * bb, dS = 2.0 * (ab + tn * bb) * dt;
-            const double rS = (S > 0.0) ? rsqrt_pos(S) : 0.0;
-            const double Rn = S * rS;
+            const double rS = (S > 0.0) ? rsqrt_pos(S) : 0.0, R = S * rS, dR = 0.5 * dS * rS;
+            const double F = sqrt6mu * R - (m.Y + h0.H), dF = sqrt6mu * (dR - R) - h0.dH * (R * ic32);
+            // Elastic step: taken only when the state at x_prev -- with the OLD stretch -- is on the elastic branch too: a point
+            // that is plastic there but elastic once the stretch relaxes has two roots of the reference's residual (the elastic
+            // one and one on the plastic branch with dgam < 0), and which of them the reference's iteration from x_prev ends in
+            // is decided by its iterates -- such a lane starts at x_prev and retraces them.
+            if (!done && !(F > 0.0)) { done = true; ok = !plastic_prev; }
+            if (!done) c = fmin(fmax(-F * rcp(dF), 0.0), 0.999999);
+        }
+        if (__any(!done) && hardening_seed_ok(m)) {
+            // two Newton steps in float from there (see cm_device.hpp, "single-precision seeds")
+            const float zaf = (float)za, zbf = (float)zb, n0f = (float)n0, d0f = (float)d0, aaf = (float)aa, abf = (float)ab, bbf = (float)bb;
+            const float s6f = (float)sqrt6mu, Yf = (float)m.Y, apf = (float)alpha_p;
+            float cf = (float)c;
+#pragma unroll
+            for (int sit = 0; sit < 2; ++sit) {
+                const float w = 1.0f - cf, N = zaf * w + n0f, D = zbf * w + d0f, iD = rcp_f(D);
+                const float tn = -N * iD, dt = (zaf * D - N * zbf) * (iD * iD);
+                const float S = aaf + 2.0f * tn * abf + tn * tn * bbf, dS = 2.0f * (abf + tn * bbf) * dt;
+                const float rS = rsq_f(S), R = S * rS, dR = 0.5f * dS * rS;
+                const HardF h = hardening_f(m, apf + cf * R * (float)ic32);
+                const float F = s6f * R * w - (Yf + h.H), dF = s6f * (dR * w - R) - h.dH * ((R + cf * dR) * (float)ic32);
+                const float cn = cf - F * rcp_f(dF);
+                if (cn >= 0.0f && cn < 0.999999f) cf = cn;          // (a step that leaves the interval, or is not finite, is dropped)
+            }
+            if (!done) c = (double)cf;
+        }
+        for (int wit = 0; wit < 12; ++wit) {
+            const double w = 1.0 - c, N = za * w + n0, D = zb * w + d0, iD = rcp(D);
+            const double tn = -N * iD, dt = (za * D - N * zb) * (iD * iD);
+            const double S = aa + 2.0 * tn * ab + tn * tn * bb, dS = 2.0 * (ab + tn * bb) * dt;
+            const double rS = (S > 0.0) ? rsqrt_pos(S) : 0.0, R = S * rS, dR = 0.5 * dS * rS;
+            const Hard h = hardening(m, alpha_p + c * R * ic32);
+            const double YH = m.Y + h.H;
+            const double F = sqrt6mu * R * w - YH, dF = sqrt6mu * (dR * w - R) - h.dH * ((R + c * dR) * ic32);
+            const double res = fabs(F);
+            if (!done && !(res < 1e300)) done = true;
+            if (!done && res < 1e-14 * YH) { done = true; ok = true; }
             // a lane that has finished keeps what it finished with: its result must not depend on how long the other lanes of
             // its wavefront keep iterating (a batch gives the same bits however it is sliced into launches)
-            if (!done) { tg = tn; Rg = Rn; }
-            const double dR = 0.5 * dS * rS;
-            const double phi_g = sqrt6mu * Rn * i1g, dphi = sqrt6mu * (dR * i1g - Rn * i1g * i1g);
-            const double dgam = g * Rn * i1g * (1.0 / c32), ddg = ((Rn + g * dR) * i1g - g * Rn * i1g * i1g) * (1.0 / c32);
-            const Hard h = hardening(m, alpha_p + dgam);
-            const double F = phi_g - (m.Y + h.H), dF = dphi - h.dH * ddg;
-            // Elastic step: g = 0, t = t(0).  Taken only when the state at x_prev -- with the OLD stretch -- is on the elastic
-            // branch too: a point that is plastic there but elastic once the stretch relaxes has two roots of the reference's
-            // residual (the elastic one and one on the plastic branch with dgam < 0), and which of them the reference's iteration
-            // from x_prev ends in is decided by its iterates -- such a lane starts at x_prev and retraces them.
-            if (!done && wit == 0 && !(F > 0.0)) { done = true; ok = !plastic_prev; }
-            const double res = fabs(F) * rcp(m.Y + h.H);
-            if (!done && !(res < 1e300)) done = true;
-            if (!done && res < 1e-14) { done = true; ok = true; }
-            const bool last = res < 1e-8;                      // quadratic convergence: the next iterate is converged to round-off
             if (!done) {
-                // Newton in c = g / (1 + g) (= c_a): phi ~ phi(0) (1 - c) and dgam ~ c phi(0) / 3 mu are nearly linear in it -- in g,
-                // phi ~ 1 / (1 + g) is strongly convex and Newton from g = 0 creeps (6-7 steps against 3-4)
-                const double cn = fmin(fmax(g * i1g - F * rcp(dF) * (i1g * i1g), 0.0), 0.999999);
-                g = cn * rcp(1.0 - cn);
-                if (last) {
-                    done = true; ok = true;
-                    const double j1g = rcp(1.0 + g);
-                    tg = -(za * j1g + Kz * tr0) * rcp(zb * j1g + Kz * trz);
-                    const double S2 = aa + 2.0 * tg * ab + tg * tg * bb;
-                    Rg = sqrt(fmax(S2, 0.0));
-                }
+                c = fmin(fmax(c - F * rcp(dF), 0.0), 0.999999);
+                if (res < 1e-8 * YH) { done = true; ok = true; }    // quadratic convergence: this iterate is converged to round-off
             }
             if (!__any(!done)) break;
         }
         if (ok) {
-            const double i1g = rcp(1.0 + g);
-            ca = g * i1g; cb = tg * g * i1g; t = tg;
-            alpha = alpha_p + g * Rg * i1g * (1.0 / c32);
+            const double w = 1.0 - c, tg = -(za * w + n0) * rcp(zb * w + d0);
+            const double S = aa + 2.0 * tg * ab + tg * tg * bb, Rg = (S > 0.0) ? S * rsqrt_pos(S) : 0.0;
+            ca = c; cb = tg * c; t = tg;
+            alpha = alpha_p + c * Rg * ic32;
         }
     }
     double p, q, rP, phi, f, nsq;          // the evaluation at the current u: read after the loop (a stopped lane re-evaluates its unchanged u)
