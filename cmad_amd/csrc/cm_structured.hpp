@@ -704,6 +704,9 @@ CM_D bool hosford_warm_start(const cm_model_desc& m, const double eg[6], const d
 // (relative to ||C(x_prev)||), so a converged map costs one residual evaluation and anything else is finished by the general
 // iteration.  CM_SOLVER_GENERAL_NEWTON / CM_SOLVER_REFERENCE_ITERATES keep the iteration from x_prev.
 constexpr int kHillWarmMaxIt = 12;
+// (Tried for the hybrid Hill + network surface with the network term frozen at its trial value: on BASELINE configs[3] the
+// reference's Newton needs MORE iterations from that seed than from x_prev, 4.84 against 4.46 -- the network term bends the flow
+// direction too much for the Hill normal to be a useful start.  Not built.)
 CM_D bool hill_warm_start(const cm_model_desc& m, const double eg[6], const double* xp, double* x0, double& n0sq, bool lane_valid) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) x0[k] = xp[k];
