@@ -55,12 +55,19 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
         route = {name: kv["avg_us"]}
     entry["step_kernels_us"] = route
     step_us = sum(route.values())
+    # the same sums over the first 14 launches and over the launches from the 50th on (parse_profiles.py)
+    by_short = {short(k): v for k, v in kernels.items()}
+    part = {w: sum(by_short[k].get(w, float("nan")) for k in route) for w in ("first14_avg_us", "sustained_avg_us")}
+    entry.update({k: v for k, v in part.items() if v == v})
     if pts and bpu:
         entry["algorithmic_GBs_at_kernel_time"] = bpu * pts / (step_us * 1e-6) / 1e9
         entry["hbm_roof_frac_kernel_only"] = entry["algorithmic_GBs_at_kernel_time"] / 8000.0
+        for w, key in (("first14_avg_us", "hbm_roof_frac_first14"), ("sustained_avg_us", "hbm_roof_frac_sustained")):
+            if part[w] == part[w]:
+                entry[key] = bpu * pts / (part[w] * 1e-6) / 1e9 / 8000.0
         entry["bench_under_trace"] = {k: bench.get(k) for k in ("value", "ms_per_step")}
     c = {}
-    for sec in ("pmc_sq", "pmc_mix", "pmc_fetch", "pmc_write"):
+    for sec in ("pmc_sq", "pmc_mix32", "pmc_mix", "pmc_fetch", "pmc_write"):
         for k, v in d.get(sec, {}).items():
             if short(k) == name:
                 c.update({cn: cv["mean"] for cn, cv in v.items()})
@@ -93,6 +100,14 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
             entry["fp64_valu_roof_frac"] = entry["fp64_tflops"] / 78.6
             if c.get("SQ_WAVES"):
                 entry["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"]
+            # share of the VALU stream that is floating-point arithmetic: fp64 (FMA + MUL + ADD + TRANS) and, where the float pass
+            # ran, fp32 (the warm-start seeds)
+            if c.get("SQ_INSTS_VALU"):
+                f64 = sum(c.get(f"SQ_INSTS_VALU_{k}_F64", 0.0) for k in ("FMA", "MUL", "ADD", "TRANS"))
+                f32 = sum(c.get(f"SQ_INSTS_VALU_{k}_F32", 0.0) for k in ("FMA", "MUL", "ADD", "TRANS"))
+                entry["fp64_share_of_valu"] = f64 / c["SQ_INSTS_VALU"]
+                if "SQ_INSTS_VALU_FMA_F32" in c:
+                    entry["fp32_share_of_valu"] = f32 / c["SQ_INSTS_VALU"]
         if c.get("GRBM_GUI_ACTIVE"):
             # busy cycles summed over the 8 XCDs during the launch -> mean engine clock while the kernel ran (approximate: the
             # counter pass and the kernel-trace pass are different runs)
@@ -101,11 +116,13 @@ for f in sorted(glob.glob(f"gpurun_out/prof_{tag}_*/summary_{tag}_*.json")):
     co = entry["code_object"] or {}
     lines.append(f"{wl:16s} {name[len('void (anonymous namespace)::'):][:52]:52s} avg {kv['avg_us']:8.1f} us x{kv['calls']:3d} | "
                  f"{co.get('vgpr', '?')} vgpr ({co.get('agpr', '?')} acc) {co.get('scratch_bytes', '?')} B scratch {co.get('lds_bytes', '?')} B lds | "
-                 f"hbm roof {entry.get('hbm_roof_frac_kernel_only', float('nan')):.3f} | fp64 valu roof {entry.get('fp64_valu_roof_frac', float('nan')):.3f} | "
+                 f"hbm roof {entry.get('hbm_roof_frac_kernel_only', float('nan')):.3f} (first 14: {entry.get('hbm_roof_frac_first14', float('nan')):.3f}, "
+                 f"from launch 50: {entry.get('hbm_roof_frac_sustained', float('nan')):.3f}) | fp64 valu roof {entry.get('fp64_valu_roof_frac', float('nan')):.3f} | "
                  f"valu/wait/stall {entry.get('wave_cycle_split', {}).get('valu_active', float('nan')):.2f}/"
                  f"{entry.get('wave_cycle_split', {}).get('wait_any', float('nan')):.2f}/"
                  f"{entry.get('wave_cycle_split', {}).get('wait_inst_any', float('nan')):.2f} | lanes {entry.get('active_lane_fraction', float('nan')):.2f} | "
-                 f"traffic {entry.get('hbm_bytes_per_point', float('nan')):.1f} B/pt | {entry.get('valu_insts_per_wave', float('nan')):.0f} valu/wave | "
+                 f"traffic {entry.get('hbm_bytes_per_point', float('nan')):.1f} B/pt | {entry.get('valu_insts_per_wave', float('nan')):.0f} valu/wave "
+                 f"(fp64 {entry.get('fp64_share_of_valu', float('nan')):.2f} fp32 {entry.get('fp32_share_of_valu', float('nan')):.2f}) | "
                  f"~{entry.get('approx_engine_clock_GHz', float('nan')):.2f} GHz")
 os.makedirs("profiles", exist_ok=True)
 json.dump(out, open(f"profiles/{tag}_rocprof_summary.json", "w"), indent=1)

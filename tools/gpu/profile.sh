@@ -2,7 +2,9 @@
 # rocprofv3 kernel-trace stats + PMC passes (tools/profile_gpu.sh) of the twelve bench workloads of DESIGN.md section 6, in two
 # leases (six workloads each fit one gpurun call):
 #   gpurun --timeout 1190 -- 'bash tools/gpu/profile.sh <round tag> a'      then      ... b
-# afterwards, here: python tools/annotate_profiles.py <round tag>; python tools/make_traffic_json.py
+# afterwards, here: python tools/annotate_profiles.py <round tag>; python tools/make_traffic_json.py <summary> <kernel> <points>
+# (gpurun MERGES its output into gpurun_out/: remove an earlier session's gpurun_out/prof_<round tag>_* first, or a local re-run of
+# tools/parse_profiles.py averages the old CSVs in)
 R=${1:?round tag}; HALF=${2:?a or b}
 p() { bash tools/profile_gpu.sh "$@" > /dev/null || exit 1; }
 if [ "$HALF" == "a" ]; then

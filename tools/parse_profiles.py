@@ -36,14 +36,23 @@ for f in find("trace", "*kernel_trace.csv"):
     with open(f) as fh:
         for r in csv.DictReader(fh):
             key = (r.get("Kernel_Name", ""), int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0))
-            ktr[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            ktr[key].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
             meta[key] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
             meta[key]["Workgroup_Size"] = r.get("Workgroup_Size") or r.get("Workgroup_Size_X")
             meta[key]["Grid_Size"] = key[1]
 
 
-def stats(v):
-    return {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+def stats(tv):
+    """tv: (start timestamp, duration us) of every launch.  A back-to-back sequence of an fp64-heavy kernel dips in clock over its
+    launches ~3-30 and recovers (profiles/r04_sustained.txt): beside the plain average, the first 14 launches and -- for a
+    sequence of 100 or more -- the launches from the 50th on are averaged separately."""
+    v = [d for _, d in sorted(tv)]
+    out = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+    if len(v) >= 14:
+        out["first14_avg_us"] = sum(v[:14]) / 14
+    if len(v) >= 100:
+        out["sustained_avg_us"] = sum(v[50:]) / len(v[50:])
+    return out
 
 
 main_grid = {}
@@ -74,6 +83,7 @@ summary["pmc_fetch"] = pmc("pmc_fetch")
 summary["pmc_write"] = pmc("pmc_write")
 summary["pmc_sq"] = pmc("pmc_sq")
 summary["pmc_mix"] = pmc("pmc_mix")
+summary["pmc_mix32"] = pmc("pmc_mix32")
 for name in ("bench_trace.json", "bench_fetch.json"):
     try:
         with open(os.path.join(out_dir, name)) as fh:
