@@ -26,7 +26,7 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-NPARTS = 11         # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
+NPARTS = 12         # cmad_hip.hip compiles in independent pieces selected by -DCM_PART=k (see its header comment)
 
 
 def build(force=False, verbose=False, jobs=None):
@@ -45,9 +45,9 @@ def build(force=False, verbose=False, jobs=None):
            [[hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", f"-DCM_PART={k}", "-DCM_HNN_VARIANT=1", "-DCM_RATE_DENSE=0",
              "-DCM_RATE_UNIAXIAL_DENSE=0", "-c", src, "-o", objs[NPARTS + k]] for k in range(NPARTS)]
     jobs = jobs or min(NPARTS, os.cpu_count() or 1)
-    # longest compiles first (measured: the arithmetic-T parts 9 / 10 and the reverse-sweep part 5 of either build), every
+    # longest compiles first (measured: the arithmetic-T parts 9 - 11 and the reverse-sweep parts 5 / 6 of either build), every
     # free slot refilled as soon as ANY running compile ends
-    heavy = [NPARTS + 10, 10, NPARTS + 9, 9, 5, NPARTS + 5, 2, 1]
+    heavy = [NPARTS + 11, NPARTS + 10, 11, 10, NPARTS + 6, 5, NPARTS + 5, 9, NPARTS + 9, 2, 1]
     order = heavy + [k for k in range(2 * NPARTS) if k not in heavy]
     pending = [cmds[k] for k in order]
     procs, failed = [], []

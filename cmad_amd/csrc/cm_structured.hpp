@@ -392,15 +392,15 @@ struct PlainNorm {
 template <int YK, bool LS, int DEF = CM_FULL_3D, class NORM = PlainNorm>
 CM_D uint32_t newton_s(const cm_model_desc& m, const double eg[6], const double* xp, double* x, bool lane_valid,
                        EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}, const double* z = nullptr,
-                       const NORM norm = NORM{}, const double* x0 = nullptr, const double* n0sq_known = nullptr) {
+                       const NORM norm = NORM{}, const double* x0 = nullptr, double n0sq_known = -1.0) {
     constexpr int NX = Dims<DEF>::NX;
     double C[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) x[k] = x0 ? x0[k] : xp[k];
     residual_s<YK, DEF>(m, eg, z, x, xp, ev, C);
-    // squared-norm form of nonlinear_solver.py:140-150, see cm::newton.  n0sq_known: ||C(x_prev)||^2 when the iteration starts
+    // squared-norm form of nonlinear_solver.py:140-150, see cm::newton.  n0sq_known >= 0: ||C(x_prev)||^2 when the iteration starts
     // somewhere else (hosford_warm_start) -- the relative tolerance stays the reference's, measured against the residual at x_prev
-    const double n0sq = n0sq_known ? *n0sq_known : norm.template sq<NX>(C);
+    const double n0sq = (n0sq_known >= 0.0) ? n0sq_known : norm.template sq<NX>(C);      // (by value: a pointer would pin it to scratch)
     const double rel2 = m.rel_tol * m.rel_tol * n0sq, abs2 = m.abs_tol * m.abs_tol;
     int it = 0;
     bool running = lane_valid;
@@ -1218,15 +1218,15 @@ constexpr bool has_j2_subspace() {
 }
 // what the launchers test to pick the RL = true kernel variants (UNIAXIAL_STRESS needs no variant: its kernels always take the
 // 9 x 9 Newton step through the 4 x 4 form, uniaxial_solve in cm_device.hpp, which is the same step)
-// Hosford / FULL_3D: the reference's Newton started at the analytic warm start (hosford_warm_start) instead of x_prev
 template <int DEF, int YK, bool LS>
-constexpr bool has_hosford_warm_start() { return CM_HNN_BUILD_HAS_SUBSPACE && YK == CM_YIELD_HOSFORD && DEF == CM_FULL_3D; }
-// Hill / FULL_3D: the reference's Newton started at the scalar return map (hill_warm_start)
-template <int DEF, int YK, bool LS>
-constexpr bool has_hill_warm_start() { return CM_HNN_BUILD_HAS_SUBSPACE && YK == CM_YIELD_HILL && DEF == CM_FULL_3D; }
-template <int DEF, int YK, bool LS>
-constexpr bool has_fast_newton() {
-    return has_j2_subspace<DEF, YK, LS>() || has_hosford_warm_start<DEF, YK, LS>() || has_hill_warm_start<DEF, YK, LS>();
+constexpr bool has_fast_newton() { return has_j2_subspace<DEF, YK, LS>(); }
+// Hill / Hosford under FULL_3D: the reference's Newton started at a scalar return map (hill_warm_start) / the analytic warm start
+// (hosford_warm_start) instead of x_prev.  No kernel variant of their own: the same kernels read the description's switch
+// (warm_start_on, wave-uniform), so CM_SOLVER_REFERENCE_ITERATES costs a branch, not a second set of kernels.
+template <int DEF, int YK>
+constexpr bool has_warm_start() { return CM_HNN_BUILD_HAS_SUBSPACE && DEF == CM_FULL_3D && (YK == CM_YIELD_HILL || YK == CM_YIELD_HOSFORD); }
+CM_D bool warm_start_on(const cm_model_desc& m) {
+    return !(m.solver_flags & (CM_SOLVER_GENERAL_NEWTON | CM_SOLVER_REFERENCE_ITERATES)) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY);
 }
 template <int DEF, bool LS>
 CM_D uint32_t newton_j2_sub(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
@@ -1235,10 +1235,10 @@ CM_D uint32_t newton_j2_sub(const cm_model_desc& m, const double eg[6], const do
     if constexpr (DEF == CM_FULL_3D) return newton_j2_line<LS>(m, eg, xp, x, lane_valid, ev, stage);
     else return newton_j2_plane<LS>(m, eg, z, xp, x, lane_valid, ev, stage);
 }
-// HOST side: does this description run the RL = true variants (what has_fast_newton<> offers)?  The J2 subspace iterations treat a
-// full step as the Armijo search's first trial; under the legacy backtracking (CM_LS_LEGACY) the acceptance test is another one,
-// so those configurations run the general path.  For Hill / Hosford the RL variants ARE the warm-started ones, which
-// CM_SOLVER_REFERENCE_ITERATES switches off (for J2 that flag is read inside newton_j2_plane: the subspace form stays).
+// HOST side: does this description run the RL = true variants (what has_fast_newton<> offers), resp. the warm starts?  The J2
+// subspace iterations treat a full step as the Armijo search's first trial; under the legacy backtracking (CM_LS_LEGACY) the
+// acceptance test is another one, so those configurations run the general path.  For J2 CM_SOLVER_REFERENCE_ITERATES is read
+// inside newton_j2_plane (the subspace form stays); for Hill / Hosford it switches the warm start off (warm_start_on).
 inline bool use_fast_newton(const cm_model_desc* m) {
     if ((m->solver_flags & CM_SOLVER_GENERAL_NEWTON) || (m->ls_max_evals > 0 && m->ls_kind == CM_LS_LEGACY)) return false;
     return m->yield_kind == CM_YIELD_J2 || !(m->solver_flags & CM_SOLVER_REFERENCE_ITERATES);
@@ -1247,15 +1247,27 @@ inline bool use_fast_newton(const cm_model_desc* m) {
 template <int DEF, int YK, bool LS>
 CM_D uint32_t newton_fast(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
                           bool lane_valid, EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
-    static_assert(has_fast_newton<DEF, YK, LS>(), "no subspace iteration / warm start for this configuration");
-    if constexpr (YK == CM_YIELD_J2) return newton_j2_sub<DEF, LS>(m, eg, z, xp, x, lane_valid, ev, stage);
-    else {
-        double x0[7], n0sq;
-        bool warm;
-        if constexpr (YK == CM_YIELD_HILL) warm = hill_warm_start(m, eg, xp, x0, n0sq, lane_valid);
-        else warm = hosford_warm_start(m, eg, xp, x0, n0sq, lane_valid);
-        return newton_s<YK, LS, DEF>(m, eg, xp, x, lane_valid, ev, stage, z, PlainNorm{}, x0, warm ? &n0sq : nullptr);
+    static_assert(has_fast_newton<DEF, YK, LS>(), "no subspace iteration for this configuration");
+    return newton_j2_sub<DEF, LS>(m, eg, z, xp, x, lane_valid, ev, stage);
+}
+// the structured solve of every other kernel: newton_s, started at the warm start where the configuration has one and the
+// description leaves it on
+template <int DEF, int YK, bool LS>
+CM_D uint32_t newton_s_warm(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
+                            bool lane_valid, EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
+    if constexpr (has_warm_start<DEF, YK>()) {
+        double x0[7], n0sq = 0.0;
+        bool warm = false;
+        if (warm_start_on(m)) {                                     // uniform
+            if constexpr (YK == CM_YIELD_HILL) warm = hill_warm_start(m, eg, xp, x0, n0sq, lane_valid);
+            else warm = hosford_warm_start(m, eg, xp, x0, n0sq, lane_valid);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) x0[k] = xp[k];
+        }
+        return newton_s<YK, LS, DEF>(m, eg, xp, x, lane_valid, ev, stage, z, PlainNorm{}, x0, warm ? n0sq : -1.0);
     }
+    else return newton_s<YK, LS, DEF>(m, eg, xp, x, lane_valid, ev, stage, z);
 }
 
 // ---- reverse sweep, structured (same contract as cm::reverse_point; FULL_3D and PLANE_STRESS) ---------------
@@ -1418,7 +1430,7 @@ CM_D uint32_t newton_any(const cm_model_desc& m, const double eg[6], const doubl
     if constexpr (STRUCT && has_structured<DEF, YK>()) {
         EvalS<YK> ev;
         if constexpr (RL) return newton_fast<DEF, YK, LS>(m, eg, z, xp, x, valid, ev, stage);
-        else return newton_s<YK, LS, DEF>(m, eg, xp, x, valid, ev, stage, z);
+        else return newton_s_warm<DEF, YK, LS>(m, eg, z, xp, x, valid, ev, stage);
     }
     else return newton<DEF, YK, CM_SMALL_ELASTIC_PLASTIC, LS, STRUCT>(m, eg, z, xp, x, valid);   // STRUCT = false: the dense reference path
 }

@@ -21,7 +21,7 @@
 #include "cm_pool.hpp"
 #include "cm_hessian.hpp"
 
-// The library can be built from this one file in eleven independent pieces (hipcc -DCM_PART=0..10, see
+// The library can be built from this one file in twelve independent pieces (hipcc -DCM_PART=0..11, see
 // cmad_amd/build.py) so the template instantiations compile in parallel; without CM_PART everything is one TU.
 //   9: cm_param_blocks, cm_param_adjoint_history (extended parameter sensitivities)
 //   0: cm_update            2: cm_update_vjp, cm_adjoint_step   4: cm_update_tangent          6: cm_objective_grad,
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(kBlock, (min_waves<DEF, YK, LS, MODE, RL>())) void 
     if constexpr (MODE == 1 || MODE == 3) {
         if constexpr (SFAST) {
             if constexpr (RL) st = newton_fast<DEF, YK, LS>(m, eg, z, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock));
-            else newton_s<YK, LS, DEF>(m, eg, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock), z);
+            else newton_s_warm<DEF, YK, LS>(m, eg, z, xp, x, valid, evs, lane_stage(ls_stage, LS ? threadIdx.x : 0, kBlock));
         }
         else newton_any<DEF, YK, LS, true, RL>(m, eg, z, xp, x, valid);
         if constexpr (!EARLY) load_soa<6>(sbar_or_data, B, b, sd);       // after the solve: 12 fewer live VGPRs inside the Newton loop
@@ -2225,7 +2225,7 @@ int launch_hessian_history_ep(const cm_model_desc* m, int64_t B, int K, int n_ep
 }
 
 #endif
-#if CM_HAS_PART(10)                      // (a part of their own: the arithmetic-T model in complex arithmetic is the longest compile)
+#if CM_HAS_PART(10)                      // (parts of their own: the arithmetic-T kernels are the longest compiles)
 template <int MK>
 int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32_t* ep_index, const double* gradu,
                         const double* gradu_prev, const double* xi_prev, const double* xi, double* dC, double* dS, void* stream) {
@@ -2245,6 +2245,8 @@ int launch_param_blocks(const cm_model_desc* m, int64_t B, int n_ep, const int32
     return check_launch();
 }
 
+#endif
+#if CM_HAS_PART(11)                      // (complex arithmetic x every surface: a part of its own)
 template <int MK>
 int launch_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* ext_im, const double* gradu,
                           const double* gradu_prev, const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status,
@@ -2271,6 +2273,8 @@ int launch_update_complex(const cm_model_desc* m, int64_t B, const double* p_im,
     return check_launch();
 }
 
+#endif
+#if CM_HAS_PART(10)
 template <int MK>
 int launch_param_adjoint_history(const cm_model_desc* m, int64_t B, int K, int n_ep, const int32_t* ep_index,
                                  const double* gradu_hist, const double* xi_hist, const double* lam_hist, const double* sbar_hist,
@@ -2534,6 +2538,8 @@ int cm_param_blocks(const cm_model_desc* m, int64_t B, int32_t n_ep, const int32
         return launch_param_blocks<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, n_ep, ep_index, gradu, gradu_prev, xi_prev, xi, dC_dp, dsigma_dp, stream);
     return launch_param_blocks<CM_SMALL_ELASTIC_PLASTIC>(m, B, n_ep, ep_index, gradu, nullptr, xi_prev, xi, dC_dp, dsigma_dp, stream);
 }
+#endif
+#if CM_HAS_PART(11)
 int cm_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, const double* ext_im, const double* gradu,
                       const double* gradu_prev, const double* xi_prev, double* xi, double* residual, double* sigma, uint32_t* status,
                       void* stream) {
@@ -2542,6 +2548,8 @@ int cm_update_complex(const cm_model_desc* m, int64_t B, const double* p_im, con
         return launch_update_complex<CM_SMALL_RATE_ELASTIC_PLASTIC>(m, B, p_im, ext_im, gradu, gradu_prev, xi_prev, xi, residual, sigma, status, stream);
     return launch_update_complex<CM_SMALL_ELASTIC_PLASTIC>(m, B, p_im, ext_im, gradu, nullptr, xi_prev, xi, residual, sigma, status, stream);
 }
+#endif
+#if CM_HAS_PART(10)
 int cm_param_adjoint_history(const cm_model_desc* m, int64_t B, int32_t K, int32_t n_ep, const int32_t* ep_index,
                              const double* gradu_hist, const double* xi_hist, const double* lam_hist,
                              const double* sigma_bar_hist, double* grad_ep, void* workspace, int64_t workspace_bytes, void* stream) {

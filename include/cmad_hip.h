@@ -66,7 +66,8 @@ enum cm_param_index {
  * in FULL_3D (one equation in kappa = 2 mu dgam / phi), J2 in PLANE_STRESS (one equation in g = 3 mu dgam / phi, the stretch
  * eliminated through the sigma_33 row), J2 and Hill in UNIAXIAL_STRESS (the 1-d return map: the stress at the solution is
  * sigma_0 Z^0 and the flow direction a constant), Hosford with a >= 20 in FULL_3D (three equations in log-variables) -- the kernels solve
- * that first and START the reference's Newton iteration at its result: the reference's residual is evaluated there and the
+ * that first (a closed-form first step, two or more Newton steps in single precision as a seed, then double precision to
+ * round-off) and START the reference's Newton iteration at its result: the reference's residual is evaluated there and the
  * reference's convergence test (relative to ||C(x_prev)||) decides, so a converged map costs one residual evaluation and
  * anything else is finished by the reference's Newton steps / line search from there.  Same root to the Newton tolerance
  * (SURVEY.md Appendix A); `status` counts the iterations taken FROM the warm start (usually 0).
