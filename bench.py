@@ -316,8 +316,13 @@ def main():
     # CMAD_BENCH_FORCE_DIST=1 exercises the process-group path with a single rank (rehearsal on a 1-GPU box)
     distributed = world > 1 or os.environ.get("CMAD_BENCH_FORCE_DIST") == "1"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CMAD_BENCH_SHARED_GPU=1: rehearsal of the N-rank path on a box with ONE GPU -- every rank computes on device 0 and the
+    # collectives run over gloo (RCCL refuses two ranks on one device).  Exercises the launcher, the sharding, the barriers, the
+    # max-over-ranks timing and rank 0's line; its numbers mean nothing (the ranks share the card) and the line says so.
+    shared_gpu = os.environ.get("CMAD_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")           # set by torch.distributed.run; only the 1-rank rehearsal lacks it
@@ -327,7 +332,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if shared_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             probe = torch.zeros(1, dtype=torch.float64, device=dev)
             dist.all_reduce(probe)
             torch.cuda.synchronize()
@@ -625,6 +633,8 @@ def main():
                        "backend": dist.get_backend() if distributed else None,
                        "collective_calls": tr["collective_calls"], "payload_doubles": tr["payload_doubles"],
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else None}
+        if shared_gpu:
+            res["rccl"]["rehearsal"] = "CMAD_BENCH_SHARED_GPU=1: every rank on device 0, collectives over gloo -- not a measurement"
         if tobj is not None:
             ob, oms = algorithmic_bytes("j2_objective_grad"), tobj["elapsed"] / args.steps * 1e3
             res["objective"] = {

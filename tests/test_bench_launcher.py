@@ -60,3 +60,23 @@ def test_one_rank_rehearsal_through_the_launcher_matches_the_plain_run():
     assert dist["objective"]["total_points"] == 2000000
     for a, b in ((plain["value"], dist["value"]), (plain["objective"]["value"], dist["objective"]["value"])):
         assert abs(a - b) / a < 0.25, (a, b)           # same kernels on the same box: lease noise + one 13-double all-reduce per step
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_sharing_one_gpu():
+    """The N > 1 path of `bench.py` end to end on a one-GPU box: `--gpus 2` starts two ranks through its own launcher, both
+    compute on device 0 (CMAD_BENCH_SHARED_GPU=1; collectives over gloo, since RCCL refuses two ranks on one device), shard the
+    batch, meet at the barriers, reduce the timing over the ranks, and rank 0 alone prints the line.  Checks the bookkeeping --
+    world size, collectives counted, per-rank kernel times, both records -- not the numbers (the ranks share the card)."""
+    out = run_bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--points", "2000000", "--no-cpu-baseline"],
+                    {"CMAD_BENCH_SHARED_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["rccl"]["world_size"] == 2 and out["rccl"]["backend"] == "gloo" and "rehearsal" in out["rccl"]
+    assert out["rccl"]["launcher"] == "torch.distributed.run"
+    assert out["rccl"]["collective_calls"] == 10 and out["rccl"]["payload_doubles"] == 12
+    assert len(out["timeline"]["per_rank_kernel_ms"]) == 2 and all(t > 0 for t in out["timeline"]["per_rank_kernel_ms"])
+    assert out["config"]["points_per_gpu"] == 2000000
+    # whole-job aggregate: both ranks' points over the max-over-ranks time
+    assert abs(out["value"] - 2 * 2000000 / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    assert out["objective"]["total_points"] == 4000000 and out["objective"]["rccl"] == {"collective_calls": 10, "payload_doubles": 13}
+    assert "cpu_baseline" not in out or out["cpu_baseline"] is None          # rank 0 at N = 1 only
