@@ -118,7 +118,7 @@ __device__ __forceinline__ void store_soa(double* __restrict__ p, int64_t B, uns
 #define CM_OCC_REV_HILL 1
 #endif
 #ifndef CM_OCC_UNIAXIAL
-#define CM_OCC_UNIAXIAL 1          // UNIAXIAL_STRESS update / reverse kernels on the quadratic surfaces (4x4 Newton step, no dense Hessian)
+#define CM_OCC_UNIAXIAL 2          // UNIAXIAL_STRESS update / objective kernels on the quadratic surfaces: 302 -> 256 VGPRs + 136 B scratch in the 9x9 Newton step no lane takes since the 1-d return map; 0.150 -> 0.122 ms per 2e6 points (profiles/r04_occupancy_ab.txt)
 #endif
 #ifndef CM_OCC_PS_J2_PLANE
 #define CM_OCC_PS_J2_PLANE 1       // J2 / PLANE_STRESS kernels on the plane iteration (newton_j2_plane), plain Newton
@@ -785,7 +785,7 @@ struct Wsq { double w[6]; };
 template <int DEF, int YK, bool LS, int MODE, bool RL = false>
 constexpr int min_waves() {
     if (DEF == CM_PLANE_STRESS && YK == CM_YIELD_J2 && RL) return LS ? CM_OCC_PS_J2_PLANE_LS : CM_OCC_PS_J2_PLANE;
-    if (DEF == CM_UNIAXIAL_STRESS && (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) && (MODE == 1 || MODE == 3)) return CM_OCC_UNIAXIAL;
+    if (DEF == CM_UNIAXIAL_STRESS && (YK == CM_YIELD_J2 || YK == CM_YIELD_HILL) && MODE == 1) return CM_OCC_UNIAXIAL;   // (MODE 3, update + vjp: 4 % slower at 2 waves)
     if (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && LS) return CM_OCC_REV_J2_LS;
     if (DEF == CM_FULL_3D && YK == CM_YIELD_HILL && !LS) return CM_OCC_REV_HILL;
     return (DEF == CM_FULL_3D && YK == CM_YIELD_J2 && !LS && (MODE == 1 || MODE == 3)) ? CM_OCC_REV_J2 : 1;

@@ -1290,3 +1290,22 @@ def check_warm_start_edge_cases(backend, def_type, yield_kind, kw):
             ok2 = okp & cv_o2.astype(bool) & ((st2.astype(np.uint32) >> 16) & 1).astype(bool)
             assert ok2.mean() > 0.9
             np.testing.assert_allclose(xi_d2[:, ok2], xi_o2[:, ok2], rtol=1e-9, atol=max(1e-12, tol))
+    # units: the same material in Pa and in GPa -- the single-precision seeds of the return maps see 1e6 x / 1e-3 x the numbers.
+    # The residual is strain-like (divided by 2 mu), so states and iteration counts do not depend on the stress unit.
+    g = gauss_point_batch(B, seed=32, dev_scale=3.0, ndims=nd)
+    if ux:
+        g = np.random.default_rng(32).uniform(-4e-3, 4e-3, size=(1, B))
+    xi_ref, sig_ref, st_ref = backend.update(sc, g, x0)
+    assert ((st_ref.astype(np.uint32) >> 16) & 1).all()
+    for f in (1e6, 1e-3):
+        fs = values["plastic"]["flow stress"]
+        v2 = ol.j2_voce_values(E=values["elastic"]["E"] * f, Y=fs["initial yield"]["Y"] * f, S=fs["hardening"]["voce"]["S"] * f,
+                               yield_kind=yield_kind, **kw)
+        s2 = S()
+        s2.mat = ol.Material(v2, def_type=def_type)
+        s2.desc, s2.info = build_desc(v2, def_type=def_type, newton=sc.st_d)
+        xi2, sig2, st2 = backend.update(s2, g, x0)
+        assert ((st2.astype(np.uint32) >> 16) & 1).all()
+        np.testing.assert_allclose(xi2, xi_ref, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(sig2 / f, sig_ref, rtol=1e-9, atol=1e-9 * np.abs(sig_ref).max())
+        assert np.mean((st2.astype(np.uint32) & 0xFFFF) == (st_ref.astype(np.uint32) & 0xFFFF)) > 0.99

@@ -8,7 +8,7 @@ NAME=$1; FLAGS=$2; shift 2
 CSRC=cmad_amd/csrc
 mkdir -p ab_libs/obj_$NAME
 OBJS=""
-for k in 0 1 2 3 4 5 6 7 8 9; do
+for k in $(seq 0 11); do
   if [[ " $* " == *" $k "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++20 --offload-arch=gfx950 -fPIC -DCM_PART=$k $FLAGS -c $CSRC/cmad_hip.hip -o ab_libs/obj_$NAME/part$k.o 2>/dev/null &
     OBJS="$OBJS ab_libs/obj_$NAME/part$k.o"
