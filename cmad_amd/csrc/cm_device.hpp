@@ -1127,6 +1127,35 @@ CM_D HardF hardening_f(const cm_model_desc& m, float alpha) {
     return h;
 }
 
+// NN(s) of icnn_yield_term for a network [6, H, 1], VALUE only, hidden units in float (~34 instead of ~66 instructions per unit; a
+// float copy of the weights in the pack was measured and bought nothing -- the kernel is no longer bound by VALU issue):
+// what k_screen classifies with; a point whose yield function lands within the float evaluation's error band of zero is
+// re-evaluated in double there.  Constants (biases of the output, f(0), scalers) stay double.
+CM_D double icnn_value_f(const cm_model_desc& m, const double s[6]) {
+    const int H = m.nn_widths[1];
+    const cm_uniform_ptr u = uniform_ptr(m.nn_weights);
+    const cm_uniform_ptr sc = u + icnn_off_scalers(H);
+    const cm_uniform_ptr rec = u + icnn_off_records(H);
+    const double h = (s[0] + s[3] + s[5]) * (1.0 / 3.0);
+    const double x[6] = {s[0] - h, s[3] - h, s[5] - h, s[1], s[2], s[4]};
+    float xs[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xs[i] = (float)(sc[i] * x[i] + sc[6 + i]);
+    float F = 0.0f;
+    for (int o = 0; o < H; ++o) {
+        const cm_uniform_ptr r = rec + kIcnnRec * o;
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t += xs[i] * (float)r[i];
+        const float b = (float)r[6], wz = (float)r[7];
+        const float ap = b + t, an = b - t;
+        const float spp = fmaxf(ap, 0.0f) + log_f(1.0f + exp_f(-fabsf(ap)));
+        const float spn = fmaxf(an, 0.0f) + log_f(1.0f + exp_f(-fabsf(an)));
+        F += (spp + spn) * wz;
+    }
+    return (0.5 * (double)F + u[icnn_off_b1(H)] - sc[14] - sc[13]) / sc[12];
+}
+
 // Cel a = 2 mu a + lambda (a0+a3+a5) d
 CM_D void apply_cel(const cm_model_desc& m, const double a[6], double out[6]) {
     const double t = m.lambda * (a[0] + a[3] + a[5]), twomu = 2.0 * m.mu;

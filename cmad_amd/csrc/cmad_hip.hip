@@ -498,8 +498,23 @@ __global__ __launch_bounds__(kScreenBlock) void k_screen(cm_model_desc m, int64_
     strain_stress<CM_FULL_3D>(m, eg, z, xp, ev);                 // trial stress: what k_update stores for an elastic point
     const double* s = ev.s;
     double phi, gt[6], Hd[1];
-    yield_eval_p<YK, false>(m, s, phi, gt, Hd);                  // the value residual_s / residual see at x_prev
-    const double f0 = (phi - (m.Y + hardening(m, xp[6]).H)) * half_over_mu(m);
+    const double YH = m.Y + hardening(m, xp[6]).H;
+    bool exact = true;
+    if constexpr (YK == CM_YIELD_HYBRID_HILL_NN) {
+        // One hidden layer: the network term in float first (icnn_value_f: a third of this kernel's instructions less).  Its
+        // error is ~1e-6 of the terms it sums; a point within 2e-4 of (|phi_hill| + |N| + Y + H) of the surface -- one in a few
+        // thousand -- sends its wavefront through the double evaluation, which then decides for every lane.
+        if (m.nn_nlayers == 3) {                                  // uniform
+            double ph;
+            yield_eval_p<CM_YIELD_HILL, false>(m, s, ph, gt, Hd);
+            const double nf = icnn_value_f(m, s);
+            phi = ph + nf;
+            const bool sure = fabs(phi - YH) > 2e-4 * (fabs(ph) + fabs(nf) + YH);      // (false for a NaN)
+            exact = __any(valid && !sure);
+        }
+    }
+    if (exact) yield_eval_p<YK, false>(m, s, phi, gt, Hd);       // the value residual_s / residual see at x_prev
+    const double f0 = (phi - YH) * half_over_mu(m);
     const bool plastic0 = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
     if (valid && !plastic0) {                                    // cond_residual's elastic branch at x_prev: C = 0, nothing to iterate
         double sg[6];
