@@ -477,7 +477,14 @@ constexpr bool screen_pays() { return CM_SCREEN != 0 && is_dense_yield(YK); }
 // 1024 lanes per workgroup: the append is ONE atomic per workgroup (wave counts summed through LDS).  All wavefronts of the grid
 // add to the same address, and the device serves about 80 M same-address atomics per second: one per wavefront -- 78 000 for
 // 5 x 10^6 points -- took 0.96 ms by itself (profiles/r04_screen_atomics.txt); one per 1024 points takes 0.06 ms.
-constexpr int kScreenBlock = 1024;
+#ifndef CM_SCREEN_BLOCK
+#define CM_SCREEN_BLOCK 1024
+#endif
+#ifndef CM_SCREEN_NT
+#define CM_SCREEN_NT 1              // non-temporal input loads in k_screen: the batch's rows (640 MB at 5e6 points) do not survive in any
+                                    // cache until k_update_listed reads them again; 1.7 % on hybrid_update (profiles/r04_occupancy_ab.txt)
+#endif
+constexpr int kScreenBlock = CM_SCREEN_BLOCK;
 template <int YK, bool ROT>
 __global__ __launch_bounds__(kScreenBlock) void k_screen(cm_model_desc m, int64_t B,
         const double* __restrict__ gradu, const double* __restrict__ xi_prev,
@@ -490,8 +497,8 @@ __global__ __launch_bounds__(kScreenBlock) void k_screen(cm_model_desc m, int64_
     if (sigma) sigma += blk0;
     if (status) status += blk0;
     double G[9], xp[7], eg[6], z[6];
-    load_soa<9, false>(gradu, B, b, G);                          // (temporal: the plastic points' rows are read again)
-    load_soa<7, false>(xi_prev, B, b, xp);
+    load_soa<9, CM_SCREEN_NT != 0>(gradu, B, b, G);
+    load_soa<7, CM_SCREEN_NT != 0>(xi_prev, B, b, xp);
     strain_from_gradu<CM_FULL_3D, ROT>(m, G, eg);
     strain_z<CM_FULL_3D, ROT>(m, z);
     Eval<CM_FULL_3D> ev;
@@ -570,15 +577,20 @@ __global__ __launch_bounds__(kBlock, (min_waves_listed<YK, ROT, LS>())) void k_u
     const bool valid = t0 + threadIdx.x < n;
     const uint32_t pt = list[valid ? t0 + threadIdx.x : n - 1];  // tail lanes shadow the last listed point, never store
     const uint32_t off = pt * 8u;
+#ifndef CM_LISTED_NT
+#define CM_LISTED_NT 0              // experiment knob: non-temporal row accesses of the listed points
+#endif
     auto row_load = [&](const double* base, int k) {
         cm_gcptr row = (cm_gcptr)(base + (int64_t)k * B);
         asm volatile("" : "+s"(row));
-        return *(const __attribute__((address_space(1))) double*)(row + off);
+        if constexpr (CM_LISTED_NT != 0) return __builtin_nontemporal_load((const __attribute__((address_space(1))) double*)(row + off));
+        else return *(const __attribute__((address_space(1))) double*)(row + off);
     };
     auto row_store = [&](double* base, int k, double v) {
         cm_gptr row = (cm_gptr)(base + (int64_t)k * B);
         asm volatile("" : "+s"(row));
-        *(__attribute__((address_space(1))) double*)(row + off) = v;
+        if constexpr (CM_LISTED_NT != 0) __builtin_nontemporal_store(v, (__attribute__((address_space(1))) double*)(row + off));
+        else *(__attribute__((address_space(1))) double*)(row + off) = v;
     };
     double G[NU], xp[NX], x[NX], eg[6], z[6];
 #pragma unroll
