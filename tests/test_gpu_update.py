@@ -783,6 +783,47 @@ def test_screened_route_is_taken_and_equals_the_lockstep_kernels():
     assert 0.3 < float((it > 0).double().mean()) < 0.8
 
 
+def test_screened_route_classifies_points_at_the_yield_surface_like_the_lockstep_kernels():
+    """k_screen evaluates the network term in float and settles the points within its error band in double: trial states ON the
+    yield surface and within 1e-14 ... 1e-3 (relative) of it, on both sides, must be split into elastic and plastic exactly as
+    the double-precision lockstep kernel splits them -- states, stresses and status words bit for bit."""
+    import torch
+    from cmad_amd.models.device import DeviceEvaluator, HybridHillEffectiveStress, NewtonSettings, build_desc
+    from cmad_amd.synthetic import al7079_hybrid_setup, gauss_point_batch
+    n = 4096
+    icnn, values = al7079_hybrid_setup()
+    mk = lambda lock: NewtonSettings(50, 1e-12, 1e-12, {"max evals": 10, "sufficient decrease": 1e-4, "min backtrack factor": 0.5,
+                                                       "max backtrack factor": 0.9}, lockstep=lock)
+    ev_s, ev_l = [DeviceEvaluator(*build_desc(values, newton=mk(lock), hybrid=HybridHillEffectiveStress(icnn))) for lock in (False, True)]
+    d = torch.from_numpy(gauss_point_batch(n, seed=41, eps_y=525.0 / 70.2e3)).cuda()          # directions in strain space
+    xp = torch.zeros((7, n), dtype=torch.float64, device="cuda")
+    # the scale at which each direction reaches the surface: bisection on the lockstep kernel's own elastic / plastic decision
+    lo = torch.zeros(n, dtype=torch.float64, device="cuda")
+    hi = torch.full((n,), 8.0, dtype=torch.float64, device="cuda")
+    plastic = lambda t: (ev_l.update(d * t[None, :], xp)[2].to(torch.int64) & 0xFFFF) > 0
+    keep = plastic(hi) & ~plastic(lo + 1e-3)            # (nearly volumetric directions never yield: left out)
+    assert float(keep.double().mean()) > 0.9
+    n = int(keep.sum())
+    d, xp, lo, hi = d[:, keep].contiguous(), xp[:, keep].contiguous(), lo[keep], hi[keep]
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        pl = plastic(mid)
+        hi = torch.where(pl, mid, hi); lo = torch.where(pl, lo, mid)
+    rel = torch.tensor([0.0, 1e-14, -1e-14, 1e-11, -1e-11, 1e-8, -1e-8, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3, 0.5],
+                       dtype=torch.float64, device="cuda")
+    t = (hi[None, :] * (1.0 + rel[:, None])).reshape(-1)                                  # 16 x 4096 points around the surface
+    g = (d.repeat(1, rel.numel()) * t[None, :]).contiguous()
+    B = g.shape[1]
+    x0 = torch.zeros((7, B), dtype=torch.float64, device="cuda")
+    assert ev_s.screened(B) and not ev_l.screened(B)
+    a, b = ev_s.update(g, x0), ev_l.update(g, x0)
+    torch.cuda.synchronize()
+    for u, v, what in zip(a, b, ("xi", "sigma", "status")):
+        assert torch.equal(u, v), what
+    its = (a[2].to(torch.int64) & 0xFFFF).reshape(rel.numel(), n)
+    assert bool((its[rel > 1e-9] > 0).all()) and bool((its[rel < -1e-9] == 0).all())      # (sanity: the bracket is where the surface is)
+
+
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
