@@ -826,6 +826,169 @@ CM_D bool hill_warm_start(const cm_model_desc& m, const double eg[6], const doub
     return true;
 }
 
+// ---- Hill, PLANE_STRESS: the same scalar map with the stretch eliminated ---------------------------------------------------------
+// The trial stress is linear in the out-of-plane stretch t = F33 - 1:  s_trial(t) = s0 + t sz,  s0 = Cel (eg - v_prev),  sz = Cel z,
+// so for a given kappa = 2 mu dgam / phi the stress  s = (I + kappa W^-1 A)^-1 (s0 + t sz)  is linear in t too, and the plane-stress
+// row (w o z) . s = 0 gives t in closed form:
+//     t(kappa) = -N / D ,   N = zeta . u0 + tau p0 + 2 sum_shear z_k s0_k i_k ,   D = the same with (uz, pz, sz_k) ,
+// with u0 = B2^-1 y0, uz = B2^-1 yz the deviatoric coordinates of the normal entries (B2 = I + kappa A2, see hill_warm_start; the
+// mean stresses p0, pz pass through: A has the null vector 1), i_k = 1 / (1 + kappa a_kk / 2), zeta = E^T z_n, tau = tr z.
+// What is left is  F(kappa) = phi(kappa) - Y - H(alpha_prev + kappa phi / 2mu) = 0  with  phi^2 = y^T A2 y + sum a_kk s_k^2,
+// y = u0 + t uz, s_k = (s0_k + t sz_k) i_k, and dF/dkappa from  d(B2^-1 v) = -B2^-1 A2 B2^-1 v,  d i_k = -h_k i_k^2,
+// t' = -(N' D - N D') / D^2.  Newton in c = lb kappa / (1 + lb kappa), a closed-form first step, two steps in float, then double
+// (cm_device.hpp "single-precision seeds").  As under FULL_3D the result only STARTS the reference's Newton (newton_s on the 8-dof
+// residual, its convergence test against ||C(x_prev)||); the elastic step (kappa = 0, stretch t(0)) is taken only when the state
+// at x_prev, with the old stretch, is elastic too (two roots otherwise: see newton_j2_plane).
+template <class T> struct HillPsC {
+    T A11, A12, A22, h1, h2, h4, a11, a22, a44;        // the quadratic form
+    T y01, y02, yz1, yz2, p0, pz, s01, s02, s04, sz1, sz2, sz4;   // s0 and sz: deviatoric coordinates, mean, shear entries
+    T ze1, ze2, tau, z1, z2, z4;                        // the plane-stress row
+    T Y, alpha_p, i2mu;
+};
+// F, dF / dkappa, and the state (t, y, s_k, phi) at kappa
+template <class T, class HF>
+CM_D void hill_ps_eval(const HillPsC<T>& c, T kap, HF&& hard, T& F, T& dF, T& t, T& y1, T& y2, T& s1, T& s2, T& s4, T& phi) {
+    const T one = (T)1, two = (T)2;
+    const T b11 = one + kap * c.A11, b22 = one + kap * c.A22, b12 = kap * c.A12;
+    T idet, i1, i2, i4;
+    if constexpr (std::is_same<T, float>::value) {
+        idet = rcp_f(b11 * b22 - b12 * b12); i1 = rcp_f(one + kap * c.h1); i2 = rcp_f(one + kap * c.h2); i4 = rcp_f(one + kap * c.h4);
+    } else {
+        idet = rcp(b11 * b22 - b12 * b12); i1 = rcp(one + kap * c.h1); i2 = rcp(one + kap * c.h2); i4 = rcp(one + kap * c.h4);
+    }
+    auto inv1 = [&](T v1, T v2) { return (b22 * v1 - b12 * v2) * idet; };
+    auto inv2 = [&](T v1, T v2) { return (b11 * v2 - b12 * v1) * idet; };
+    const T u01 = inv1(c.y01, c.y02), u02 = inv2(c.y01, c.y02), uz1 = inv1(c.yz1, c.yz2), uz2 = inv2(c.yz1, c.yz2);
+    const T N = c.ze1 * u01 + c.ze2 * u02 + c.tau * c.p0 + two * (c.z1 * c.s01 * i1 + c.z2 * c.s02 * i2 + c.z4 * c.s04 * i4);
+    const T D = c.ze1 * uz1 + c.ze2 * uz2 + c.tau * c.pz + two * (c.z1 * c.sz1 * i1 + c.z2 * c.sz2 * i2 + c.z4 * c.sz4 * i4);
+    T iD;
+    if constexpr (std::is_same<T, float>::value) iD = rcp_f(D); else iD = rcp(D);
+    t = -N * iD;
+    y1 = u01 + t * uz1; y2 = u02 + t * uz2;
+    s1 = (c.s01 + t * c.sz1) * i1; s2 = (c.s02 + t * c.sz2) * i2; s4 = (c.s04 + t * c.sz4) * i4;
+    const T Ay1 = c.A11 * y1 + c.A12 * y2, Ay2 = c.A12 * y1 + c.A22 * y2;
+    const T t1 = c.a11 * s1, t2 = c.a22 * s2, t4 = c.a44 * s4;
+    const T ph2 = y1 * Ay1 + y2 * Ay2 + t1 * s1 + t2 * s2 + t4 * s4;
+    T iphi;
+    if constexpr (std::is_same<T, float>::value) iphi = rsq_f(ph2); else iphi = (ph2 > 0.0) ? rsqrt_pos(ph2) : 0.0;
+    phi = ph2 * iphi;
+    // derivatives w.r.t. kappa
+    const T a01 = c.A11 * u01 + c.A12 * u02, a02 = c.A12 * u01 + c.A22 * u02, az1 = c.A11 * uz1 + c.A12 * uz2, az2 = c.A12 * uz1 + c.A22 * uz2;
+    const T du01 = -inv1(a01, a02), du02 = -inv2(a01, a02), duz1 = -inv1(az1, az2), duz2 = -inv2(az1, az2);
+    const T g1 = c.h1 * i1 * i1, g2 = c.h2 * i2 * i2, g4 = c.h4 * i4 * i4;
+    const T dN = c.ze1 * du01 + c.ze2 * du02 - two * (c.z1 * c.s01 * g1 + c.z2 * c.s02 * g2 + c.z4 * c.s04 * g4);
+    const T dD = c.ze1 * duz1 + c.ze2 * duz2 - two * (c.z1 * c.sz1 * g1 + c.z2 * c.sz2 * g2 + c.z4 * c.sz4 * g4);
+    const T dt = -(dN * D - N * dD) * (iD * iD);
+    const T dy1 = du01 + dt * uz1 + t * duz1, dy2 = du02 + dt * uz2 + t * duz2;
+    const T ds1 = dt * c.sz1 * i1 - s1 * c.h1 * i1, ds2 = dt * c.sz2 * i2 - s2 * c.h2 * i2, ds4 = dt * c.sz4 * i4 - s4 * c.h4 * i4;
+    const T dphi = (Ay1 * dy1 + Ay2 * dy2 + t1 * ds1 + t2 * ds2 + t4 * ds4) * iphi;
+    T H, dH;
+    hard(c.alpha_p + kap * phi * c.i2mu, H, dH);
+    F = phi - (c.Y + H);
+    dF = dphi - dH * (phi + kap * dphi) * c.i2mu;
+}
+CM_D bool hill_ps_warm_start(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x0, double& n0sq,
+                             bool lane_valid) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x0[k] = xp[k];
+    const QuadForm q = quad_form<CM_YIELD_HILL>(m);
+    const double twomu = 2.0 * m.mu, i2mu = half_over_mu(m), Kb = m.lambda + (2.0 / 3.0) * m.mu;
+    constexpr double r2 = 0.7071067811865476, r6 = 0.4082482904638631, r12 = 0.2886751345948129;
+    HillPsC<double> c;
+    c.A11 = 0.5 * (q.a00 - 2.0 * q.a03 + q.a33);
+    c.A12 = (q.a00 - q.a33 - 2.0 * q.a05 + 2.0 * q.a35) * r12;
+    c.A22 = (q.a00 + q.a33 + 4.0 * q.a55 + 2.0 * q.a03 - 4.0 * q.a05 - 4.0 * q.a35) * (1.0 / 6.0);
+    c.h1 = 0.5 * q.a11; c.h2 = 0.5 * q.a22; c.h4 = 0.5 * q.a44; c.a11 = q.a11; c.a22 = q.a22; c.a44 = q.a44;
+    double e[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) e[k] = eg[k] - xp[k];
+    const double tre = e[0] + e[3] + e[5], trz = z[0] + z[3] + z[5];
+    // deviatoric coordinates / mean / shear entries of s0 = Cel e and sz = Cel z (the lambda tr terms only enter the means)
+    c.y01 = twomu * (e[0] - e[3]) * r2; c.y02 = twomu * (e[0] + e[3] - 2.0 * e[5]) * r6; c.p0 = Kb * tre;
+    c.yz1 = twomu * (z[0] - z[3]) * r2; c.yz2 = twomu * (z[0] + z[3] - 2.0 * z[5]) * r6; c.pz = Kb * trz;
+    c.s01 = twomu * e[1]; c.s02 = twomu * e[2]; c.s04 = twomu * e[4];
+    c.sz1 = twomu * z[1]; c.sz2 = twomu * z[2]; c.sz4 = twomu * z[4];
+    c.ze1 = (z[0] - z[3]) * r2; c.ze2 = (z[0] + z[3] - 2.0 * z[5]) * r6; c.tau = trz; c.z1 = z[1]; c.z2 = z[2]; c.z4 = z[4];
+    c.Y = m.Y; c.alpha_p = xp[6]; c.i2mu = i2mu;
+    const Hard hp = hardening(m, c.alpha_p);
+    bool plastic_prev;
+    {   // ||C(x_prev)||^2 = C6^2 + C7^2 with the OLD stretch (the strain rows vanish at x_prev)
+        const double tp = xp[7] - 1.0;
+        const double y1 = c.y01 + tp * c.yz1, y2 = c.y02 + tp * c.yz2, s1 = c.s01 + tp * c.sz1, s2 = c.s02 + tp * c.sz2, s4 = c.s04 + tp * c.sz4;
+        const double ph2 = y1 * (c.A11 * y1 + c.A12 * y2) + y2 * (c.A12 * y1 + c.A22 * y2) + q.a11 * s1 * s1 + q.a22 * s2 * s2 + q.a44 * s4 * s4;
+        const double phi0 = (ph2 > 0.0) ? ph2 * rsqrt_pos(ph2) : 0.0;
+        const double f0 = (phi0 - (m.Y + hp.H)) * i2mu;
+        plastic_prev = (f0 > m.yield_tol) || (fabs(f0) < m.yield_tol);
+        const double c6 = plastic_prev ? f0 : 0.0;
+        const double c7 = (c.ze1 * y1 + c.ze2 * y2 + c.tau * (c.p0 + tp * c.pz) + 2.0 * (c.z1 * s1 + c.z2 * s2 + c.z4 * s4)) * i2mu;
+        n0sq = c6 * c6 + c7 * c7;
+    }
+    // (a state that already passes the reference's test at x_prev is returned as it is, 0 iterations)
+    bool done = !lane_valid || (n0sq < m.abs_tol * m.abs_tol), ok = false;
+    if (!__any(!done)) return true;
+    constexpr double lb = 1.5;
+    auto hard_d = [&](double alpha, double& H, double& dH) { const Hard h = hardening(m, alpha); H = h.H; dH = h.dH; };
+    double kap = 0.0, t = 0.0, y1, y2, s1, s2, s4, phi, F, dF;
+    {   // kappa = 0: the elastic step with the relaxed stretch t(0); the hardening there is the one at alpha_prev
+        auto hard_0 = [&](double, double& H, double& dH) { H = hp.H; dH = hp.dH; };
+        hill_ps_eval<double>(c, 0.0, hard_0, F, dF, t, y1, y2, s1, s2, s4, phi);
+        if (!done && !(F > 0.0)) {
+            done = true;
+            if (!plastic_prev) x0[7] = 1.0 + t;                  // elastic at x_prev and after the relaxation: the elastic root
+        }
+        if (!done) { const double cn = fmin(fmax(-F * lb * rcp(dF), 0.0), 0.999999); kap = cn * rcp(lb * (1.0 - cn)); }
+    }
+    if (__any(!done) && hardening_seed_ok(m)) {
+        HillPsC<float> cf;
+        cf.A11 = (float)c.A11; cf.A12 = (float)c.A12; cf.A22 = (float)c.A22; cf.h1 = (float)c.h1; cf.h2 = (float)c.h2; cf.h4 = (float)c.h4;
+        cf.a11 = (float)c.a11; cf.a22 = (float)c.a22; cf.a44 = (float)c.a44;
+        cf.y01 = (float)c.y01; cf.y02 = (float)c.y02; cf.yz1 = (float)c.yz1; cf.yz2 = (float)c.yz2; cf.p0 = (float)c.p0; cf.pz = (float)c.pz;
+        cf.s01 = (float)c.s01; cf.s02 = (float)c.s02; cf.s04 = (float)c.s04; cf.sz1 = (float)c.sz1; cf.sz2 = (float)c.sz2; cf.sz4 = (float)c.sz4;
+        cf.ze1 = (float)c.ze1; cf.ze2 = (float)c.ze2; cf.tau = (float)c.tau; cf.z1 = (float)c.z1; cf.z2 = (float)c.z2; cf.z4 = (float)c.z4;
+        cf.Y = (float)c.Y; cf.alpha_p = (float)c.alpha_p; cf.i2mu = (float)c.i2mu;
+        auto hard_f = [&](float alpha, float& H, float& dH) { const HardF h = hardening_f(m, alpha); H = h.H; dH = h.dH; };
+        float kf = (float)kap;
+#pragma unroll
+        for (int sit = 0; sit < 2; ++sit) {
+            float Ff, dFf, tf, a1, a2, b1, b2, b4, pf;
+            hill_ps_eval<float>(cf, kf, hard_f, Ff, dFf, tf, a1, a2, b1, b2, b4, pf);
+            const float w = 1.0f + (float)lb * kf;
+            const float cn = (float)lb * kf * rcp_f(w) - Ff * (float)lb * rcp_f(dFf * w * w);
+            if (cn >= 0.0f && cn < 0.999999f) kf = cn * rcp_f((float)lb * (1.0f - cn));
+        }
+        if (!done) kap = (double)kf;
+    }
+    const double phi_ref = m.Y + hp.H;
+    for (int it = 0; it < kHillWarmMaxIt; ++it) {
+        double tn, a1, a2, b1, b2, b4, pn;
+        hill_ps_eval<double>(c, kap, hard_d, F, dF, tn, a1, a2, b1, b2, b4, pn);
+        const double res = fabs(F);
+        if (!done && !(res < 1e300)) done = true;
+        if (!done && res < 1e-14 * phi_ref) { done = true; ok = true; }
+        if (!done) {
+            const double w = 1.0 + lb * kap;
+            const double cn = fmin(fmax(lb * kap * rcp(w) - F * lb * rcp(dF * w * w), 0.0), 0.999999);
+            kap = cn * rcp(lb * (1.0 - cn));
+            if (res < 1e-8 * phi_ref) { done = true; ok = true; }  // quadratic convergence: this iterate is converged to round-off
+        }
+        if (!__any(!done)) break;
+    }
+    if (ok) {
+        auto hard_n = [&](double, double& H, double& dH) { H = 0.0; dH = 0.0; };      // (state only)
+        hill_ps_eval<double>(c, kap, hard_n, F, dF, t, y1, y2, s1, s2, s4, phi);
+        const double u1 = c.A11 * y1 + c.A12 * y2, u2 = c.A12 * y1 + c.A22 * y2, dgp = kap * i2mu;     // dgam / phi
+        x0[0] = xp[0] + dgp * (u1 * r2 + u2 * r6);
+        x0[3] = xp[3] + dgp * (-u1 * r2 + u2 * r6);
+        x0[5] = xp[5] + dgp * (-2.0 * u2 * r6);
+        x0[1] = xp[1] + dgp * (0.5 * q.a11 * s1);
+        x0[2] = xp[2] + dgp * (0.5 * q.a22 * s2);
+        x0[4] = xp[4] + dgp * (0.5 * q.a44 * s4);
+        x0[6] = c.alpha_p + dgp * phi;
+        x0[7] = 1.0 + t;
+    }
+    return true;
+}
+
 #if defined(CM_HOST_BUILD)
 // host build only (tests): how many points left newton_j2_line / newton_j2_plane for the general path
 inline long long& subspace_fallbacks() { static long long n = 0; return n; }
@@ -1224,7 +1387,10 @@ constexpr bool has_fast_newton() { return has_j2_subspace<DEF, YK, LS>(); }
 // (hosford_warm_start) instead of x_prev.  No kernel variant of their own: the same kernels read the description's switch
 // (warm_start_on, wave-uniform), so CM_SOLVER_REFERENCE_ITERATES costs a branch, not a second set of kernels.
 template <int DEF, int YK>
-constexpr bool has_warm_start() { return CM_HNN_BUILD_HAS_SUBSPACE && DEF == CM_FULL_3D && (YK == CM_YIELD_HILL || YK == CM_YIELD_HOSFORD); }
+constexpr bool has_warm_start() {
+    return CM_HNN_BUILD_HAS_SUBSPACE && ((DEF == CM_FULL_3D && (YK == CM_YIELD_HILL || YK == CM_YIELD_HOSFORD)) ||
+                                         (DEF == CM_PLANE_STRESS && YK == CM_YIELD_HILL));
+}
 CM_D bool warm_start_on(const cm_model_desc& m) {
     return !(m.solver_flags & (CM_SOLVER_GENERAL_NEWTON | CM_SOLVER_REFERENCE_ITERATES)) && !(m.ls_max_evals > 0 && m.ls_kind == CM_LS_LEGACY);
 }
@@ -1256,14 +1422,16 @@ template <int DEF, int YK, bool LS>
 CM_D uint32_t newton_s_warm(const cm_model_desc& m, const double eg[6], const double* z, const double* xp, double* x,
                             bool lane_valid, EvalS<YK>& ev, LaneStage stage = LaneStage{nullptr, 0}) {
     if constexpr (has_warm_start<DEF, YK>()) {
-        double x0[7], n0sq = 0.0;
+        constexpr int NX = Dims<DEF>::NX;
+        double x0[NX], n0sq = 0.0;
         bool warm = false;
         if (warm_start_on(m)) {                                     // uniform
-            if constexpr (YK == CM_YIELD_HILL) warm = hill_warm_start(m, eg, xp, x0, n0sq, lane_valid);
+            if constexpr (DEF == CM_PLANE_STRESS) warm = hill_ps_warm_start(m, eg, z, xp, x0, n0sq, lane_valid);
+            else if constexpr (YK == CM_YIELD_HILL) warm = hill_warm_start(m, eg, xp, x0, n0sq, lane_valid);
             else warm = hosford_warm_start(m, eg, xp, x0, n0sq, lane_valid);
         } else {
 #pragma unroll
-            for (int k = 0; k < 7; ++k) x0[k] = xp[k];
+            for (int k = 0; k < NX; ++k) x0[k] = xp[k];
         }
         return newton_s<YK, LS, DEF>(m, eg, xp, x, lane_valid, ev, stage, z, PlainNorm{}, x0, warm ? n0sq : -1.0);
     }

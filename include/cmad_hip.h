@@ -63,8 +63,9 @@ enum cm_param_index {
 #define CM_SOLVER_J2_RADIAL_LINE 1
 #define CM_SOLVER_GENERAL_NEWTON 2
 /* Warm starts (default on).  Where the backward-Euler equations reduce to a scalar return map or a small benign system -- Hill
- * in FULL_3D (one equation in kappa = 2 mu dgam / phi), J2 in PLANE_STRESS (one equation in g = 3 mu dgam / phi, the stretch
- * eliminated through the sigma_33 row), J2 and Hill in UNIAXIAL_STRESS (the 1-d return map: the stress at the solution is
+ * in FULL_3D (one equation in kappa = 2 mu dgam / phi) and in PLANE_STRESS (the same with the stretch eliminated through the
+ * sigma_33 row, which is linear in it), J2 in PLANE_STRESS (one equation in g = 3 mu dgam / phi, the stretch
+ * eliminated the same way), J2 and Hill in UNIAXIAL_STRESS (the 1-d return map: the stress at the solution is
  * sigma_0 Z^0 and the flow direction a constant), Hosford with a >= 20 in FULL_3D (three equations in log-variables) -- the kernels solve
  * that first (a closed-form first step, two or more Newton steps in single precision as a seed, then double precision to
  * round-off) and START the reference's Newton iteration at its result: the reference's residual is evaluated there and the

@@ -826,7 +826,7 @@ def test_screened_route_classifies_points_at_the_yield_surface_like_the_lockstep
 
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
-@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}), (ol.PLANE_STRESS, "hill", {"hill": pc.HILL}),
                                                     (ol.FULL_3D, "hosford", {"a": 20.0}), (ol.FULL_3D, "hosford", {"a": 64.0}),
                                                     (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
 def test_warm_started_newton_against_the_oracle(backend, def_type, yield_kind, kw, rot, ls):
@@ -836,7 +836,7 @@ def test_warm_started_newton_against_the_oracle(backend, def_type, yield_kind, k
     pc.check_warm_start(backend, def_type, yield_kind, kw, rot, ls, B=4096, uniaxial_idx=2 if rot else 1)
 
 
-@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}), (ol.PLANE_STRESS, "hill", {"hill": pc.HILL}),
                                                     (ol.FULL_3D, "hosford", {"a": 100.0}), (ol.FULL_3D, "hosford", {"a": 20.0}),
                                                     (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
 def test_warm_started_newton_edge_cases(backend, def_type, yield_kind, kw):

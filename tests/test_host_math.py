@@ -648,7 +648,7 @@ def test_plain_newton_through_the_line_search_kernels(def_type, yield_kind, kw, 
 
 @pytest.mark.parametrize("ls", [False, True])
 @pytest.mark.parametrize("rot", [False, True])
-@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}), (ol.PLANE_STRESS, "hill", {"hill": pc.HILL}),
                                                     (ol.FULL_3D, "hosford", {"a": 20.0}), (ol.FULL_3D, "hosford", {"a": 64.0}),
                                                     (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
 def test_warm_started_newton_against_the_oracle(def_type, yield_kind, kw, rot, ls, solver_variant):
@@ -660,7 +660,7 @@ def test_warm_started_newton_against_the_oracle(def_type, yield_kind, kw, rot, l
     pc.check_warm_start(BACKEND, def_type, yield_kind, kw, rot, ls, B=512, uniaxial_idx=2 if rot else 1)
 
 
-@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}),
+@pytest.mark.parametrize("def_type,yield_kind,kw", [(ol.FULL_3D, "hill", {"hill": pc.HILL}), (ol.PLANE_STRESS, "J2", {}), (ol.PLANE_STRESS, "hill", {"hill": pc.HILL}),
                                                     (ol.FULL_3D, "hosford", {"a": 100.0}), (ol.FULL_3D, "hosford", {"a": 20.0}),
                                                     (ol.UNIAXIAL_STRESS, "J2", {}), (ol.UNIAXIAL_STRESS, "hill", {"hill": pc.HILL})])
 def test_warm_started_newton_edge_cases(def_type, yield_kind, kw, solver_variant):

@@ -29,3 +29,5 @@ run --workload hybrid_update_vjp --points 5000000
 run --workload j2_update --def-type uniaxial_stress --points 2000000 --reference-iterates
 run --workload j2_objective_grad --def-type uniaxial_stress --points 2000000
 run --workload j2_update_vjp --def-type uniaxial_stress --yield-surface hill --points 2000000
+run --workload j2_update_vjp --def-type plane_stress --yield-surface hill
+run --workload j2_update_vjp --def-type plane_stress --yield-surface hill --reference-iterates
